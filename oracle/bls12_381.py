@@ -1,0 +1,941 @@
+"""CPU oracle for the BLS12-381 hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product path (ethereum_consensus_amd/ -> libecgpu.so -> HIP kernels) never does.
+
+What it restates
+----------------
+The reference (`/root/reference/ethereum-consensus/src/crypto/bls.rs`) is a thin wrapper over
+the third-party crate `blst` (crates.io, `blst = "0.3.11"`, /root/reference/Cargo.toml:21),
+whose source is NOT in /root/reference.  This file therefore restates the *published*
+algorithms blst implements, in plain Python big-int arithmetic:
+
+  * BLS12-381 curve/tower/pairing (the standard construction; constants SURVEY.md App. B),
+  * ZCash compressed point serialization (flags in the top 3 bits),
+  * RFC 9380 hash_to_curve suite BLS12381G2_XMD:SHA-256_SSWU_RO_ (constants SURVEY.md App. B-2),
+  * IETF draft-irtf-cfrg-bls-signature-05, proof-of-possession scheme, min-pk variant,
+  * the blst `min_pk` API *behaviour* the wrappers rely on (error codes and their order),
+    anchored on the reference call sites crypto/bls.rs:64-160, 279-285, 330-349.
+
+Parity pinning: the oracle is pinned by the reference's own fixed
+vectors -- `test_can_sign` (crypto/bls.rs:530-544), the EIP-2335 pubkey KAT
+(bin/ec/validator/keystores.rs:240-249), the group order (bin/ec/bls.rs:6-7), the infinity
+encodings (crypto/bls.rs:338-343,356-359), the decodable fixtures
+`test_signature_from_good_bytes` / `good_public_key` (crypto/bls.rs:382-395,447-456) and the
+sepolia BlobSidecar signature/commitment bytes (deneb/blob_sidecar.rs:70-105).  See
+tests/test_oracle_bls.py.  Negative/edge verdicts (non-subgroup points, flag rules, error
+order) follow the blst semantics as recalled and are marked [offline-unverified] where the
+blst source would be needed to confirm them: for those the parity claim is
+"parity pinned to the standards, blst edge behaviour unpinned".
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import List, Optional, Sequence, Tuple
+
+# --------------------------------------------------------------------------------------
+# constants
+# --------------------------------------------------------------------------------------
+P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+X_ABS = 0xD201000000010000  # |x|; the curve parameter x is negative
+X = -X_ABS
+assert R == X**4 - X**2 + 1
+assert P == ((X - 1) ** 2 * R) // 3 + X
+
+# blst BLST_ERROR numbering (bindings/blst.h) [offline-unverified numbering, SURVEY 8b]
+BLST_SUCCESS = 0
+BLST_BAD_ENCODING = 1
+BLST_POINT_NOT_ON_CURVE = 2
+BLST_POINT_NOT_IN_GROUP = 3
+BLST_AGGR_TYPE_MISMATCH = 4
+BLST_VERIFY_FAIL = 5
+BLST_PK_IS_INFINITY = 6
+BLST_BAD_SCALAR = 7
+
+DST = b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"  # crypto/bls.rs:22
+
+G1_X = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
+G1_Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+G2_X = (
+    0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+    0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E,
+)
+G2_Y = (
+    0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+    0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE,
+)
+
+# --------------------------------------------------------------------------------------
+# Fp
+# --------------------------------------------------------------------------------------
+
+def fp_inv(a: int) -> int:
+    return pow(a, P - 2, P)
+
+
+def fp_is_square(a: int) -> bool:
+    return a % P == 0 or pow(a, (P - 1) // 2, P) == 1
+
+
+def fp_sqrt(a: int) -> Optional[int]:
+    """p = 3 mod 4: candidate a^((p+1)/4)."""
+    a %= P
+    s = pow(a, (P + 1) // 4, P)
+    return s if s * s % P == a else None
+
+
+# --------------------------------------------------------------------------------------
+# Fp2 = Fp[i]/(i^2+1), elements are tuples (c0, c1)
+# --------------------------------------------------------------------------------------
+Fp2 = Tuple[int, int]
+F2_ZERO: Fp2 = (0, 0)
+F2_ONE: Fp2 = (1, 0)
+XI: Fp2 = (1, 1)  # the sextic non-residue 1+i
+
+
+def f2_add(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+def f2_sub(a, b):
+    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+
+
+def f2_neg(a):
+    return ((-a[0]) % P, (-a[1]) % P)
+
+
+def f2_mul(a, b):
+    a0, a1 = a
+    b0, b1 = b
+    return ((a0 * b0 - a1 * b1) % P, (a0 * b1 + a1 * b0) % P)
+
+
+def f2_sqr(a):
+    a0, a1 = a
+    return ((a0 + a1) * (a0 - a1) % P, 2 * a0 * a1 % P)
+
+
+def f2_muls(a, k: int):
+    return (a[0] * k % P, a[1] * k % P)
+
+
+def f2_conj(a):
+    return (a[0], (-a[1]) % P)
+
+
+def f2_inv(a):
+    a0, a1 = a
+    d = fp_inv((a0 * a0 + a1 * a1) % P)
+    return (a0 * d % P, (-a1) * d % P)
+
+
+def f2_mul_xi(a):
+    # (a0 + a1 i)(1 + i) = (a0 - a1) + (a0 + a1) i
+    return ((a[0] - a[1]) % P, (a[0] + a[1]) % P)
+
+
+def f2_is_zero(a):
+    return a[0] % P == 0 and a[1] % P == 0
+
+
+def f2_pow(a, e: int):
+    r = F2_ONE
+    b = a
+    while e:
+        if e & 1:
+            r = f2_mul(r, b)
+        b = f2_sqr(b)
+        e >>= 1
+    return r
+
+
+def f2_sqrt(a) -> Optional[Fp2]:
+    """Any square root of a in Fp2, or None.  Via the norm (complex method)."""
+    a0, a1 = a[0] % P, a[1] % P
+    if a1 == 0:
+        s = fp_sqrt(a0)
+        if s is not None:
+            return (s, 0)
+        s = fp_sqrt((-a0) % P)  # (s*i)^2 = -s^2
+        assert s is not None
+        return (0, s)
+    n = (a0 * a0 + a1 * a1) % P
+    s = fp_sqrt(n)
+    if s is None:
+        return None
+    inv2 = (P + 1) // 2
+    d = (a0 + s) * inv2 % P
+    x0 = fp_sqrt(d)
+    if x0 is None:
+        d = (a0 - s) * inv2 % P
+        x0 = fp_sqrt(d)
+        if x0 is None:
+            return None
+    x1 = a1 * fp_inv(2 * x0 % P) % P
+    r = (x0, x1)
+    return r if f2_sqr(r) == (a0, a1) else None
+
+
+def f2_sgn0(a) -> int:
+    """RFC 9380 sgn0 for m=2."""
+    a0, a1 = a[0] % P, a[1] % P
+    return (a0 & 1) | ((a0 == 0) & (a1 & 1))
+
+
+def f2_lex_largest(a) -> bool:
+    """ZCash 'lexicographically largest' flag: compare c1 first, then c0."""
+    a0, a1 = a[0] % P, a[1] % P
+    half = (P - 1) // 2
+    if a1 != 0:
+        return a1 > half
+    return a0 > half
+
+
+# --------------------------------------------------------------------------------------
+# Fp6 = Fp2[v]/(v^3 - xi), Fp12 = Fp6[w]/(w^2 - v); elements are nested tuples
+# --------------------------------------------------------------------------------------
+F6_ZERO = (F2_ZERO, F2_ZERO, F2_ZERO)
+F6_ONE = (F2_ONE, F2_ZERO, F2_ZERO)
+F12_ONE = (F6_ONE, F6_ZERO)
+
+
+def f6_add(a, b):
+    return (f2_add(a[0], b[0]), f2_add(a[1], b[1]), f2_add(a[2], b[2]))
+
+
+def f6_sub(a, b):
+    return (f2_sub(a[0], b[0]), f2_sub(a[1], b[1]), f2_sub(a[2], b[2]))
+
+
+def f6_neg(a):
+    return (f2_neg(a[0]), f2_neg(a[1]), f2_neg(a[2]))
+
+
+def f6_mul(a, b):
+    a0, a1, a2 = a
+    b0, b1, b2 = b
+    t0 = f2_mul(a0, b0)
+    t1 = f2_mul(a1, b1)
+    t2 = f2_mul(a2, b2)
+    c0 = f2_add(t0, f2_mul_xi(f2_sub(f2_mul(f2_add(a1, a2), f2_add(b1, b2)), f2_add(t1, t2))))
+    c1 = f2_add(f2_sub(f2_mul(f2_add(a0, a1), f2_add(b0, b1)), f2_add(t0, t1)), f2_mul_xi(t2))
+    c2 = f2_add(f2_sub(f2_mul(f2_add(a0, a2), f2_add(b0, b2)), f2_add(t0, t2)), t1)
+    return (c0, c1, c2)
+
+
+def f6_mul_v(a):
+    """multiply by v: (a0 + a1 v + a2 v^2) v = xi*a2 + a0 v + a1 v^2"""
+    return (f2_mul_xi(a[2]), a[0], a[1])
+
+
+def f6_inv(a):
+    a0, a1, a2 = a
+    c0 = f2_sub(f2_sqr(a0), f2_mul_xi(f2_mul(a1, a2)))
+    c1 = f2_sub(f2_mul_xi(f2_sqr(a2)), f2_mul(a0, a1))
+    c2 = f2_sub(f2_sqr(a1), f2_mul(a0, a2))
+    t = f2_add(f2_mul(a0, c0), f2_mul_xi(f2_add(f2_mul(a2, c1), f2_mul(a1, c2))))
+    ti = f2_inv(t)
+    return (f2_mul(c0, ti), f2_mul(c1, ti), f2_mul(c2, ti))
+
+
+def f12_mul(a, b):
+    a0, a1 = a
+    b0, b1 = b
+    t0 = f6_mul(a0, b0)
+    t1 = f6_mul(a1, b1)
+    c0 = f6_add(t0, f6_mul_v(t1))
+    c1 = f6_sub(f6_mul(f6_add(a0, a1), f6_add(b0, b1)), f6_add(t0, t1))
+    return (c0, c1)
+
+
+def f12_sqr(a):
+    return f12_mul(a, a)
+
+
+def f12_conj(a):
+    return (a[0], f6_neg(a[1]))
+
+
+def f12_inv(a):
+    a0, a1 = a
+    t = f6_sub(f6_mul(a0, a0), f6_mul_v(f6_mul(a1, a1)))
+    ti = f6_inv(t)
+    return (f6_mul(a0, ti), f6_neg(f6_mul(a1, ti)))
+
+
+def f12_pow(a, e: int):
+    r = F12_ONE
+    b = a
+    while e:
+        if e & 1:
+            r = f12_mul(r, b)
+        b = f12_sqr(b)
+        e >>= 1
+    return r
+
+
+# Frobenius: a = sum_{k=0..5} a_k w^k with a_k in Fp2; a^p = sum conj(a_k) * GAMMA[k] * w^k,
+# GAMMA[k] = xi^(k (p-1)/6) (derived, not recalled).  Basis: w^0=1, w^1=w, w^2=v, w^3=vw,
+# w^4=v^2, w^5=v^2 w  ->  c0 = (a0, a2, a4), c1 = (a1, a3, a5).
+GAMMA = [f2_pow(XI, k * (P - 1) // 6) for k in range(6)]
+
+
+def _f12_to_w(a):
+    (a0, a2, a4), (a1, a3, a5) = a
+    return [a0, a1, a2, a3, a4, a5]
+
+
+def _f12_from_w(c):
+    return ((c[0], c[2], c[4]), (c[1], c[3], c[5]))
+
+
+def f12_frob(a, n: int = 1):
+    for _ in range(n):
+        c = _f12_to_w(a)
+        a = _f12_from_w([f2_mul(f2_conj(c[k]), GAMMA[k]) for k in range(6)])
+    return a
+
+
+# --------------------------------------------------------------------------------------
+# curves: E1: y^2 = x^3 + 4 over Fp ; E2: y^2 = x^3 + 4(1+i) over Fp2
+# points are affine tuples (x, y) or None for infinity.  Slow and obvious.
+# --------------------------------------------------------------------------------------
+B1 = 4
+B2: Fp2 = (4, 4)
+G1 = (G1_X, G1_Y)
+G2 = (G2_X, G2_Y)
+
+
+def g1_on_curve(pt) -> bool:
+    if pt is None:
+        return True
+    x, y = pt
+    return (y * y - x * x * x - B1) % P == 0
+
+
+def g1_neg(pt):
+    return None if pt is None else (pt[0], (-pt[1]) % P)
+
+
+def g1_add(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    x1, y1 = a
+    x2, y2 = b
+    if x1 == x2:
+        if (y1 + y2) % P == 0:
+            return None
+        lam = 3 * x1 * x1 * fp_inv(2 * y1 % P) % P
+    else:
+        lam = (y2 - y1) * fp_inv((x2 - x1) % P) % P
+    x3 = (lam * lam - x1 - x2) % P
+    return (x3, (lam * (x1 - x3) - y1) % P)
+
+
+def g1_mul(pt, k: int):
+    if k < 0:
+        return g1_mul(g1_neg(pt), -k)
+    # Jacobian double-and-add for speed; obvious formulas
+    if pt is None or k == 0:
+        return None
+    X1, Y1, Z1 = pt[0], pt[1], 1
+    RX, RY, RZ = 0, 1, 0  # infinity
+    for bit in bin(k)[2:]:
+        RX, RY, RZ = _jac1_dbl(RX, RY, RZ)
+        if bit == "1":
+            RX, RY, RZ = _jac1_add(RX, RY, RZ, X1, Y1, Z1)
+    return _jac1_affine(RX, RY, RZ)
+
+
+def _jac1_dbl(X1, Y1, Z1):
+    if Z1 == 0 or Y1 == 0:
+        return (0, 1, 0)
+    A = X1 * X1 % P
+    B = Y1 * Y1 % P
+    C = B * B % P
+    D = 2 * ((X1 + B) * (X1 + B) - A - C) % P
+    E = 3 * A % P
+    F = E * E % P
+    X3 = (F - 2 * D) % P
+    Y3 = (E * (D - X3) - 8 * C) % P
+    Z3 = 2 * Y1 * Z1 % P
+    return (X3, Y3, Z3)
+
+
+def _jac1_add(X1, Y1, Z1, X2, Y2, Z2):
+    if Z1 == 0:
+        return (X2, Y2, Z2)
+    if Z2 == 0:
+        return (X1, Y1, Z1)
+    Z1Z1 = Z1 * Z1 % P
+    Z2Z2 = Z2 * Z2 % P
+    U1 = X1 * Z2Z2 % P
+    U2 = X2 * Z1Z1 % P
+    S1 = Y1 * Z2 * Z2Z2 % P
+    S2 = Y2 * Z1 * Z1Z1 % P
+    if U1 == U2:
+        if S1 == S2:
+            return _jac1_dbl(X1, Y1, Z1)
+        return (0, 1, 0)
+    H = (U2 - U1) % P
+    Rr = (S2 - S1) % P
+    H2 = H * H % P
+    H3 = H * H2 % P
+    V = U1 * H2 % P
+    X3 = (Rr * Rr - H3 - 2 * V) % P
+    Y3 = (Rr * (V - X3) - S1 * H3) % P
+    Z3 = H * Z1 * Z2 % P
+    return (X3, Y3, Z3)
+
+
+def _jac1_affine(X1, Y1, Z1):
+    if Z1 == 0:
+        return None
+    zi = fp_inv(Z1)
+    zi2 = zi * zi % P
+    return (X1 * zi2 % P, Y1 * zi2 * zi % P)
+
+
+def g1_in_subgroup(pt) -> bool:
+    """Definition: r * P == infinity."""
+    return g1_mul(pt, R) is None
+
+
+def g2_on_curve(pt) -> bool:
+    if pt is None:
+        return True
+    x, y = pt
+    return f2_sub(f2_sqr(y), f2_add(f2_mul(f2_sqr(x), x), B2)) == F2_ZERO
+
+
+def g2_neg(pt):
+    return None if pt is None else (pt[0], f2_neg(pt[1]))
+
+
+def g2_add(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    x1, y1 = a
+    x2, y2 = b
+    if x1 == x2:
+        if f2_is_zero(f2_add(y1, y2)):
+            return None
+        lam = f2_mul(f2_muls(f2_sqr(x1), 3), f2_inv(f2_muls(y1, 2)))
+    else:
+        lam = f2_mul(f2_sub(y2, y1), f2_inv(f2_sub(x2, x1)))
+    x3 = f2_sub(f2_sub(f2_sqr(lam), x1), x2)
+    return (x3, f2_sub(f2_mul(lam, f2_sub(x1, x3)), y1))
+
+
+def _jac2_dbl(T):
+    X1, Y1, Z1 = T
+    if f2_is_zero(Z1) or f2_is_zero(Y1):
+        return (F2_ZERO, F2_ONE, F2_ZERO)
+    A = f2_sqr(X1)
+    B = f2_sqr(Y1)
+    C = f2_sqr(B)
+    D = f2_muls(f2_sub(f2_sub(f2_sqr(f2_add(X1, B)), A), C), 2)
+    E = f2_muls(A, 3)
+    F = f2_sqr(E)
+    X3 = f2_sub(F, f2_muls(D, 2))
+    Y3 = f2_sub(f2_mul(E, f2_sub(D, X3)), f2_muls(C, 8))
+    Z3 = f2_muls(f2_mul(Y1, Z1), 2)
+    return (X3, Y3, Z3)
+
+
+def _jac2_add(T, Q):
+    X1, Y1, Z1 = T
+    X2, Y2, Z2 = Q
+    if f2_is_zero(Z1):
+        return Q
+    if f2_is_zero(Z2):
+        return T
+    Z1Z1 = f2_sqr(Z1)
+    Z2Z2 = f2_sqr(Z2)
+    U1 = f2_mul(X1, Z2Z2)
+    U2 = f2_mul(X2, Z1Z1)
+    S1 = f2_mul(f2_mul(Y1, Z2), Z2Z2)
+    S2 = f2_mul(f2_mul(Y2, Z1), Z1Z1)
+    if U1 == U2:
+        if S1 == S2:
+            return _jac2_dbl(T)
+        return (F2_ZERO, F2_ONE, F2_ZERO)
+    H = f2_sub(U2, U1)
+    Rr = f2_sub(S2, S1)
+    H2 = f2_sqr(H)
+    H3 = f2_mul(H, H2)
+    V = f2_mul(U1, H2)
+    X3 = f2_sub(f2_sub(f2_sqr(Rr), H3), f2_muls(V, 2))
+    Y3 = f2_sub(f2_mul(Rr, f2_sub(V, X3)), f2_mul(S1, H3))
+    Z3 = f2_mul(f2_mul(H, Z1), Z2)
+    return (X3, Y3, Z3)
+
+
+def _jac2_affine(T):
+    X1, Y1, Z1 = T
+    if f2_is_zero(Z1):
+        return None
+    zi = f2_inv(Z1)
+    zi2 = f2_sqr(zi)
+    return (f2_mul(X1, zi2), f2_mul(f2_mul(Y1, zi2), zi))
+
+
+def g2_mul(pt, k: int):
+    if k < 0:
+        return g2_mul(g2_neg(pt), -k)
+    if pt is None or k == 0:
+        return None
+    Q = (pt[0], pt[1], F2_ONE)
+    T = (F2_ZERO, F2_ONE, F2_ZERO)
+    for bit in bin(k)[2:]:
+        T = _jac2_dbl(T)
+        if bit == "1":
+            T = _jac2_add(T, Q)
+    return _jac2_affine(T)
+
+
+def g2_in_subgroup(pt) -> bool:
+    return g2_mul(pt, R) is None
+
+
+# psi endomorphism on E2 (untwist-Frobenius-twist): psi(x,y) = (conj(x)*PSI_X, conj(y)*PSI_Y)
+# with PSI_X = 1/xi^((p-1)/3), PSI_Y = 1/xi^((p-1)/2)  (derived from xi; checked in tests
+# through psi(P) == [p mod r] P on G2).
+PSI_X = f2_inv(f2_pow(XI, (P - 1) // 3))
+PSI_Y = f2_inv(f2_pow(XI, (P - 1) // 2))
+
+
+def g2_psi(pt):
+    if pt is None:
+        return None
+    return (f2_mul(f2_conj(pt[0]), PSI_X), f2_mul(f2_conj(pt[1]), PSI_Y))
+
+
+# --------------------------------------------------------------------------------------
+# ZCash serialization (blst e1.c/e2.c Uncompress_Z semantics [offline-unverified])
+# --------------------------------------------------------------------------------------
+
+def g1_decompress(b: bytes):
+    """48 bytes -> (status, point).  Mirrors blst `PublicKey::from_bytes` on 48-byte input:
+    BAD_ENCODING for missing compression flag / bad infinity / x >= p, POINT_NOT_ON_CURVE when
+    x^3+4 is not a square.  x == 0 (the points (0,+-2), not in G1) is reported by blst's
+    deserializer itself as POINT_NOT_IN_GROUP [offline-unverified]."""
+    assert len(b) == 48
+    b0 = b[0]
+    if not (b0 & 0x80):
+        return BLST_BAD_ENCODING, None
+    if b0 & 0x40:
+        if (b0 & 0x3F) == 0 and not any(b[1:]):
+            return BLST_SUCCESS, None
+        return BLST_BAD_ENCODING, None
+    x = int.from_bytes(bytes([b0 & 0x1F]) + b[1:], "big")
+    if x >= P:
+        return BLST_BAD_ENCODING, None
+    y = fp_sqrt((x * x * x + B1) % P)
+    if y is None:
+        return BLST_POINT_NOT_ON_CURVE, None
+    if (y > (P - 1) // 2) != bool(b0 & 0x20):
+        y = (-y) % P
+    if x == 0:
+        return BLST_POINT_NOT_IN_GROUP, None
+    return BLST_SUCCESS, (x, y)
+
+
+def g1_compress(pt) -> bytes:
+    if pt is None:
+        return bytes([0xC0]) + bytes(47)
+    x, y = pt
+    out = bytearray(x.to_bytes(48, "big"))
+    out[0] |= 0x80
+    if y > (P - 1) // 2:
+        out[0] |= 0x20
+    return bytes(out)
+
+
+def g2_decompress(b: bytes):
+    """96 bytes (x.c1 || x.c0) -> (status, point); on-curve only, no subgroup check
+    (blst `Signature::from_bytes`, reference crypto/bls.rs:330-336)."""
+    assert len(b) == 96
+    b0 = b[0]
+    if not (b0 & 0x80):
+        return BLST_BAD_ENCODING, None
+    if b0 & 0x40:
+        if (b0 & 0x3F) == 0 and not any(b[1:]):
+            return BLST_SUCCESS, None
+        return BLST_BAD_ENCODING, None
+    x1 = int.from_bytes(bytes([b0 & 0x1F]) + b[1:48], "big")
+    x0 = int.from_bytes(b[48:], "big")
+    if x1 >= P or x0 >= P:
+        return BLST_BAD_ENCODING, None
+    x = (x0, x1)
+    y = f2_sqrt(f2_add(f2_mul(f2_sqr(x), x), B2))
+    if y is None:
+        return BLST_POINT_NOT_ON_CURVE, None
+    if f2_lex_largest(y) != bool(b0 & 0x20):
+        y = f2_neg(y)
+    if x == F2_ZERO:
+        return BLST_POINT_NOT_IN_GROUP, None
+    return BLST_SUCCESS, (x, y)
+
+
+def g2_compress(pt) -> bytes:
+    if pt is None:
+        return bytes([0xC0]) + bytes(95)
+    (x0, x1), y = pt
+    out = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+    out[0] |= 0x80
+    if f2_lex_largest(y):
+        out[0] |= 0x20
+    return bytes(out)
+
+
+# --------------------------------------------------------------------------------------
+# RFC 9380 hash_to_curve, suite BLS12381G2_XMD:SHA-256_SSWU_RO_  
+# --------------------------------------------------------------------------------------
+
+def expand_message_xmd(msg: bytes, dst: bytes, len_in_bytes: int) -> bytes:
+    b_in_bytes, s_in_bytes = 32, 64
+    ell = (len_in_bytes + b_in_bytes - 1) // b_in_bytes
+    assert ell <= 255 and len(dst) <= 255
+    dst_prime = dst + bytes([len(dst)])
+    z_pad = bytes(s_in_bytes)
+    l_i_b = len_in_bytes.to_bytes(2, "big")
+    b0 = hashlib.sha256(z_pad + msg + l_i_b + b"\x00" + dst_prime).digest()
+    bi = hashlib.sha256(b0 + b"\x01" + dst_prime).digest()
+    out = bi
+    for i in range(2, ell + 1):
+        bi = hashlib.sha256(bytes(x ^ y for x, y in zip(b0, bi)) + bytes([i]) + dst_prime).digest()
+        out += bi
+    return out[:len_in_bytes]
+
+
+def hash_to_field_fp2(msg: bytes, dst: bytes, count: int = 2) -> List[Fp2]:
+    L = 64
+    u = expand_message_xmd(msg, dst, count * 2 * L)
+    out = []
+    for i in range(count):
+        e = []
+        for j in range(2):
+            off = L * (j + i * 2)
+            e.append(int.from_bytes(u[off : off + L], "big") % P)
+        out.append((e[0], e[1]))
+    return out
+
+
+SSWU_A: Fp2 = (0, 240)
+SSWU_B: Fp2 = (1012, 1012)
+SSWU_Z: Fp2 = (P - 2, P - 1)
+
+
+def map_to_curve_sswu(u: Fp2):
+    """Simplified SWU onto E2' : y^2 = x^3 + A' x + B' (RFC 9380 section 6.6.2, straight-line form)."""
+    tv1 = f2_mul(SSWU_Z, f2_sqr(u))
+    tv2 = f2_add(f2_sqr(tv1), tv1)
+    if f2_is_zero(tv2):
+        x1 = f2_mul(SSWU_B, f2_inv(f2_mul(SSWU_Z, SSWU_A)))
+    else:
+        x1 = f2_mul(f2_mul(f2_neg(SSWU_B), f2_inv(SSWU_A)), f2_add(F2_ONE, f2_inv(tv2)))
+    gx1 = f2_add(f2_add(f2_mul(f2_sqr(x1), x1), f2_mul(SSWU_A, x1)), SSWU_B)
+    y = f2_sqrt(gx1)
+    if y is not None:
+        x = x1
+    else:
+        x = f2_mul(tv1, x1)
+        gx2 = f2_add(f2_add(f2_mul(f2_sqr(x), x), f2_mul(SSWU_A, x)), SSWU_B)
+        y = f2_sqrt(gx2)
+        assert y is not None
+    if f2_sgn0(u) != f2_sgn0(y):
+        y = f2_neg(y)
+    return (x, y)
+
+
+_ISO_A = 0x5C759507E8E333EBB5B7A9A47D7ED8532C52D39FD3A042A88B58423C50AE15D5C2638E343D9C71C6238AAAAAAAA97D6
+_ISO_B = 0x1530477C7AB4113B59A4C18B076D11930F7DA5D4A07F649BF54439D87D27E500FC8C25EBF8C92F6812CFC71C71C6D706
+ISO_XNUM = [
+    (_ISO_A, _ISO_A),
+    (0, 0x11560BF17BAA99BC32126FCED787C88F984F87ADF7AE0C7F9A208C6B4F20A4181472AAA9CB8D555526A9FFFFFFFFC71A),
+    (
+        0x11560BF17BAA99BC32126FCED787C88F984F87ADF7AE0C7F9A208C6B4F20A4181472AAA9CB8D555526A9FFFFFFFFC71E,
+        0x8AB05F8BDD54CDE190937E76BC3E447CC27C3D6FBD7063FCD104635A790520C0A395554E5C6AAAA9354FFFFFFFFE38D,
+    ),
+    (0x171D6541FA38CCFAED6DEA691F5FB614CB14B4E7F4E810AA22D6108F142B85757098E38D0F671C7188E2AAAAAAAA5ED1, 0),
+]
+ISO_XDEN = [(0, P - 0x48), (0xC, P - 0xC), F2_ONE]
+ISO_YNUM = [
+    (_ISO_B, _ISO_B),
+    (0, 0x5C759507E8E333EBB5B7A9A47D7ED8532C52D39FD3A042A88B58423C50AE15D5C2638E343D9C71C6238AAAAAAAA97BE),
+    (
+        0x11560BF17BAA99BC32126FCED787C88F984F87ADF7AE0C7F9A208C6B4F20A4181472AAA9CB8D555526A9FFFFFFFFC71C,
+        0x8AB05F8BDD54CDE190937E76BC3E447CC27C3D6FBD7063FCD104635A790520C0A395554E5C6AAAA9354FFFFFFFFE38F,
+    ),
+    (0x124C9AD43B6CF79BFBF7043DE3811AD0761B0F37A1E26286B0E977C69AA274524E79097A56DC4BD9E1B371C71C718B10, 0),
+]
+ISO_YDEN = [(P - 0x1B0, P - 0x1B0), (0, P - 0xD8), (0x12, P - 0x12), F2_ONE]
+
+
+def _horner(coeffs, x):
+    acc = coeffs[-1]
+    for c in reversed(coeffs[:-1]):
+        acc = f2_add(f2_mul(acc, x), c)
+    return acc
+
+
+def iso3(pt):
+    """3-isogeny E2' -> E2."""
+    x, y = pt
+    xd = _horner(ISO_XDEN, x)
+    yd = _horner(ISO_YDEN, x)
+    if f2_is_zero(xd) or f2_is_zero(yd):
+        return None  # exceptional point maps to infinity
+    xn = _horner(ISO_XNUM, x)
+    yn = _horner(ISO_YNUM, x)
+    return (f2_mul(xn, f2_inv(xd)), f2_mul(y, f2_mul(yn, f2_inv(yd))))
+
+
+H_EFF = 0xBC69F08F2EE75B3584C6A0EA91B352888E2A8E9145AD7689986FF031508FFE1329C2F178731DB956D82BF015D1212B02EC0EC69D7477C1AE954CBC06689F6A359894C0ADEBBF6B4E8020005AAA95551
+
+
+def clear_cofactor_g2(pt):
+    """Definition: multiply by h_eff (RFC 9380 section 8.8.2)."""
+    return g2_mul(pt, H_EFF)
+
+
+def clear_cofactor_g2_fast(pt):
+    """Budroni-Pintore: [x^2 - x - 1]P + [x - 1]psi(P) + psi^2(2P); must equal h_eff*P
+    (checked in tests/test_oracle_bls.py)."""
+    t1 = g2_mul(pt, X)  # [x]P
+    t2 = g2_psi(pt)
+    t3 = g2_psi(g2_psi(g2_add(pt, pt)))  # psi^2(2P)
+    t3 = g2_add(t3, g2_neg(t2))  # psi^2(2P) - psi(P)
+    t2 = g2_add(t1, t2)  # xP + psi(P)
+    t2 = g2_mul(t2, X)  # x^2 P + x psi(P)
+    t3 = g2_add(t3, t2)
+    t3 = g2_add(t3, g2_neg(t1))
+    return g2_add(t3, g2_neg(pt))
+
+
+def hash_to_g2(msg: bytes, dst: bytes = DST, fast: bool = True):
+    u0, u1 = hash_to_field_fp2(msg, dst, 2)
+    q0 = iso3(map_to_curve_sswu(u0))
+    q1 = iso3(map_to_curve_sswu(u1))
+    s = g2_add(q0, q1)
+    return clear_cofactor_g2_fast(s) if fast else clear_cofactor_g2(s)
+
+
+# --------------------------------------------------------------------------------------
+# pairing: optimal ate, Miller loop over |x| on the M-twist, f in Fp12
+# --------------------------------------------------------------------------------------
+
+def _line(lam: Fp2, xT: Fp2, yT: Fp2, Pt):
+    """Line through the untwisted T with slope lam*w^-1, evaluated at P=(xP,yP) in E(Fp) and
+    scaled by w^3 (killed by the final exponentiation):
+        l*w^3 = (lam*xT - yT) + (-lam*xP) w^2 + yP w^3,   w^2 = v, w^3 = v w."""
+    xP, yP = Pt
+    c00 = f2_sub(f2_mul(lam, xT), yT)
+    c01 = f2_muls(f2_neg(lam), xP)
+    return ((c00, c01, F2_ZERO), (F2_ZERO, (yP % P, 0), F2_ZERO))
+
+
+def miller_loop(Pt, Q):
+    """f_{|x|,Q}(P), conjugated because x < 0.  P in E1 affine, Q in E2 affine (twist coords)."""
+    if Pt is None or Q is None:
+        return F12_ONE
+    f = F12_ONE
+    T = Q
+    for bit in bin(X_ABS)[3:]:
+        xT, yT = T
+        lam = f2_mul(f2_muls(f2_sqr(xT), 3), f2_inv(f2_muls(yT, 2)))
+        f = f12_mul(f12_sqr(f), _line(lam, xT, yT, Pt))
+        T = g2_add(T, T)
+        if bit == "1":
+            xT, yT = T
+            lam = f2_mul(f2_sub(Q[1], yT), f2_inv(f2_sub(Q[0], xT)))
+            f = f12_mul(f, _line(lam, xT, yT, Pt))
+            T = g2_add(T, Q)
+    return f12_conj(f)
+
+
+assert 3 * ((P**4 - P**2 + 1) // R) == (X - 1) ** 2 * (X + P) * (X**2 + P**2 - 1) + 3
+
+
+def _cyc_pow_x(a):
+    """a^x for a in the cyclotomic subgroup (inverse == conjugate), x < 0."""
+    return f12_conj(f12_pow(a, X_ABS))
+
+
+def final_exponentiation(f):
+    """f^(3 (p^12-1)/r).  The factor 3 is coprime to r so `== 1` is unaffected; the plain
+    definition is `final_exponentiation_slow`."""
+    # easy part: (p^6 - 1)(p^2 + 1)
+    t = f12_mul(f12_conj(f), f12_inv(f))
+    t = f12_mul(f12_frob(t, 2), t)
+    # hard part: 3*(p^4-p^2+1)/r = (x-1)^2 (x+p)(x^2+p^2-1) + 3
+    a = f12_mul(_cyc_pow_x(t), f12_conj(t))  # t^(x-1)
+    a = f12_mul(_cyc_pow_x(a), f12_conj(a))  # t^((x-1)^2)
+    b = f12_mul(_cyc_pow_x(a), f12_frob(a, 1))  # a^(x+p)
+    c = f12_mul(f12_mul(_cyc_pow_x(_cyc_pow_x(b)), f12_frob(b, 2)), f12_conj(b))  # b^(x^2+p^2-1)
+    return f12_mul(c, f12_mul(f12_sqr(t), t))
+
+
+def final_exponentiation_slow(f):
+    return f12_pow(f, (P**12 - 1) // R)
+
+
+def pairing(Pt, Q):
+    return final_exponentiation(miller_loop(Pt, Q))
+
+
+def pairing_product_is_one(pairs) -> bool:
+    f = F12_ONE
+    for Pt, Q in pairs:
+        f = f12_mul(f, miller_loop(Pt, Q))
+    return final_exponentiation(f) == F12_ONE
+
+
+# --------------------------------------------------------------------------------------
+# key / signature helpers used to *generate* test inputs (SecretKey side of crypto/bls.rs:162-225)
+# --------------------------------------------------------------------------------------
+
+def sk_to_pk(sk: int) -> bytes:
+    return g1_compress(g1_mul(G1, sk % R))
+
+
+def sign(sk: int, msg: bytes) -> bytes:
+    return g2_compress(g2_mul(hash_to_g2(msg), sk % R))
+
+
+# --------------------------------------------------------------------------------------
+# blst min_pk behaviour as used by the reference wrappers -> BLST_ERROR codes
+# --------------------------------------------------------------------------------------
+
+def key_validate(pk: bytes):
+    """blst `PublicKey::key_validate` (reference crypto/bls.rs:279-285): decode, reject infinity,
+    subgroup check."""
+    st, pt = g1_decompress(pk)
+    if st != BLST_SUCCESS:
+        return st, None
+    if pt is None:
+        return BLST_PK_IS_INFINITY, None
+    if not g1_in_subgroup(pt):
+        return BLST_POINT_NOT_IN_GROUP, None
+    return BLST_SUCCESS, pt
+
+
+def sig_from_bytes(sig: bytes):
+    """blst `Signature::from_bytes` (reference crypto/bls.rs:330-336)."""
+    return g2_decompress(sig)
+
+
+def _core_verify(agg_pk, msgs_pts, sig_pt) -> int:
+    """prod e(pk_i, H_i) == e(g1, sig) with signature group check (sig_groupcheck=true).
+    Infinite signatures pass the group check; infinite public keys are rejected."""
+    if sig_pt is not None and not g2_in_subgroup(sig_pt):
+        return BLST_POINT_NOT_IN_GROUP
+    pairs = []
+    for pk_pt, h in zip(agg_pk, msgs_pts):
+        if pk_pt is None:
+            return BLST_PK_IS_INFINITY
+        pairs.append((pk_pt, h))
+    pairs.append((g1_neg(G1), sig_pt))
+    return BLST_SUCCESS if pairing_product_is_one(pairs) else BLST_VERIFY_FAIL
+
+
+def verify_signature(pk: bytes, msg: bytes, sig: bytes) -> int:
+    """reference crypto/bls.rs:64-77.  Returns the first BLST_ERROR met (0 == Ok);
+    codes 1,2,3,6 raised at decode time map to Error::BLST, the rest to InvalidSignature."""
+    st, pk_pt = key_validate(pk)
+    if st:
+        return st
+    st, sig_pt = sig_from_bytes(sig)
+    if st:
+        return st
+    return _core_verify([pk_pt], [hash_to_g2(msg)], sig_pt)
+
+
+def fast_aggregate_verify(pks: Sequence[bytes], msg: bytes, sig: bytes) -> int:
+    """reference crypto/bls.rs:114-132: keys validated left to right (first error wins), then the
+    signature is decoded, then blst fast_aggregate_verify (empty list -> AGGR_TYPE_MISMATCH)."""
+    pts = []
+    for pk in pks:
+        st, pt = key_validate(pk)
+        if st:
+            return st
+        pts.append(pt)
+    st, sig_pt = sig_from_bytes(sig)
+    if st:
+        return st
+    if not pts:
+        return BLST_AGGR_TYPE_MISMATCH
+    agg = None
+    for pt in pts:
+        agg = g1_add(agg, pt)
+    return _core_verify([agg], [hash_to_g2(msg)], sig_pt)
+
+
+INFINITY_SIGNATURE = bytes([0xC0]) + bytes(95)
+INFINITY_PUBLIC_KEY = bytes([0xC0]) + bytes(47)
+
+
+def eth_fast_aggregate_verify(pks: Sequence[bytes], msg: bytes, sig: bytes) -> int:
+    """reference crypto/bls.rs:150-160."""
+    if len(pks) == 0 and sig == INFINITY_SIGNATURE:
+        return BLST_SUCCESS
+    return fast_aggregate_verify(pks, msg, sig)
+
+
+def aggregate_verify(pks: Sequence[bytes], msgs: Sequence[bytes], sig: bytes) -> int:
+    """reference crypto/bls.rs:95-112; blst returns VERIFY_FAIL for n == 0 or a length
+    mismatch [offline-unverified]."""
+    pts = []
+    for pk in pks:
+        st, pt = key_validate(pk)
+        if st:
+            return st
+        pts.append(pt)
+    st, sig_pt = sig_from_bytes(sig)
+    if st:
+        return st
+    if len(pts) == 0 or len(msgs) != len(pts):
+        return BLST_VERIFY_FAIL
+    return _core_verify(pts, [hash_to_g2(m) for m in msgs], sig_pt)
+
+
+EMPTY_AGGREGATE = -100  # Error::EmptyAggregate (crypto/bls.rs:80-82,136-138); not a blst code
+
+
+def aggregate(sigs: Sequence[bytes]):
+    """reference crypto/bls.rs:79-93 -> (status, 96 bytes).  Each signature decoded first
+    (collect::<Result<..>>), then group-checked while summing; infinity is allowed."""
+    if len(sigs) == 0:
+        return EMPTY_AGGREGATE, None
+    pts = []
+    for s in sigs:
+        st, pt = sig_from_bytes(s)
+        if st:
+            return st, None
+        pts.append(pt)
+    acc = None
+    for pt in pts:
+        if pt is not None and not g2_in_subgroup(pt):
+            return BLST_POINT_NOT_IN_GROUP, None
+        acc = g2_add(acc, pt)
+    return BLST_SUCCESS, g2_compress(acc)
+
+
+def eth_aggregate_public_keys(pks: Sequence[bytes]):
+    """reference crypto/bls.rs:135-148 -> (status, 48 bytes)."""
+    if len(pks) == 0:
+        return EMPTY_AGGREGATE, None
+    acc = None
+    for pk in pks:
+        st, pt = key_validate(pk)
+        if st:
+            return st, None
+        acc = g1_add(acc, pt)
+    return BLST_SUCCESS, g1_compress(acc)

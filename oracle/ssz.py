@@ -1,0 +1,430 @@
+"""CPU oracle for SSZ Merkleization -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+The reference's `hash_tree_root` lives in the un-vendored git dependency `ssz_rs` @
+84ef2b71aa004f6767420badb42c902ad56b8b72 (/root/reference/Cargo.toml:20) on top of `sha2`
+0.10.8 (Cargo.toml:23).  Neither is on disk, so this restates the published algorithm they
+implement -- consensus-specs `ssz/simple-serialize.md` -- over
+`hashlib.sha256`, and takes the *type trees* from the reference:
+
+  BeaconBlockHeader  phase0/beacon_block.rs:83-91      Validator   phase0/validator.rs:10-26
+  Fork/ForkData      phase0/beacon_state.rs:15-29      Checkpoint  phase0/operations.rs:13-17
+  Eth1Data           phase0/operations.rs:66-71        SigningData signing.rs:8-12
+  SyncCommittee      altair/sync.rs:17-22              HistoricalSummary capella (phase0/beacon_state.rs:42-45)
+  ExecutionPayloadHeader (deneb)  deneb/execution_payload.rs:48-76
+  BeaconState (deneb)             deneb/beacon_state.rs:13-64
+  presets            phase0/presets/{mainnet,minimal}.rs, altair/presets/mainnet.rs:19,
+                     bellatrix/presets/mainnet.rs:23-24
+
+Pinned (tests/test_oracle_ssz.py) by the reference's offline fixtures: the sepolia BlobSidecar
+inclusion proof (deneb/blob_sidecar.rs:70-132: htr(ByteVector<48>) + 17-deep branch, which
+contains Z0..Z3 and a length mix-in chunk) and the generalized indices of
+deneb/beacon_block.rs:139-154.
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import List, Sequence
+
+BYTES_PER_CHUNK = 32
+
+
+def hash64(a: bytes, b: bytes) -> bytes:
+    return hashlib.sha256(a + b).digest()
+
+
+ZERO_HASHES: List[bytes] = [bytes(32)]
+for _ in range(64):
+    ZERO_HASHES.append(hash64(ZERO_HASHES[-1], ZERO_HASHES[-1]))
+
+
+def _depth_for(limit: int) -> int:
+    return 0 if limit <= 1 else (limit - 1).bit_length()
+
+
+def merkleize_chunks(chunks: Sequence[bytes], limit: int | None = None) -> bytes:
+    """Appendix A `merkleize`: virtual zero padding to next_pow2(limit); odd tails pair with Z_d."""
+    n = len(chunks)
+    if limit is None:
+        limit = n
+    assert n <= max(limit, 0) or (limit == 0 and n == 0), (n, limit)
+    depth = _depth_for(limit)
+    if n == 0:
+        return ZERO_HASHES[depth]
+    layer = list(chunks)
+    for d in range(depth):
+        if len(layer) & 1:
+            layer.append(ZERO_HASHES[d])
+        layer = [hash64(layer[i], layer[i + 1]) for i in range(0, len(layer), 2)]
+    assert len(layer) == 1
+    return layer[0]
+
+
+def merkleize_bytes(data: bytes, limit_chunks: int | None = None) -> bytes:
+    """`pack` (right-pad to 32) then merkleize."""
+    if len(data) % 32:
+        data = data + bytes(32 - len(data) % 32)
+    chunks = [data[i : i + 32] for i in range(0, len(data), 32)]
+    return merkleize_chunks(chunks, limit_chunks)
+
+
+def mix_in_length(root: bytes, length: int) -> bytes:
+    return hash64(root, length.to_bytes(32, "little"))
+
+
+def is_valid_merkle_branch(leaf: bytes, branch: Sequence[bytes], depth: int, index: int, root: bytes) -> bool:
+    """Appendix A; argument order as at phase0/block_processing.rs:433."""
+    v = leaf
+    for i in range(depth):
+        if (index >> i) & 1:
+            v = hash64(branch[i], v)
+        else:
+            v = hash64(v, branch[i])
+    return v == root
+
+
+def hash64_count(n_chunks: int, limit: int) -> int:
+    """Number of hash64 the merkleize above performs (for work accounting in bench.py)."""
+    depth = _depth_for(limit)
+    if n_chunks == 0:
+        return 0
+    c, total = n_chunks, 0
+    for _ in range(depth):
+        c = (c + 1) // 2
+        total += c
+    return total
+
+
+# --------------------------------------------------------------------------------------
+# a tiny SSZ type system: every type has serialize(v) -> bytes and htr(v) -> 32 bytes
+# --------------------------------------------------------------------------------------
+class SSZType:
+    fixed_size: int | None = None
+
+    def serialize(self, v) -> bytes:  # pragma: no cover
+        raise NotImplementedError
+
+    def htr(self, v) -> bytes:  # pragma: no cover
+        raise NotImplementedError
+
+    def default(self):  # pragma: no cover
+        raise NotImplementedError
+
+
+class UInt(SSZType):
+    def __init__(self, bits: int):
+        self.bits = bits
+        self.fixed_size = bits // 8
+
+    def serialize(self, v):
+        return int(v).to_bytes(self.fixed_size, "little")
+
+    def htr(self, v):
+        return self.serialize(v).ljust(32, b"\0")
+
+    def default(self):
+        return 0
+
+
+class Boolean(SSZType):
+    fixed_size = 1
+
+    def serialize(self, v):
+        return b"\x01" if v else b"\x00"
+
+    def htr(self, v):
+        return self.serialize(v).ljust(32, b"\0")
+
+    def default(self):
+        return False
+
+
+uint8, uint64, uint256, boolean = UInt(8), UInt(64), UInt(256), Boolean()
+
+
+class ByteVector(SSZType):
+    def __init__(self, n: int):
+        self.n = n
+        self.fixed_size = n
+
+    def serialize(self, v):
+        assert len(v) == self.n
+        return bytes(v)
+
+    def htr(self, v):
+        return merkleize_bytes(self.serialize(v), (self.n + 31) // 32)
+
+    def default(self):
+        return bytes(self.n)
+
+
+class ByteList(SSZType):
+    def __init__(self, limit: int):
+        self.limit = limit
+
+    def serialize(self, v):
+        assert len(v) <= self.limit
+        return bytes(v)
+
+    def htr(self, v):
+        return mix_in_length(merkleize_bytes(bytes(v), (self.limit + 31) // 32), len(v))
+
+    def default(self):
+        return b""
+
+
+Bytes32 = ByteVector(32)
+Root = Bytes32
+
+
+class Vector(SSZType):
+    def __init__(self, elem: SSZType, n: int):
+        self.elem, self.n = elem, n
+        if elem.fixed_size is not None:
+            self.fixed_size = elem.fixed_size * n
+
+    def serialize(self, v):
+        assert len(v) == self.n
+        return b"".join(self.elem.serialize(x) for x in v)
+
+    def htr(self, v):
+        assert len(v) == self.n
+        if isinstance(self.elem, (UInt, Boolean)):
+            return merkleize_bytes(self.serialize(v), (self.n * self.elem.fixed_size + 31) // 32)
+        return merkleize_chunks([self.elem.htr(x) for x in v], self.n)
+
+    def default(self):
+        return [self.elem.default() for _ in range(self.n)]
+
+
+class SSZList(SSZType):
+    def __init__(self, elem: SSZType, limit: int):
+        self.elem, self.limit = elem, limit
+
+    def serialize(self, v):
+        assert self.elem.fixed_size is not None, "variable-size list elements not needed on this path"
+        return b"".join(self.elem.serialize(x) for x in v)
+
+    def htr(self, v):
+        assert len(v) <= self.limit
+        if isinstance(self.elem, (UInt, Boolean)):
+            lim = (self.limit * self.elem.fixed_size + 31) // 32
+            return mix_in_length(merkleize_bytes(self.serialize(v), lim), len(v))
+        return mix_in_length(merkleize_chunks([self.elem.htr(x) for x in v], self.limit), len(v))
+
+    def default(self):
+        return []
+
+
+class Bitvector(SSZType):
+    def __init__(self, n: int):
+        self.n = n
+        self.fixed_size = (n + 7) // 8
+
+    def serialize(self, v):
+        assert len(v) == self.n
+        out = bytearray(self.fixed_size)
+        for i, b in enumerate(v):
+            if b:
+                out[i // 8] |= 1 << (i % 8)
+        return bytes(out)
+
+    def htr(self, v):
+        return merkleize_bytes(self.serialize(v), (self.n + 255) // 256)
+
+    def default(self):
+        return [False] * self.n
+
+
+class Bitlist(SSZType):
+    def __init__(self, limit: int):
+        self.limit = limit
+
+    def htr(self, v):
+        out = bytearray((len(v) + 7) // 8)
+        for i, b in enumerate(v):
+            if b:
+                out[i // 8] |= 1 << (i % 8)
+        return mix_in_length(merkleize_bytes(bytes(out), (self.limit + 255) // 256), len(v))
+
+    def default(self):
+        return []
+
+
+class Container(SSZType):
+    def __init__(self, name: str, fields: Sequence[tuple]):
+        self.name = name
+        self.fields = list(fields)
+        if all(t.fixed_size is not None for _, t in self.fields):
+            self.fixed_size = sum(t.fixed_size for _, t in self.fields)
+
+    def serialize(self, v):
+        assert self.fixed_size is not None, "only fixed-size containers are serialized on this path"
+        return b"".join(t.serialize(v[n]) for n, t in self.fields)
+
+    def htr(self, v):
+        return merkleize_chunks([t.htr(v[n]) for n, t in self.fields], len(self.fields))
+
+    def field_roots(self, v):
+        return [t.htr(v[n]) for n, t in self.fields]
+
+    def default(self):
+        return {n: t.default() for n, t in self.fields}
+
+    def generalized_index(self, path: Sequence) -> int:
+        """ssz_rs `generalized_index` for the paths exercised at deneb/beacon_block.rs:139-154."""
+        g, typ = 1, self
+        for p in path:
+            if isinstance(typ, Container):
+                names = [n for n, _ in typ.fields]
+                i = names.index(p)
+                width = 1 << _depth_for(len(names))
+                g = g * width + i
+                typ = typ.fields[i][1]
+            elif isinstance(typ, SSZList):
+                g = g * 2  # data subtree (length is the right child)
+                chunks = typ.limit if not isinstance(typ.elem, (UInt, Boolean)) else (typ.limit * typ.elem.fixed_size + 31) // 32
+                width = 1 << _depth_for(chunks)
+                g = g * width + int(p)
+                typ = typ.elem
+            elif isinstance(typ, Vector):
+                width = 1 << _depth_for(typ.n)
+                g = g * width + int(p)
+                typ = typ.elem
+            else:
+                raise TypeError(typ)
+        return g
+
+
+# --------------------------------------------------------------------------------------
+# the reference's type trees on the hot path
+# --------------------------------------------------------------------------------------
+BlsPublicKey = ByteVector(48)
+BlsSignature = ByteVector(96)
+Version = ByteVector(4)
+ExecutionAddress = ByteVector(20)
+
+SigningData = Container("SigningData", [("object_root", Root), ("domain", Bytes32)])
+ForkData = Container("ForkData", [("current_version", Version), ("genesis_validators_root", Root)])
+Fork = Container("Fork", [("previous_version", Version), ("current_version", Version), ("epoch", uint64)])
+Checkpoint = Container("Checkpoint", [("epoch", uint64), ("root", Root)])
+Eth1Data = Container("Eth1Data", [("deposit_root", Root), ("deposit_count", uint64), ("block_hash", Bytes32)])
+BeaconBlockHeader = Container(
+    "BeaconBlockHeader",
+    [("slot", uint64), ("proposer_index", uint64), ("parent_root", Root), ("state_root", Root), ("body_root", Root)],
+)
+AttestationData = Container(
+    "AttestationData",
+    [("slot", uint64), ("index", uint64), ("beacon_block_root", Root), ("source", Checkpoint), ("target", Checkpoint)],
+)
+Validator = Container(
+    "Validator",
+    [
+        ("public_key", BlsPublicKey),
+        ("withdrawal_credentials", Bytes32),
+        ("effective_balance", uint64),
+        ("slashed", boolean),
+        ("activation_eligibility_epoch", uint64),
+        ("activation_epoch", uint64),
+        ("exit_epoch", uint64),
+        ("withdrawable_epoch", uint64),
+    ],
+)
+assert Validator.fixed_size == 121 and BeaconBlockHeader.fixed_size == 112
+DepositMessage = Container("DepositMessage", [("public_key", BlsPublicKey), ("withdrawal_credentials", Bytes32), ("amount", uint64)])
+DepositData = Container(
+    "DepositData",
+    [("public_key", BlsPublicKey), ("withdrawal_credentials", Bytes32), ("amount", uint64), ("signature", BlsSignature)],
+)
+HistoricalSummary = Container("HistoricalSummary", [("block_summary_root", Root), ("state_summary_root", Root)])
+
+
+def SyncCommittee(size: int) -> Container:
+    return Container("SyncCommittee", [("public_keys", Vector(BlsPublicKey, size)), ("aggregate_public_key", BlsPublicKey)])
+
+
+def ExecutionPayloadHeaderDeneb(bytes_per_logs_bloom: int = 256, max_extra_data_bytes: int = 32) -> Container:
+    return Container(
+        "ExecutionPayloadHeader",
+        [
+            ("parent_hash", Bytes32),
+            ("fee_recipient", ExecutionAddress),
+            ("state_root", Bytes32),
+            ("receipts_root", Bytes32),
+            ("logs_bloom", ByteVector(bytes_per_logs_bloom)),
+            ("prev_randao", Bytes32),
+            ("block_number", uint64),
+            ("gas_limit", uint64),
+            ("gas_used", uint64),
+            ("timestamp", uint64),
+            ("extra_data", ByteList(max_extra_data_bytes)),
+            ("base_fee_per_gas", uint256),
+            ("block_hash", Bytes32),
+            ("transactions_root", Root),
+            ("withdrawals_root", Root),
+            ("blob_gas_used", uint64),
+            ("excess_blob_gas", uint64),
+        ],
+    )
+
+
+class Preset:
+    def __init__(self, name, slots_per_historical_root, historical_roots_limit, eth1_data_votes_bound,
+                 validator_registry_limit, epochs_per_historical_vector, epochs_per_slashings_vector,
+                 sync_committee_size):
+        self.name = name
+        self.SLOTS_PER_HISTORICAL_ROOT = slots_per_historical_root
+        self.HISTORICAL_ROOTS_LIMIT = historical_roots_limit
+        self.ETH1_DATA_VOTES_BOUND = eth1_data_votes_bound
+        self.VALIDATOR_REGISTRY_LIMIT = validator_registry_limit
+        self.EPOCHS_PER_HISTORICAL_VECTOR = epochs_per_historical_vector
+        self.EPOCHS_PER_SLASHINGS_VECTOR = epochs_per_slashings_vector
+        self.SYNC_COMMITTEE_SIZE = sync_committee_size
+
+
+# phase0/presets/mainnet.rs:7-36,82-84 ; altair/presets/mainnet.rs:19 ; minimal.rs equivalents
+MAINNET = Preset("mainnet", 8192, 1 << 24, 2048, 1 << 40, 65536, 8192, 512)
+MINIMAL = Preset("minimal", 64, 1 << 24, 32, 1 << 40, 64, 64, 32)
+
+
+def BeaconStateDeneb(p: Preset) -> Container:
+    """deneb/beacon_state.rs:25-63, 28 fields."""
+    return Container(
+        "BeaconState",
+        [
+            ("genesis_time", uint64),
+            ("genesis_validators_root", Root),
+            ("slot", uint64),
+            ("fork", Fork),
+            ("latest_block_header", BeaconBlockHeader),
+            ("block_roots", Vector(Root, p.SLOTS_PER_HISTORICAL_ROOT)),
+            ("state_roots", Vector(Root, p.SLOTS_PER_HISTORICAL_ROOT)),
+            ("historical_roots", SSZList(Root, p.HISTORICAL_ROOTS_LIMIT)),
+            ("eth1_data", Eth1Data),
+            ("eth1_data_votes", SSZList(Eth1Data, p.ETH1_DATA_VOTES_BOUND)),
+            ("eth1_deposit_index", uint64),
+            ("validators", SSZList(Validator, p.VALIDATOR_REGISTRY_LIMIT)),
+            ("balances", SSZList(uint64, p.VALIDATOR_REGISTRY_LIMIT)),
+            ("randao_mixes", Vector(Bytes32, p.EPOCHS_PER_HISTORICAL_VECTOR)),
+            ("slashings", Vector(uint64, p.EPOCHS_PER_SLASHINGS_VECTOR)),
+            ("previous_epoch_participation", SSZList(uint8, p.VALIDATOR_REGISTRY_LIMIT)),
+            ("current_epoch_participation", SSZList(uint8, p.VALIDATOR_REGISTRY_LIMIT)),
+            ("justification_bits", Bitvector(4)),
+            ("previous_justified_checkpoint", Checkpoint),
+            ("current_justified_checkpoint", Checkpoint),
+            ("finalized_checkpoint", Checkpoint),
+            ("inactivity_scores", SSZList(uint64, p.VALIDATOR_REGISTRY_LIMIT)),
+            ("current_sync_committee", SyncCommittee(p.SYNC_COMMITTEE_SIZE)),
+            ("next_sync_committee", SyncCommittee(p.SYNC_COMMITTEE_SIZE)),
+            ("latest_execution_payload_header", ExecutionPayloadHeaderDeneb()),
+            ("next_withdrawal_index", uint64),
+            ("next_withdrawal_validator_index", uint64),
+            ("historical_summaries", SSZList(HistoricalSummary, p.HISTORICAL_ROOTS_LIMIT)),
+        ],
+    )
+
+
+def compute_signing_root(obj_type: SSZType, obj, domain: bytes) -> bytes:
+    """signing.rs:14-22."""
+    return SigningData.htr({"object_root": obj_type.htr(obj), "domain": domain})

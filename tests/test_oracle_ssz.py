@@ -1,0 +1,121 @@
+"""Pins oracle/ssz.py against the reference's offline fixtures."""
+import hashlib
+
+from oracle import ssz
+
+# sepolia BlobSidecar, /root/reference/ethereum-consensus/src/deneb/blob_sidecar.rs:70-105
+KZG_COMMITMENT = bytes.fromhex(
+    "8da04bbe26b2bbc6b042f4db18a36f1b4714123706065ed3946a3c3aeb681f98d3e67a3483b088612cb9b0c5322723a0")
+BODY_ROOT = bytes.fromhex("940ebac04b768dab430d21b4b2d7ecd5d3f87e0486293a5612c16b9e8d4c078a")
+PROOF = [bytes.fromhex(h) for h in [
+    "0000000000000000000000000000000000000000000000000000000000000000",
+    "f5a5fd42d16a20302798ef6ed309979b43003d2320d9f0e8ea9831a92759fb4b",
+    "db56114e00fdd4c1f85c892bf35ac9a89289aaecb1ebd0a96cde606a748b5d71",
+    "c78009fdf07fc56a11f122370658a353aaa542ed63e44c4bc15ff4cd105ab33c",
+    "536d98837f2dd165a55d5eeae91485954472d56f246df256bf3cae19352a123c",
+    "9efde052aa15429fae05bad4d0b1d7c64da64d03d7a1854a588c2cb8430c0d30",
+    "d88ddfeed400a8755596b21942c1497e114c302e6118290f91e6772976041fa1",
+    "87eb0ddba57e35f6d286673802a4af5975e22506c7cf4c64bb6be5ee11527f2c",
+    "26846476fd5fc54a5d43385167c95144f2643f533cc85bb9d16b782f8d7db193",
+    "506d86582d252405b840018792cad2bf1259f1ef5aa5f887e13cb2f0094f51e1",
+    "ffff0ad7e659772f9534c195c815efc4014ef1e1daed4404c06385d11192e92b",
+    "6cf04127db05441cd833107a52be852868890e4317e6a02ab47683aa75964220",
+    "0100000000000000000000000000000000000000000000000000000000000000",
+    "792930bbd5baac43bcc798ee49aa8185ef76bb3b44ba62b91d86ae569e4bb535",
+    "818d8d71c18b108e28500c2bd5bb946069c5877a512a699cdd8a40b90aaf44ca",
+    "db56114e00fdd4c1f85c892bf35ac9a89289aaecb1ebd0a96cde606a748b5d71",
+    "d130f52a1da1e28d4a38d8f4b89a0f0c3f047e7d9935408aef8efc3bc0930c13",
+]]
+HEADER = {
+    "slot": 4659411, "proposer_index": 301,
+    "parent_root": bytes.fromhex("285d29372101b50d993ecafd80ccced44e6a8ce153553bb47c97b71e255c3cd6"),
+    "state_root": bytes.fromhex("f8eccd3ab5db7ffdb19923b27a6531fb4e95824e1a02c11f945b38e6ae0837c2"),
+    "body_root": BODY_ROOT,
+}
+
+# a stand-in for deneb BeaconBlockBody: only field names/positions matter for generalized indices
+BODY_FIELDS = ["randao_reveal", "eth1_data", "graffiti", "proposer_slashings", "attester_slashings", "attestations",
+               "deposits", "voluntary_exits", "sync_aggregate", "execution_payload", "bls_to_execution_changes",
+               "blob_kzg_commitments"]
+BeaconBlockBody = ssz.Container("BeaconBlockBody", [
+    (n, ssz.SSZList(ssz.BlsPublicKey, 4096) if n == "blob_kzg_commitments" else ssz.Root) for n in BODY_FIELDS])
+
+
+def test_zero_hashes_match_fixture():
+    # the proof literally contains Z0..Z3 (blob_sidecar.rs:88-91) and Z2 again at depth 15
+    for d in range(4):
+        assert ssz.ZERO_HASHES[d] == PROOF[d]
+    assert ssz.ZERO_HASHES[2] == PROOF[15]
+
+
+def test_generalized_indices():
+    # deneb/beacon_block.rs:139-154
+    got = [BeaconBlockBody.generalized_index(["blob_kzg_commitments"])]
+    got += [BeaconBlockBody.generalized_index(["blob_kzg_commitments", i]) for i in range(6)]
+    assert got == [27, 221184, 221185, 221186, 221187, 221188, 221189]
+
+
+def test_blob_sidecar_inclusion_proof():
+    # deneb/blob_sidecar.rs:47-64,108-132
+    g = BeaconBlockBody.generalized_index(["blob_kzg_commitments", 0])
+    depth = 17
+    subtree_index = g % (1 << depth)
+    leaf = ssz.BlsPublicKey.htr(KZG_COMMITMENT)
+    assert leaf == hashlib.sha256(KZG_COMMITMENT[:32] + KZG_COMMITMENT[32:] + bytes(16)).digest()
+    assert ssz.is_valid_merkle_branch(leaf, PROOF, depth, subtree_index, BODY_ROOT)
+    assert not ssz.is_valid_merkle_branch(leaf, PROOF, depth, subtree_index ^ 1, BODY_ROOT)
+    # the length mix-in chunk of the commitments list sits at depth 12 (blob_sidecar.rs:100)
+    assert PROOF[12] == (1).to_bytes(32, "little")
+
+
+def test_header_root_is_container_merkleization():
+    # config 1 input (blob_sidecar.rs:78-84): 5 leaves padded to 8
+    leaves = [ssz.uint64.htr(HEADER["slot"]), ssz.uint64.htr(HEADER["proposer_index"]), HEADER["parent_root"],
+              HEADER["state_root"], HEADER["body_root"]]
+    h = lambda a, b: hashlib.sha256(a + b).digest()
+    z = bytes(32)
+    want = h(h(h(leaves[0], leaves[1]), h(leaves[2], leaves[3])), h(h(leaves[4], z), h(z, z)))
+    assert ssz.BeaconBlockHeader.htr(HEADER) == want
+    assert want.hex().startswith("3a251ef7")  # value recorded in SURVEY.md 8c(8)
+
+
+def test_merkleize_limits_and_mixin():
+    h = lambda a, b: hashlib.sha256(a + b).digest()
+    c = [bytes([i]) * 32 for i in range(3)]
+    assert ssz.merkleize_chunks([], 0) == bytes(32)
+    assert ssz.merkleize_chunks([], 8) == ssz.ZERO_HASHES[3]
+    assert ssz.merkleize_chunks(c[:1], 1) == c[0]
+    assert ssz.merkleize_chunks(c, 4) == h(h(c[0], c[1]), h(c[2], bytes(32)))
+    assert ssz.merkleize_chunks(c, 8) == h(h(h(c[0], c[1]), h(c[2], bytes(32))), ssz.ZERO_HASHES[2])
+    assert ssz.SSZList(ssz.uint64, 8).htr([1, 2, 3, 4, 5]) == h(
+        h((1).to_bytes(8, "little") + (2).to_bytes(8, "little") + (3).to_bytes(8, "little") + (4).to_bytes(8, "little"),
+          (5).to_bytes(8, "little").ljust(32, b"\0")), (5).to_bytes(32, "little"))
+    assert ssz.hash64_count(3, 8) == 2 + 1 + 1
+    assert ssz.hash64_count(1 << 20, 1 << 40) == (1 << 20) - 1 + 20
+
+
+def test_validator_root_shape():
+    v = ssz.Validator.default()
+    v["public_key"] = bytes(range(48))
+    v["effective_balance"] = 32 * 10**9
+    v["slashed"] = True
+    ser = ssz.Validator.serialize(v)
+    assert len(ser) == 121
+    h = lambda a, b: hashlib.sha256(a + b).digest()
+    pk_root = h(ser[0:32], ser[32:48] + bytes(16))
+    leaves = [pk_root, ser[48:80], ser[80:88].ljust(32, b"\0"), ser[88:89].ljust(32, b"\0")] + [
+        ser[89 + 8 * i: 97 + 8 * i].ljust(32, b"\0") for i in range(4)]
+    want = h(h(h(leaves[0], leaves[1]), h(leaves[2], leaves[3])), h(h(leaves[4], leaves[5]), h(leaves[6], leaves[7])))
+    assert ssz.Validator.htr(v) == want
+
+
+def test_default_state_roots_both_presets():
+    for p in (ssz.MINIMAL, ssz.MAINNET):
+        t = ssz.BeaconStateDeneb(p)
+        assert len(t.fields) == 28
+        s = t.default()
+        r = t.htr(s)
+        assert len(r) == 32
+        # validators: empty list -> Z_40 mixed with 0
+        i = [n for n, _ in t.fields].index("validators")
+        assert t.field_roots(s)[i] == hashlib.sha256(ssz.ZERO_HASHES[40] + bytes(32)).digest()
