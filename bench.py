@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- the two hot paths on MI355X, one JSON line (contract: see README / DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W [--workload bls|merkle]
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+  bls    : fast_aggregate_verify of 65 536 (pk, msg, sig) tuples  (BASELINE.json configs[1])
+  merkle : hash_tree_root(BeaconState), deneb mainnet, 2^20 validators (configs[2])
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank processes its own shard
+of the same size (weak scaling); the only collective is the RCCL all-gather of the per-shard
+verify status bytes (bls) / of the 32-byte roots (merkle).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s, 6.29 measured copy)
+INT_VALU_PEAK_TOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, full-rate 32-bit integer ops
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("ECGPU_BENCH_WORKLOAD", "auto"))
+    ap.add_argument("--validators", type=int, default=1 << 20)
+    ap.add_argument("--tuples", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline_merkle(n_validators: int):
+    """oracle/c restatement (SHA-NI when the host has it) on one host core: htr(List<Validator>)
+    of the same registry -- 93 % of the state's hash64.  Reported, never the target."""
+    from oracle import cref
+    from ethereum_consensus_amd import synthetic as S
+    enc = S.validators(n_validators).tobytes()
+    best = None
+    hashes = 0
+    t_total = time.time()
+    reps = 0
+    while reps < 3 or (time.time() - t_total < 10 and reps < 12):
+        t = time.time()
+        _, hashes = cref.htr_validators(enc)
+        dt = time.time() - t
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    return {"value": hashes / best, "unit": "leaves/s", "cores": 1, "kind": "port",
+            "sample": f"htr(List<Validator,2^40>) of the same {n_validators} validators ({hashes} hash64), "
+                      f"oracle/c/sha256_merkle.c, sha_ni={int(cref.lib().oc_have_shani())}, best of {reps}"}
+
+
+def run_merkle(args, L, torch, dist, rank, world):
+    from ethereum_consensus_amd import synthetic as S
+    n = args.validators
+    enc = S.beacon_state_deneb(n, "mainnet", seed=1 + rank)
+    fixed = int(L.ecgpu_beacon_state_deneb_fixed_size(0))
+    h_fixed = ctypes.create_string_buffer(enc[:fixed], fixed)
+    import numpy as np
+    d_state = torch.from_numpy(np.frombuffer(enc, dtype=np.uint8).copy()).cuda()
+    d_root = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        rc = L.ecgpu_htr_beacon_state_deneb_dev(d_state.data_ptr(), len(enc), h_fixed, 0, d_root.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(f"ecgpu_htr_beacon_state_deneb_dev -> {rc}: {L.ecgpu_last_error()}")
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    hashes = int(L.ecgpu_last_hash64_count())
+    dom = b"merkle_pass_validators"
+    L.ecgpu_prof_filter(dom)
+    L.ecgpu_prof_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        # the path's only exchange: every rank learns every shard's root
+        roots = [torch.empty_like(d_root) for _ in range(world)]
+        dist.all_gather(roots, d_root)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ms = ctypes.c_double(0)
+    nl = ctypes.c_uint64(0)
+    L.ecgpu_prof_read(dom, ctypes.byref(ms), ctypes.byref(nl))
+    L.ecgpu_prof_enable(0)
+    kern_ms = ms.value / max(nl.value, 1)
+    # algorithmic bytes of the dominant kernel per launch: 121 B read per validator + one
+    # 32-byte node written per lane (2^D validators per lane, D from the schedule)
+    lanes = n >> max(1, min(6, n.bit_length() - 1 - 18))
+    alg_bytes = 121 * n + 32 * lanes
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    val_hashes = 8 * n + (n - lanes)  # hash64 executed inside the dominant kernel
+    return dict(
+        dt=dt, units_per_step=hashes, metric="merkle_leaves_hashed_per_sec", unit="leaves/s", dtype="u32",
+        config={"workload": f"hash_tree_root(BeaconState) deneb mainnet, {n} validators, SSZ-encoded state "
+                            f"({len(enc)} B) resident in HBM", "hash64_per_state": hashes, "state_bytes": len(enc),
+                "sharding": "one independent state per GPU; all-gather of the 32-byte roots"},
+        roofline={"bound": "hbm", "kernel": "k_merkle_pass<ValidatorLeaves>", "achieved": achieved,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                  "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches_timed": int(nl.value),
+                  "valu_int": {"achieved_Tops": val_hashes * 2410 / (kern_ms * 1e-3) / 1e12 if kern_ms else 0.0,
+                               "peak_Tops": INT_VALU_PEAK_TOPS,
+                               "note": "2410 VALU instructions per hash64 (ISA count of ecg::hash64)"}},
+        root=bytes(d_root.cpu().numpy()).hex(),
+    )
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible: bench.py measures the HIP path only"}))
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    from ethereum_consensus_amd import _lib
+    L = _lib.load(build_if_missing=False)
+    rc = L.ecgpu_init(local)
+    if rc != 0:
+        raise RuntimeError(f"ecgpu_init -> {rc}: {L.ecgpu_last_error()}")
+    workload = args.workload
+    if workload == "auto":
+        workload = "merkle"
+    if workload == "merkle":
+        r = run_merkle(args, L, torch, dist, rank, world)
+    else:
+        raise SystemExit("unknown workload " + workload)
+    # max over ranks
+    dt = r["dt"]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        total_units = r["units_per_step"] * args.steps * world
+        line = {
+            "metric": r["metric"], "value": total_units / dt, "unit": r["unit"], "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": r["dtype"],
+            "data": "synthetic", "config": r["config"], "roofline": r["roofline"],
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_merkle(args.validators) if workload == "merkle" else None
+        line["check"] = {"root": r.get("root")}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""Build libecgpu.so (gfx950 only) and the test-side helpers.
+
+    python -m ethereum_consensus_amd.build            # product library
+    python -m ethereum_consensus_amd.build --hostsim  # + tests/hostsim kernel simulator (g++)
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects are cached by source mtime so that an
+edit to one .hip rebuilds one object.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libecgpu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _headers():
+    out = [os.path.join(ROOT, "include", "ecgpu.h")]
+    for f in os.listdir(CSRC):
+        if f.endswith(".h"):
+            out.append(os.path.join(CSRC, f))
+    return out
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("build failed: " + cmd[-1])
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build_lib(verbose: bool = True) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = _headers()
+    jobs = []
+    objs = []
+    for f in srcs:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJDIR, f[:-4] + ".o")
+        objs.append(obj)
+        if _newer(obj, [src] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    if jobs:
+        if verbose:
+            print(f"[ecgpu build] compiling {len(jobs)} object(s) for {ARCH}", flush=True)
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or _newer(LIB, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        if verbose:
+            print("[ecgpu build] linked", LIB, flush=True)
+    return LIB
+
+
+def build_hostsim(verbose: bool = True) -> str:
+    """g++ build of the same csrc headers: CPU-side kernel simulator for tests ONLY."""
+    d = os.path.join(ROOT, "tests", "hostsim")
+    src = os.path.join(d, "hostsim.cpp")
+    out = os.path.join(d, "libhostsim.so")
+    if _newer(out, [src] + _headers()):
+        if verbose:
+            print("[ecgpu build] building tests/hostsim", flush=True)
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-I" + CSRC,
+              "-I" + os.path.join(ROOT, "include"), src, "-o", out])
+    return out
+
+
+def build_oracle_c(verbose: bool = True) -> str:
+    d = os.path.join(ROOT, "oracle")
+    if os.path.exists(os.path.join(d, "Makefile")):
+        _run(["make", "-s", "-C", d])
+    return d
+
+
+if __name__ == "__main__":
+    build_lib()
+    if "--hostsim" in sys.argv:
+        build_hostsim()
+    if "--oracle" in sys.argv:
+        build_oracle_c()

@@ -1,0 +1,229 @@
+// SSZ Merkleization lane programs (replaces ssz_rs `merkleize` / `mix_in_length` under every
+// `.hash_tree_root()` of the reference, e.g. /root/reference/ethereum-consensus/src/phase0/
+// slot_processing.rs:67,75; algorithm = SURVEY.md Appendix A).
+//
+// Layout: a wave covers a tile of 64 * 2^D consecutive chunks; every LANE owns the 2^D
+// consecutive chunks of one aligned subtree and reduces them depth-first entirely in
+// registers (2^D - 1 hash64, no LDS, no cross-lane traffic, all 64 lanes busy), then stores
+// one 32-byte node.  A lane streams its own contiguous 32*2^D bytes, so every fetched cache
+// line is consumed exactly once (leaf buffer read once from HBM); the 64 node stores of a wave
+// are contiguous (2 KiB).  Interior nodes below level D never touch memory.
+#pragma once
+#include "sha256.h"
+
+namespace ecg {
+
+// zero-subtree ladder Z_0..Z_64, device-resident, filled at init by a
+// GPU kernel (no host hashing).
+struct ZeroTable {
+    Node z[65];
+};
+
+ECG_HD u32 funnel_bytes(u32 lo, u32 hi, u32 byte_shift) {
+    // bytes [byte_shift, byte_shift+4) of the little-endian 8-byte value hi:lo -> v_alignbyte_b32
+    u64 v = ((u64)hi << 32) | lo;
+    return (u32)(v >> (8 * byte_shift));
+}
+
+// Load `nw` little-endian dwords that start at byte `off` of the buffer [base, base+total);
+// bytes at or beyond `total` read as zero.  Only naturally aligned dwords that contain at
+// least one in-range byte are touched, so unaligned SSZ slices of a larger buffer are safe.
+template <int NW>
+ECG_HD void load_bytes_le(u32 (&out)[NW], const u8* base, u64 off, u64 total) {
+    const u8* addr = base + off;
+    const u64 a = (u64)addr;
+    const u32 sh = (u32)(a & 3);
+    const u8* end = base + total;
+    if (sh == 0 && off + 4ull * NW <= total) {
+        const u32* q = reinterpret_cast<const u32*>(addr);
+#pragma unroll
+        for (int i = 0; i < NW; i++) out[i] = q[i];
+        return;
+    }
+    const u32* q = reinterpret_cast<const u32*>(a - sh);
+    u32 raw[NW + 1];
+#pragma unroll
+    for (int i = 0; i < NW + 1; i++) {
+        const u8* p = reinterpret_cast<const u8*>(q + i);
+        raw[i] = (p < end && off < total) ? q[i] : 0u;
+    }
+    const u64 rem = off < total ? total - off : 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        u32 v = funnel_bytes(raw[i], raw[i + 1], sh);
+        u64 valid = rem > 4ull * i ? rem - 4ull * i : 0;
+        if (valid < 4) v &= valid == 0 ? 0u : (0xffffffffu >> (8 * (4 - (u32)valid)));
+        out[i] = v;
+    }
+}
+
+// ---- leaf functors: produce the level-0 node with index `idx` ------------------------------
+
+// packed chunks: node idx = bytes [32 idx, 32 idx + 32) of the buffer, zero padded (`pack`)
+struct ChunkLeaves {
+    const u8* base;
+    u64 total_bytes;
+    ECG_HD Node operator()(u64 idx) const {
+        u32 d[8];
+        load_bytes_le<8>(d, base, idx * 32, total_bytes);
+        Node n;
+#pragma unroll
+        for (int i = 0; i < 8; i++) n.w[i] = ecg_bswap32(d[i]);
+        return n;
+    }
+};
+
+// nodes already produced by a previous pass (32-byte aligned workspace)
+struct NodeLeaves {
+    const u8* base;
+    ECG_HD Node operator()(u64 idx) const {
+        Node n;
+        node_load(n, base + idx * 32);
+        return n;
+    }
+};
+
+// hash_tree_root(Validator) from the 121-byte SSZ record
+// (/root/reference/ethereum-consensus/src/phase0/validator.rs:10-26): leaves
+//   htr(pubkey 48 B) | withdrawal_credentials | effective_balance | slashed |
+//   activation_eligibility_epoch | activation_epoch | exit_epoch | withdrawable_epoch
+// = 1 + 7 hash64 per validator.
+struct ValidatorLeaves {
+    const u8* base;  // n * 121 bytes
+    u64 total_bytes;
+    ECG_HD Node operator()(u64 idx) const {
+        u32 d[31];
+        load_bytes_le<31>(d, base, idx * 121, total_bytes);  // 124 bytes, the last 3 are the next record
+        Node l[8];
+        Node a, b;
+#pragma unroll
+        for (int i = 0; i < 8; i++) a.w[i] = ecg_bswap32(d[i]);          // pubkey[0..32)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { b.w[i] = ecg_bswap32(d[8 + i]); b.w[4 + i] = 0; }  // pubkey[32..48) || 0^16
+        l[0] = hash64(a, b);
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[1].w[i] = ecg_bswap32(d[12 + i]);   // withdrawal_credentials
+#pragma unroll
+        for (int k = 2; k < 8; k++) node_zero(l[k]);
+        l[2].w[0] = ecg_bswap32(d[20]);                                   // effective_balance u64 LE
+        l[2].w[1] = ecg_bswap32(d[21]);
+        l[3].w[0] = ecg_bswap32(d[22] & 0xffu);                           // slashed: byte 88
+        // four u64 epochs at bytes 89,97,105,113: one byte past a dword boundary
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 lo = funnel_bytes(d[22 + 2 * k], d[23 + 2 * k], 1);
+            u32 hi = funnel_bytes(d[23 + 2 * k], d[24 + 2 * k], 1);
+            l[4 + k].w[0] = ecg_bswap32(lo);
+            l[4 + k].w[1] = ecg_bswap32(hi);
+        }
+        Node h01 = hash64(l[0], l[1]);
+        Node h23 = hash64(l[2], l[3]);
+        Node h45 = hash64(l[4], l[5]);
+        Node h67 = hash64(l[6], l[7]);
+        return hash64(hash64(h01, h23), hash64(h45, h67));
+    }
+};
+
+// hash_tree_root(ByteVector<48>) for packed 48-byte records (BlsPublicKey vectors of
+// SyncCommittee, /root/reference/ethereum-consensus/src/altair/sync.rs:17-22)
+struct Bytes48Leaves {
+    const u8* base;
+    u64 total_bytes;
+    ECG_HD Node operator()(u64 idx) const {
+        u32 d[12];
+        load_bytes_le<12>(d, base, idx * 48, total_bytes);
+        Node a, b;
+#pragma unroll
+        for (int i = 0; i < 8; i++) a.w[i] = ecg_bswap32(d[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { b.w[i] = ecg_bswap32(d[8 + i]); b.w[4 + i] = 0; }
+        return hash64(a, b);
+    }
+};
+
+// two-chunk containers packed as 64-byte records (Checkpoint-like pairs of roots,
+// HistoricalSummary: /root/reference/ethereum-consensus/src/phase0/beacon_state.rs:42-45)
+struct Pair64Leaves {
+    const u8* base;
+    u64 total_bytes;
+    ECG_HD Node operator()(u64 idx) const {
+        u32 d[16];
+        load_bytes_le<16>(d, base, idx * 64, total_bytes);
+        Node a, b;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a.w[i] = ecg_bswap32(d[i]); b.w[i] = ecg_bswap32(d[8 + i]); }
+        return hash64(a, b);
+    }
+};
+
+// hash_tree_root(Eth1Data) from the 72-byte record deposit_root | deposit_count u64 | block_hash
+// (/root/reference/ethereum-consensus/src/phase0/operations.rs:66-71): 3 leaves padded to 4.
+struct Eth1DataLeaves {
+    const u8* base;
+    u64 total_bytes;
+    ECG_HD Node operator()(u64 idx) const {
+        u32 d[18];
+        load_bytes_le<18>(d, base, idx * 72, total_bytes);
+        Node a, b, c, z;
+        node_zero(b);
+        node_zero(z);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a.w[i] = ecg_bswap32(d[i]); c.w[i] = ecg_bswap32(d[10 + i]); }
+        b.w[0] = ecg_bswap32(d[8]);
+        b.w[1] = ecg_bswap32(d[9]);
+        return hash64(hash64(a, b), hash64(c, z));
+    }
+};
+
+// ---- in-lane depth-first subtree ------------------------------------------------------------
+// Root of the aligned subtree of height K whose first level-0 node is `first`; level-0 nodes
+// with index >= n are virtual: an entirely virtual subtree of height k at absolute level
+// `level0 + k` is the ladder entry Z[level0 + k] (odd tails pair with Z_d, Appendix A).
+template <int K, class Leaf>
+struct Subtree {
+    static ECG_HD Node run(const Leaf& leaf, u64 first, u64 n, const ZeroTable* zt, int level0) {
+        if (first >= n) return zt->z[level0 + K];
+        Node l = Subtree<K - 1, Leaf>::run(leaf, first, n, zt, level0);
+        Node r = Subtree<K - 1, Leaf>::run(leaf, first + (1ull << (K - 1)), n, zt, level0);
+        return hash64(l, r);
+    }
+};
+template <class Leaf>
+struct Subtree<0, Leaf> {
+    static ECG_HD Node run(const Leaf& leaf, u64 first, u64 n, const ZeroTable* zt, int level0) {
+        if (first >= n) return zt->z[level0];
+        return leaf(first);
+    }
+};
+
+// One lane of a pass: out node `gid` = subtree of height D over level-0 nodes [gid<<D, (gid+1)<<D).
+template <int D, class Leaf>
+ECG_HD void lane_pass(const Leaf& leaf, u64 gid, u64 n_in, u8* out, const ZeroTable* zt, int level0) {
+    Node r = Subtree<D, Leaf>::run(leaf, gid << D, n_in, zt, level0);
+    node_store(r, out + gid * 32);
+}
+
+ECG_HD Node len_chunk(u64 len) {
+    // u256 little-endian length as a node (mix_in_length)
+    Node n;
+    node_zero(n);
+    n.w[0] = ecg_bswap32((u32)len);
+    n.w[1] = ecg_bswap32((u32)(len >> 32));
+    return n;
+}
+
+// A finishing job: `n` nodes at absolute level `level` -> climb to `depth` with the zero
+// ladder -> optional mix_in_length.  Executed by one workgroup (k_tree_jobs) or by the
+// hostsim with the same per-lane steps.
+struct TreeJob {
+    u64 in_off;    // byte offset of the first input node in the job buffer (32-byte aligned)
+    u64 out_off;   // byte offset of the 32-byte result
+    u64 mix_len;   // length to mix in
+    u32 n;         // number of input nodes (<= TREEJOB_MAX_NODES)
+    u32 level;     // absolute level of the input nodes
+    u32 depth;     // absolute level of the root = ceil(log2(limit))
+    u32 mix;       // 1: mix_in_length(root, mix_len)
+};
+constexpr u32 TREEJOB_MAX_NODES = 512;
+
+}  // namespace ecg

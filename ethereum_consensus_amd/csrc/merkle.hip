@@ -1,0 +1,401 @@
+// gfx950 SHA-256 Merkle kernels + host driver + C ABI entry points (see include/ecgpu.h).
+#include "merkle_driver.h"
+
+#include <cstring>
+
+namespace ecg {
+
+// ---------------------------------------------------------------------------------------------
+// device tables
+// ---------------------------------------------------------------------------------------------
+__device__ ZeroTable g_zero_table;
+
+__global__ void k_init_zero_table() {
+    // 64 sequential hash64 on one lane, once per process
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Node z;
+    node_zero(z);
+    g_zero_table.z[0] = z;
+    for (int d = 1; d <= 64; d++) {
+        z = hash64(z, z);
+        g_zero_table.z[d] = z;
+    }
+}
+
+static ZeroTable* g_zero_table_ptr = nullptr;
+const ZeroTable* device_zero_table() { return g_zero_table_ptr; }
+
+int init_merkle_tables(hipStream_t s) {
+    ECG_HIP_CHECK(hipGetSymbolAddress((void**)&g_zero_table_ptr, HIP_SYMBOL(g_zero_table)));
+    hipLaunchKernelGGL(k_init_zero_table, dim3(1), dim3(64), 0, s);
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+constexpr int PASS_BLOCK = 256;  // 4 waves; one lane = one output node
+
+// One pass: n_out nodes, node gid = height-D subtree over level-0 nodes [gid<<D, (gid+1)<<D).
+// Consecutive workgroups cover consecutive tiles, so the 8 XCDs stream 8 adjacent 64*2^D-chunk
+// tiles at a time (each tile is read once: nothing to share across L2s).
+template <int D, class Leaf>
+__global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass(Leaf leaf, u64 n_in, u64 n_out, u8* out,
+                                                            const ZeroTable* zt, int level0) {
+    u64 gid = (u64)blockIdx.x * PASS_BLOCK + threadIdx.x;
+    if (gid >= n_out) return;
+    lane_pass<D, Leaf>(leaf, gid, n_in, out, zt, level0);
+}
+
+// Finishing jobs: one workgroup per job; level-by-level in LDS, then the zero-ladder climb and
+// mix_in_length on lane 0.
+constexpr int JOB_BLOCK = 256;
+__device__ __forceinline__ void run_tree_job(const TreeJob& job, u8* buf, const ZeroTable* zt) {
+    __shared__ Node nodes[TREEJOB_MAX_NODES];
+    const u32 t = threadIdx.x;
+    u32 m = job.n;
+    for (u32 i = t; i < m; i += JOB_BLOCK) node_load(nodes[i], buf + job.in_off + 32ull * i);
+    __syncthreads();
+    u32 lvl = job.level;
+    while (m > 1) {
+        u32 pairs = (m + 1) >> 1;
+        Node h[TREEJOB_MAX_NODES / 2 / JOB_BLOCK];
+#pragma unroll
+        for (u32 k = 0; k < TREEJOB_MAX_NODES / 2 / JOB_BLOCK; k++) {
+            u32 i = t + k * JOB_BLOCK;
+            if (i < pairs) {
+                Node l = nodes[2 * i];
+                Node r = (2 * i + 1 < m) ? nodes[2 * i + 1] : zt->z[lvl];
+                h[k] = hash64(l, r);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < TREEJOB_MAX_NODES / 2 / JOB_BLOCK; k++) {
+            u32 i = t + k * JOB_BLOCK;
+            if (i < pairs) nodes[i] = h[k];
+        }
+        __syncthreads();
+        m = pairs;
+        lvl++;
+    }
+    if (t == 0) {
+        Node x = (job.n == 0) ? zt->z[job.depth] : nodes[0];
+        if (job.n != 0) {
+            for (; lvl < job.depth; lvl++) x = hash64(x, zt->z[lvl]);
+        }
+        if (job.mix) x = hash64(x, len_chunk(job.mix_len));
+        node_store(x, buf + job.out_off);
+    }
+}
+
+__global__ void __launch_bounds__(JOB_BLOCK) k_tree_jobs(const TreeJob* jobs, u8* buf, const ZeroTable* zt) {
+    TreeJob job = jobs[blockIdx.x];
+    run_tree_job(job, buf, zt);
+}
+__global__ void __launch_bounds__(JOB_BLOCK) k_tree_job1(TreeJob job, u8* buf, const ZeroTable* zt) {
+    run_tree_job(job, buf, zt);
+}
+
+__global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u32 n, u8* dst) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    GatherDesc g = desc[i];
+    u32 d[8];
+    u64 lim = g.src_off + g.n_bytes;
+    if (lim > src_total) lim = src_total;
+    load_bytes_le<8>(d, src, g.src_off, lim);
+    u32* q = reinterpret_cast<u32*>(dst + 32ull * g.dst_chunk);
+#pragma unroll
+    for (int k = 0; k < 8; k++) q[k] = d[k];
+}
+
+// crypto::hash: one lane per message (latency path; the batch form is what a caller should use)
+__global__ void k_sha256_batch(const u8* data, u64 len, u64 n, u8* out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Sha256Stream s;
+    sha256_init(s);
+    sha256_update(s, data + i * len, len);
+    u32 dg[8];
+    sha256_final(s, dg);
+    for (int k = 0; k < 8; k++) {
+        u32 v = dg[k];
+        out[i * 32 + 4 * k + 0] = (u8)(v >> 24);
+        out[i * 32 + 4 * k + 1] = (u8)(v >> 16);
+        out[i * 32 + 4 * k + 2] = (u8)(v >> 8);
+        out[i * 32 + 4 * k + 3] = (u8)v;
+    }
+}
+
+// Merkle branch fold (is_valid_merkle_branch): one lane, `depth` sequential hash64
+__global__ void k_merkle_branch(const u8* leaf_branch_root, u32 depth, u64 index, u8* ok) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Node v, r;
+    node_load(v, leaf_branch_root);
+    for (u32 i = 0; i < depth; i++) {
+        Node b;
+        node_load(b, leaf_branch_root + 32ull * (1 + i));
+        v = ((index >> i) & 1) ? hash64(b, v) : hash64(v, b);
+    }
+    node_load(r, leaf_branch_root + 32ull * (1 + depth));
+    bool eq = true;
+    for (int i = 0; i < 8; i++) eq = eq && (v.w[i] == r.w[i]);
+    *ok = eq ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------
+size_t merkle_ws_bytes(u64 n0) {
+    // ping-pong node buffers: first pass output <= n0/2 nodes, then geometric
+    u64 a = (n0 + 1) / 2 + 64;
+    return (size_t)(a * 32 * 2 + 1024);
+}
+
+template <class Leaf>
+static int launch_pass(hipStream_t s, int D, const Leaf& leaf, u64 n_in, u64 n_out, u8* out, int level0,
+                       const char* tag) {
+    dim3 grid((unsigned)((n_out + PASS_BLOCK - 1) / PASS_BLOCK)), block(PASS_BLOCK);
+    const ZeroTable* zt = device_zero_table();
+    ProfScope ps(tag, s);
+    switch (D) {
+        case 0: hipLaunchKernelGGL((k_merkle_pass<0, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
+        case 1: hipLaunchKernelGGL((k_merkle_pass<1, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
+        case 2: hipLaunchKernelGGL((k_merkle_pass<2, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
+        case 3: hipLaunchKernelGGL((k_merkle_pass<3, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
+        case 4: hipLaunchKernelGGL((k_merkle_pass<4, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
+        case 5: hipLaunchKernelGGL((k_merkle_pass<5, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
+        default: hipLaunchKernelGGL((k_merkle_pass<6, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
+    }
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
+int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes, u64 n0, u32 depth, bool mix,
+                     u64 mix_len, u8* d_out, u8* ws, u64* hash_count) {
+    if (depth > 64) {
+        set_last_error("limit too large");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    if (depth < 64 && n0 > (1ull << depth)) {
+        set_last_error("more level-0 nodes than the limit allows");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    const MerkleSchedule sc = schedule_merkleize(kind, n0, depth, mix);
+    const u64 half = ((n0 + 1) / 2 + 64) * 32;
+    u8* bufA = ws;
+    u8* bufB = ws + half;
+    const u8* cur = d_in;
+    for (const PassStep& p : sc.passes) {
+        u8* out = (cur == bufA) ? bufB : bufA;
+        int rc;
+        if (p.first) {
+            switch (kind) {
+                case LEAF_CHUNKS: rc = launch_pass(s, p.D, ChunkLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_chunks"); break;
+                case LEAF_VALIDATORS: rc = launch_pass(s, p.D, ValidatorLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_validators"); break;
+                case LEAF_BYTES48: rc = launch_pass(s, p.D, Bytes48Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_bytes48"); break;
+                case LEAF_PAIR64: rc = launch_pass(s, p.D, Pair64Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_pair64"); break;
+                default: rc = launch_pass(s, p.D, Eth1DataLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_eth1data"); break;
+            }
+        } else {
+            rc = launch_pass(s, p.D, NodeLeaves{cur}, p.n_in, p.n_out, out, (int)p.level_in, "merkle_pass_nodes");
+        }
+        if (rc) return rc;
+        cur = out;
+    }
+    // finishing job: <= 512 nodes at job_level (or the empty tree) -> climb -> mix-in -> d_out
+    TreeJob job;
+    u8* jbase = const_cast<u8*>(cur);
+    job.in_off = 0;
+    job.out_off = (u64)((uintptr_t)d_out - (uintptr_t)jbase);
+    job.n = sc.job_n;
+    job.level = sc.job_level;
+    job.depth = depth;
+    job.mix = mix ? 1 : 0;
+    job.mix_len = mix_len;
+    {
+        ProfScope ps("merkle_tree_job", s);
+        hipLaunchKernelGGL(k_tree_job1, dim3(1), dim3(JOB_BLOCK), 0, s, job, jbase, device_zero_table());
+    }
+    ECG_HIP_CHECK(hipGetLastError());
+    if (hash_count) *hash_count += sc.hashes;
+    return ECGPU_SUCCESS;
+}
+
+int launch_tree_jobs(hipStream_t s, const TreeJob* d_jobs, u32 n_jobs, u8* d_buf) {
+    if (n_jobs == 0) return ECGPU_SUCCESS;
+    ProfScope ps("merkle_tree_jobs", s);
+    hipLaunchKernelGGL(k_tree_jobs, dim3(n_jobs), dim3(JOB_BLOCK), 0, s, d_jobs, d_buf, device_zero_table());
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
+int launch_gather(hipStream_t s, const u8* d_src, u64 src_total, const GatherDesc* d_desc, u32 n, u8* d_dst) {
+    if (n == 0) return ECGPU_SUCCESS;
+    hipLaunchKernelGGL(k_gather, dim3((n + 63) / 64), dim3(64), 0, s, d_src, src_total, d_desc, n, d_dst);
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
+// shared body of the host-memory entry points: H2D, run, D2H 32 bytes
+static int merkleize_host(LeafKind kind, const u8* h_in, u64 in_bytes, u64 n0, u32 depth, bool mix, u64 mix_len,
+                          u8 root[32]) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    size_t need = in_bytes + 256 + merkle_ws_bytes(n0) + 1024;
+    rc = ar.reserve(need);
+    if (rc) return rc;
+    u8* d_in = ar.take(in_bytes + 4);
+    u8* ws = ar.take(merkle_ws_bytes(n0));
+    u8* d_root = ar.take(32);
+    if (in_bytes) ECG_HIP_CHECK(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, s));
+    u64 hc = 0;
+    rc = merkleize_device(s, kind, d_in, in_bytes, n0, depth, mix, mix_len, d_root, ws, &hc);
+    if (rc) return rc;
+    c->last_hash64 = hc;
+    ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ECGPU_SUCCESS;
+}
+
+}  // namespace ecg
+
+using namespace ecg;
+
+extern "C" {
+
+int ecgpu_merkleize(const uint8_t* data, uint64_t n_bytes, uint64_t limit_chunks, int mix_in_len, uint64_t len,
+                    uint8_t root[32]) {
+    if ((!data && n_bytes) || !root) return ECGPU_ERR_BAD_ARG;
+    u64 n0 = (n_bytes + 31) / 32;
+    u64 limit = limit_chunks ? limit_chunks : n0;
+    if (n0 > limit) {
+        set_last_error("more chunks than limit_chunks");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    return merkleize_host(LEAF_CHUNKS, data, n_bytes, n0, ceil_log2_u64(limit), mix_in_len != 0, len, root);
+}
+
+int ecgpu_merkleize_dev(const uint8_t* d_data, uint64_t n_bytes, uint64_t limit_chunks, int mix_in_len,
+                        uint64_t len, uint8_t* d_root, ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    u64 n0 = (n_bytes + 31) / 32;
+    u64 limit = limit_chunks ? limit_chunks : n0;
+    if (n0 > limit) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(stream);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    rc = ar.reserve(merkle_ws_bytes(n0) + 512);
+    if (rc) return rc;
+    u8* ws = ar.take(merkle_ws_bytes(n0));
+    u64 hc = 0;
+    rc = merkleize_device(s, LEAF_CHUNKS, d_data, n_bytes, n0, ceil_log2_u64(limit), mix_in_len != 0, len, d_root,
+                          ws, &hc);
+    c->last_hash64 = hc;
+    return rc;
+}
+
+int ecgpu_htr_validators(const uint8_t* ssz121, uint64_t n, uint64_t limit, uint8_t root[32]) {
+    if ((!ssz121 && n) || !root || n > limit) return ECGPU_ERR_BAD_ARG;
+    return merkleize_host(LEAF_VALIDATORS, ssz121, n * 121, n, ceil_log2_u64(limit), true, n, root);
+}
+
+int ecgpu_htr_validators_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t limit, uint8_t* d_root,
+                             ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n > limit) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(stream);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    rc = ar.reserve(merkle_ws_bytes(n) + 512);
+    if (rc) return rc;
+    u8* ws = ar.take(merkle_ws_bytes(n));
+    u64 hc = 0;
+    rc = merkleize_device(s, LEAF_VALIDATORS, d_ssz121, n * 121, n, ceil_log2_u64(limit), true, n, d_root, ws, &hc);
+    c->last_hash64 = hc;
+    return rc;
+}
+
+int ecgpu_htr_beacon_block_header(const uint8_t ssz112[112], uint8_t root[32]) {
+    if (!ssz112 || !root) return ECGPU_ERR_BAD_ARG;
+    // leaves: slot, proposer_index (u64 -> chunk), parent_root, state_root, body_root -> limit 5 (padded to 8)
+    u8 chunks[5 * 32];
+    std::memset(chunks, 0, sizeof(chunks));
+    std::memcpy(chunks + 0, ssz112 + 0, 8);
+    std::memcpy(chunks + 32, ssz112 + 8, 8);
+    std::memcpy(chunks + 64, ssz112 + 16, 96);
+    return merkleize_host(LEAF_CHUNKS, chunks, sizeof(chunks), 5, 3, false, 0, root);
+}
+
+int ecgpu_signing_root(const uint8_t object_root[32], const uint8_t domain[32], uint8_t root[32]) {
+    if (!object_root || !domain || !root) return ECGPU_ERR_BAD_ARG;
+    u8 chunks[64];
+    std::memcpy(chunks, object_root, 32);
+    std::memcpy(chunks + 32, domain, 32);
+    return merkleize_host(LEAF_CHUNKS, chunks, 64, 2, 1, false, 0, root);
+}
+
+int ecgpu_sha256_batch(const uint8_t* data, size_t len, uint64_t n, uint8_t* out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n == 0) return ECGPU_SUCCESS;
+    if ((!data && len) || !out) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    rc = ar.reserve(len * n + 32 * n + 1024);
+    if (rc) return rc;
+    u8* d_in = ar.take(len * n + 4);
+    u8* d_out = ar.take(32 * n);
+    if (len) ECG_HIP_CHECK(hipMemcpyAsync(d_in, data, len * n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sha256_batch, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_in, (u64)len, n, d_out);
+    ECG_HIP_CHECK(hipGetLastError());
+    ECG_HIP_CHECK(hipMemcpyAsync(out, d_out, 32 * n, hipMemcpyDeviceToHost, s));
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ECGPU_SUCCESS;
+}
+
+int ecgpu_sha256(const uint8_t* data, size_t len, uint8_t out[32]) { return ecgpu_sha256_batch(data, len, 1, out); }
+
+int ecgpu_is_valid_merkle_branch(const uint8_t leaf[32], const uint8_t* branch, uint32_t depth, uint64_t index,
+                                 const uint8_t root[32]) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!leaf || (!branch && depth) || !root || depth > 64) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    size_t nb = 32ull * (depth + 2);
+    rc = ar.reserve(nb + 512);
+    if (rc) return rc;
+    rc = c->staging.reserve(nb + 8);
+    if (rc) return rc;
+    u8* d = ar.take(nb);
+    u8* d_ok = ar.take(8);
+    std::memcpy(c->staging.p, leaf, 32);
+    if (depth) std::memcpy(c->staging.p + 32, branch, 32ull * depth);
+    std::memcpy(c->staging.p + 32ull * (depth + 1), root, 32);
+    ECG_HIP_CHECK(hipMemcpyAsync(d, c->staging.p, nb, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_merkle_branch, dim3(1), dim3(64), 0, s, d, depth, index, d_ok);
+    ECG_HIP_CHECK(hipGetLastError());
+    u8 ok = 0;
+    ECG_HIP_CHECK(hipMemcpyAsync(&ok, d_ok, 1, hipMemcpyDeviceToHost, s));
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ok ? ECGPU_SUCCESS : ECGPU_VERIFY_FAIL;
+}
+
+uint64_t ecgpu_last_hash64_count(void) { return tctx()->last_hash64; }
+
+}  // extern "C"

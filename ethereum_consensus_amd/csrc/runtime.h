@@ -1,0 +1,68 @@
+// Host-side runtime of libecgpu.so: device binding, per-thread stream + workspace arenas, error
+// reporting and HIP-event kernel timing.  There is deliberately no CPU execution path here.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ecgpu.h"
+#include "common.h"
+
+namespace ecg {
+
+void set_last_error(const std::string& s);
+
+#define ECG_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ecg::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));          \
+            return _e == hipErrorOutOfMemory ? ECGPU_ERR_OOM                                 \
+                   : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? ECGPU_ERR_NO_DEVICE \
+                                                                              : ECGPU_ERR_HIP; \
+        }                                                                                    \
+    } while (0)
+
+// A growable device arena owned by one (thread, stream) pair.  Offsets are handed out bump-style
+// per call; nothing is freed until the thread exits, so steady-state calls do no hipMalloc.
+struct Arena {
+    u8* base = nullptr;
+    size_t cap = 0;
+    size_t used = 0;
+    int reserve(size_t bytes);            // ensure capacity (may reallocate: only legal when used == 0)
+    u8* take(size_t bytes, size_t align = 256);
+    void reset() { used = 0; }
+};
+
+struct PinnedBuf {
+    u8* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+};
+
+struct ThreadCtx {
+    hipStream_t own_stream = nullptr;
+    std::map<hipStream_t, Arena> arenas;
+    PinnedBuf staging;      // host-pinned staging for small H2D/D2H payloads
+    u64 last_hash64 = 0;
+    hipStream_t stream_or_own(ecgpu_stream_t s);
+    Arena& arena(hipStream_t s) { return arenas[s]; }
+};
+
+int ensure_init();          // ECGPU_SUCCESS or ECGPU_ERR_NO_DEVICE
+ThreadCtx* tctx();          // per-thread context (after ensure_init)
+
+// kernel timing with HIP events on the launch stream
+struct ProfScope {
+    ProfScope(const char* tag, hipStream_t s);
+    ~ProfScope();
+    const char* tag;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on;
+};
+
+}  // namespace ecg

@@ -1,0 +1,363 @@
+// Host-side plan of hash_tree_root(BeaconState) for the deneb fork: pure offset arithmetic over
+// the state's SSZ encoding, no hashing and no HIP calls (so tests/hostsim can execute the very
+// same plan on the CPU lane simulator).
+//
+// Type tree: /root/reference/ethereum-consensus/src/deneb/beacon_state.rs:13-64 (28 fields),
+// sub-containers phase0/beacon_state.rs:15-22 (Fork), phase0/beacon_block.rs:83-91 (header),
+// phase0/operations.rs:13-17,66-71 (Checkpoint, Eth1Data), altair/sync.rs:17-22 (SyncCommittee),
+// deneb/execution_payload.rs:48-76 (ExecutionPayloadHeader); limits from
+// phase0/presets/{mainnet,minimal}.rs, altair/presets/mainnet.rs:19.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "merkle.h"
+
+namespace ecg {
+
+enum LeafKind : int {
+    LEAF_CHUNKS = 0,      // packed bytes -> 32-byte chunks
+    LEAF_NODES = 1,       // 32-byte nodes in a workspace
+    LEAF_VALIDATORS = 2,  // 121-byte Validator records -> htr(Validator)
+    LEAF_BYTES48 = 3,     // 48-byte records -> htr(ByteVector<48>)
+    LEAF_PAIR64 = 4,      // 64-byte records -> hash64 (two-field containers of roots)
+    LEAF_ETH1DATA = 5,    // 72-byte Eth1Data records -> htr(Eth1Data)
+};
+
+inline u32 ceil_log2_u64(u64 x) {
+    u32 d = 0;
+    while (d < 64 && (1ull << d) < x) d++;
+    return d;
+}
+
+// ---- pass schedule of one merkleize ----------------------------------------------------------
+// Height of the subtree one lane reduces in a pass over `n` inputs: keep >= 2^18 lanes in flight
+// (4 waves per SIMD on 256 CUs) while the tree is wide, go level by level once it is narrow
+// (a narrow level is latency-bound by one hash64 per lane whatever D is).
+inline int choose_pass_height(u64 n) {
+    int lg = 63 - __builtin_clzll(n | 1);
+    int d = lg - 18;
+    if (d < 1) d = 1;
+    if (d > 6) d = 6;
+    return d;
+}
+
+struct PassStep {
+    int D;         // subtree height per lane
+    u64 n_in;      // level-0 nodes (first pass) or nodes of the previous pass
+    u64 n_out;
+    u32 level_in;  // absolute level of the inputs (0 for the first pass)
+    bool first;    // runs the leaf functor of the field
+};
+
+struct MerkleSchedule {
+    std::vector<PassStep> passes;
+    u32 job_n, job_level;  // finishing job: job_n nodes at job_level -> depth (+ mix-in)
+    u64 hashes;            // hash64 executed, leaf functors included
+};
+
+inline u64 leaf_hash_cost(LeafKind k) {
+    switch (k) {
+        case LEAF_VALIDATORS: return 8;
+        case LEAF_BYTES48:
+        case LEAF_PAIR64: return 1;
+        case LEAF_ETH1DATA: return 3;
+        default: return 0;
+    }
+}
+
+inline MerkleSchedule schedule_merkleize(LeafKind kind, u64 n0, u32 depth, bool mix) {
+    MerkleSchedule sc;
+    sc.hashes = n0 * leaf_hash_cost(kind);
+    u64 n = n0;
+    u32 level = 0;
+    bool first = (kind != LEAF_NODES);  // a leaf functor still has to run
+    while (n > 0 && (first || n > TREEJOB_MAX_NODES)) {
+        int D = choose_pass_height(n);
+        if ((u32)D > depth - level) D = (int)(depth - level);
+        if (!first && D == 0) break;
+        const u64 n_out = (n + (1ull << D) - 1) >> D;
+        sc.passes.push_back({D, n, n_out, level, first});
+        u64 c = n;  // hash64 of the pass: every non-virtual node of levels 1..D
+        for (int d = 0; d < D; d++) {
+            c = (c + 1) / 2;
+            sc.hashes += c;
+        }
+        level += (u32)D;
+        n = n_out;
+        first = false;
+    }
+    sc.job_n = (u32)n;
+    sc.job_level = level;
+    if (n > 0) {
+        u64 c = n;
+        u32 l = level;
+        while (c > 1) { c = (c + 1) / 2; sc.hashes += c; l++; }
+        sc.hashes += depth - l;
+    }
+    if (mix) sc.hashes += 1;
+    return sc;
+}
+
+// Gather byte ranges of the encoding into zero-padded 32-byte chunks.
+struct GatherDesc {
+    u64 src_off;
+    u32 n_bytes;    // <= 32
+    u32 dst_chunk;  // chunk index in the small-chunk buffer
+};
+
+// A big field: reduced by the pass kernels straight from the encoding.
+struct BigField {
+    LeafKind kind;
+    u64 src, bytes, n0;
+    u32 depth;
+    bool mix;
+    u64 mix_len;
+    u32 out_chunk;
+};
+
+struct StatePlan {
+    std::vector<GatherDesc> gathers;
+    std::vector<TreeJob> jobs[3];  // dependency levels: leaf containers, nested containers, the state
+    std::vector<BigField> bigs;
+    u32 n_small_chunks = 0;
+    u32 root_chunk = 0;
+    u64 small_hashes = 0;  // hash64 performed by the jobs
+    std::string error;
+};
+
+struct Preset {
+    u64 slots_per_historical_root, historical_roots_limit, eth1_data_votes_bound, validator_registry_limit,
+        epochs_per_historical_vector, epochs_per_slashings_vector, sync_committee_size;
+};
+static const Preset STATE_PRESETS[2] = {
+    {8192, 1ull << 24, 2048, 1ull << 40, 65536, 8192, 512},  // mainnet
+    {64, 1ull << 24, 32, 1ull << 40, 64, 64, 32},            // minimal
+};
+
+// byte offsets of the fields inside the fixed-size part of the encoding
+struct FixedLayout {
+    u64 genesis_time, genesis_validators_root, slot, fork, latest_block_header, block_roots, state_roots,
+        historical_roots_off, eth1_data, eth1_data_votes_off, eth1_deposit_index, validators_off, balances_off,
+        randao_mixes, slashings, prev_participation_off, cur_participation_off, justification_bits,
+        prev_justified, cur_justified, finalized, inactivity_scores_off, current_sync_committee,
+        next_sync_committee, payload_header_off, next_withdrawal_index, next_withdrawal_validator_index,
+        historical_summaries_off, size;
+};
+
+inline FixedLayout layout_for(const Preset& p) {
+    FixedLayout L;
+    u64 o = 0;
+    auto take = [&](u64 n) { u64 r = o; o += n; return r; };
+    L.genesis_time = take(8);
+    L.genesis_validators_root = take(32);
+    L.slot = take(8);
+    L.fork = take(16);
+    L.latest_block_header = take(112);
+    L.block_roots = take(32 * p.slots_per_historical_root);
+    L.state_roots = take(32 * p.slots_per_historical_root);
+    L.historical_roots_off = take(4);
+    L.eth1_data = take(72);
+    L.eth1_data_votes_off = take(4);
+    L.eth1_deposit_index = take(8);
+    L.validators_off = take(4);
+    L.balances_off = take(4);
+    L.randao_mixes = take(32 * p.epochs_per_historical_vector);
+    L.slashings = take(8 * p.epochs_per_slashings_vector);
+    L.prev_participation_off = take(4);
+    L.cur_participation_off = take(4);
+    L.justification_bits = take(1);
+    L.prev_justified = take(40);
+    L.cur_justified = take(40);
+    L.finalized = take(40);
+    L.inactivity_scores_off = take(4);
+    L.current_sync_committee = take(48 * p.sync_committee_size + 48);
+    L.next_sync_committee = take(48 * p.sync_committee_size + 48);
+    L.payload_header_off = take(4);
+    L.next_withdrawal_index = take(8);
+    L.next_withdrawal_validator_index = take(8);
+    L.historical_summaries_off = take(4);
+    L.size = o;
+    return L;
+}
+
+inline u32 rd32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+
+constexpr u64 PAYLOAD_HEADER_FIXED = 584;  // deneb ExecutionPayloadHeader fixed part (extra_data offset at 436)
+
+struct Builder {
+    std::vector<GatherDesc> gathers;
+    std::vector<TreeJob> jobs[3];
+    u32 next_chunk = 32;  // chunks 0..31 = the state container's field roots
+    u64 hashes = 0;
+    u32 alloc(u32 n) { u32 r = next_chunk; next_chunk += n; return r; }
+    void gather(u64 src, u32 nbytes, u32 dst_chunk) { gathers.push_back({src, nbytes, dst_chunk}); }
+    void job(int lvl, u32 in_chunk, u32 n, u32 depth, u32 out_chunk, bool mix = false, u64 mix_len = 0) {
+        TreeJob j;
+        j.in_off = 32ull * in_chunk;
+        j.out_off = 32ull * out_chunk;
+        j.n = n;
+        j.level = 0;
+        j.depth = depth;
+        j.mix = mix ? 1 : 0;
+        j.mix_len = mix_len;
+        jobs[lvl].push_back(j);
+        u64 c = n, l = 0;
+        while (c > 1) { c = (c + 1) / 2; hashes += c; l++; }
+        if (n) hashes += depth - l;
+        if (mix) hashes++;
+    }
+};
+
+// Returns false (plan.error set) when the encoding is malformed.
+inline bool build_state_plan_deneb(const u8* h_fixed, u64 n_bytes, int preset, StatePlan& plan) {
+    auto fail = [&](const char* m) { plan.error = m; return false; };
+    if (preset < 0 || preset > 1) return fail("bad preset");
+    const Preset& P = STATE_PRESETS[preset];
+    const FixedLayout L = layout_for(P);
+    if (n_bytes < L.size) {
+        return fail("state encoding shorter than its fixed part");
+    }
+    // variable parts, in field order
+    u64 off[10];
+    off[0] = rd32(h_fixed + L.historical_roots_off);
+    off[1] = rd32(h_fixed + L.eth1_data_votes_off);
+    off[2] = rd32(h_fixed + L.validators_off);
+    off[3] = rd32(h_fixed + L.balances_off);
+    off[4] = rd32(h_fixed + L.prev_participation_off);
+    off[5] = rd32(h_fixed + L.cur_participation_off);
+    off[6] = rd32(h_fixed + L.inactivity_scores_off);
+    off[7] = rd32(h_fixed + L.payload_header_off);
+    off[8] = rd32(h_fixed + L.historical_summaries_off);
+    off[9] = n_bytes;
+    if (off[0] != L.size) {
+        return fail("first SSZ offset does not match the fixed part");
+    }
+    for (int i = 0; i < 9; i++)
+        if (off[i] > off[i + 1]) {
+            return fail("SSZ offsets not monotonic");
+        }
+    const u64 len_hroots = off[1] - off[0], len_votes = off[2] - off[1], len_vals = off[3] - off[2],
+              len_bal = off[4] - off[3], len_pp = off[5] - off[4], len_cp = off[6] - off[5],
+              len_inact = off[7] - off[6], len_hdr = off[8] - off[7], len_hsum = off[9] - off[8];
+    if (len_hroots % 32 || len_votes % 72 || len_vals % 121 || len_bal % 8 || len_inact % 8 || len_hsum % 64 ||
+        len_hdr < PAYLOAD_HEADER_FIXED || len_hdr > PAYLOAD_HEADER_FIXED + 32) {
+        return fail("variable-size field has an impossible length");
+    }
+    const u64 n_hroots = len_hroots / 32, n_votes = len_votes / 72, n_vals = len_vals / 121, n_bal = len_bal / 8,
+              n_inact = len_inact / 8, n_hsum = len_hsum / 64, extra_len = len_hdr - PAYLOAD_HEADER_FIXED;
+    if (n_hroots > P.historical_roots_limit || n_votes > P.eth1_data_votes_bound ||
+        n_vals > P.validator_registry_limit || n_hsum > P.historical_roots_limit) {
+        return fail("list longer than its limit");
+    }
+
+    Builder B;
+    std::vector<BigField>& bigs = plan.bigs;
+    const u32 sc_pk_root[2] = {B.alloc(2), B.alloc(2)};  // SyncCommittee container chunks: [pubkeys root, agg root]
+    auto lg = [](u64 x) { return ceil_log2_u64(x); };
+    bigs.push_back({LEAF_CHUNKS, L.block_roots, 32 * P.slots_per_historical_root, P.slots_per_historical_root,
+                    lg(P.slots_per_historical_root), false, 0, 5});
+    bigs.push_back({LEAF_CHUNKS, L.state_roots, 32 * P.slots_per_historical_root, P.slots_per_historical_root,
+                    lg(P.slots_per_historical_root), false, 0, 6});
+    bigs.push_back({LEAF_CHUNKS, off[0], len_hroots, n_hroots, lg(P.historical_roots_limit), true, n_hroots, 7});
+    bigs.push_back({LEAF_ETH1DATA, off[1], len_votes, n_votes, lg(P.eth1_data_votes_bound), true, n_votes, 9});
+    bigs.push_back({LEAF_VALIDATORS, off[2], len_vals, n_vals, lg(P.validator_registry_limit), true, n_vals, 11});
+    bigs.push_back({LEAF_CHUNKS, off[3], len_bal, (len_bal + 31) / 32, lg(P.validator_registry_limit / 4), true, n_bal, 12});
+    bigs.push_back({LEAF_CHUNKS, L.randao_mixes, 32 * P.epochs_per_historical_vector, P.epochs_per_historical_vector,
+                    lg(P.epochs_per_historical_vector), false, 0, 13});
+    bigs.push_back({LEAF_CHUNKS, L.slashings, 8 * P.epochs_per_slashings_vector, P.epochs_per_slashings_vector / 4,
+                    lg(P.epochs_per_slashings_vector / 4), false, 0, 14});
+    bigs.push_back({LEAF_CHUNKS, off[4], len_pp, (len_pp + 31) / 32, lg(P.validator_registry_limit / 32), true, len_pp, 15});
+    bigs.push_back({LEAF_CHUNKS, off[5], len_cp, (len_cp + 31) / 32, lg(P.validator_registry_limit / 32), true, len_cp, 16});
+    bigs.push_back({LEAF_CHUNKS, off[6], len_inact, (len_inact + 31) / 32, lg(P.validator_registry_limit / 4), true, n_inact, 21});
+    bigs.push_back({LEAF_BYTES48, L.current_sync_committee, 48 * P.sync_committee_size, P.sync_committee_size,
+                    lg(P.sync_committee_size), false, 0, sc_pk_root[0]});
+    bigs.push_back({LEAF_BYTES48, L.next_sync_committee, 48 * P.sync_committee_size, P.sync_committee_size,
+                    lg(P.sync_committee_size), false, 0, sc_pk_root[1]});
+    bigs.push_back({LEAF_PAIR64, off[8], len_hsum, n_hsum, lg(P.historical_roots_limit), true, n_hsum, 27});
+
+    // ---- small fields: gathers + jobs ----------------------------------------------------------
+    // basic fields: the root is the zero-padded chunk itself
+    B.gather(L.genesis_time, 8, 0);
+    B.gather(L.genesis_validators_root, 32, 1);
+    B.gather(L.slot, 8, 2);
+    B.gather(L.eth1_deposit_index, 8, 10);
+    B.gather(L.justification_bits, 1, 17);
+    B.gather(L.next_withdrawal_index, 8, 25);
+    B.gather(L.next_withdrawal_validator_index, 8, 26);
+    {   // Fork: previous_version[4], current_version[4], epoch u64
+        u32 c0 = B.alloc(3);
+        B.gather(L.fork, 4, c0);
+        B.gather(L.fork + 4, 4, c0 + 1);
+        B.gather(L.fork + 8, 8, c0 + 2);
+        B.job(0, c0, 3, 2, 3);
+    }
+    {   // BeaconBlockHeader: slot, proposer_index, parent_root, state_root, body_root
+        u32 c0 = B.alloc(5);
+        B.gather(L.latest_block_header, 8, c0);
+        B.gather(L.latest_block_header + 8, 8, c0 + 1);
+        for (u32 k = 0; k < 3; k++) B.gather(L.latest_block_header + 16 + 32 * k, 32, c0 + 2 + k);
+        B.job(0, c0, 5, 3, 4);
+    }
+    {   // Eth1Data: deposit_root, deposit_count, block_hash
+        u32 c0 = B.alloc(3);
+        B.gather(L.eth1_data, 32, c0);
+        B.gather(L.eth1_data + 32, 8, c0 + 1);
+        B.gather(L.eth1_data + 40, 32, c0 + 2);
+        B.job(0, c0, 3, 2, 8);
+    }
+    const u64 cps[3] = {L.prev_justified, L.cur_justified, L.finalized};
+    for (u32 k = 0; k < 3; k++) {  // Checkpoint: epoch, root
+        u32 c0 = B.alloc(2);
+        B.gather(cps[k], 8, c0);
+        B.gather(cps[k] + 8, 32, c0 + 1);
+        B.job(0, c0, 2, 1, 18 + k);
+    }
+    const u64 scs[2] = {L.current_sync_committee, L.next_sync_committee};
+    for (u32 k = 0; k < 2; k++) {  // SyncCommittee: htr(Vector<PublicKey>) (big pass), htr(aggregate_public_key)
+        u32 c0 = B.alloc(2);
+        u64 agg = scs[k] + 48 * P.sync_committee_size;
+        B.gather(agg, 32, c0);
+        B.gather(agg + 32, 16, c0 + 1);
+        B.job(0, c0, 2, 1, sc_pk_root[k] + 1);
+        B.job(1, sc_pk_root[k], 2, 1, 22 + k);
+        B.hashes += 0;
+    }
+    {   // ExecutionPayloadHeader (deneb): 17 fields
+        const u64 h = off[7];
+        u32 f = B.alloc(17);
+        B.gather(h + 0, 32, f + 0);      // parent_hash
+        B.gather(h + 32, 20, f + 1);     // fee_recipient
+        B.gather(h + 52, 32, f + 2);     // state_root
+        B.gather(h + 84, 32, f + 3);     // receipts_root
+        u32 bloom = B.alloc(8);          // logs_bloom: 256 bytes = 8 chunks
+        for (u32 k = 0; k < 8; k++) B.gather(h + 116 + 32 * k, 32, bloom + k);
+        B.job(0, bloom, 8, 3, f + 4);
+        B.gather(h + 372, 32, f + 5);    // prev_randao
+        B.gather(h + 404, 8, f + 6);     // block_number
+        B.gather(h + 412, 8, f + 7);     // gas_limit
+        B.gather(h + 420, 8, f + 8);     // gas_used
+        B.gather(h + 428, 8, f + 9);     // timestamp
+        u32 extra = B.alloc(1);          // extra_data: ByteList<32> -> one chunk, mix in length
+        B.gather(h + PAYLOAD_HEADER_FIXED, (u32)extra_len, extra);
+        B.job(0, extra, extra_len ? 1 : 0, 0, f + 10, true, extra_len);
+        B.gather(h + 440, 32, f + 11);   // base_fee_per_gas (U256 LE)
+        B.gather(h + 472, 32, f + 12);   // block_hash
+        B.gather(h + 504, 32, f + 13);   // transactions_root
+        B.gather(h + 536, 32, f + 14);   // withdrawals_root
+        B.gather(h + 568, 8, f + 15);    // blob_gas_used
+        B.gather(h + 576, 8, f + 16);    // excess_blob_gas
+        B.job(1, f, 17, 5, 24);
+    }
+    const u32 root_chunk = B.alloc(1);
+    B.job(2, 0, 28, 5, root_chunk);
+
+    plan.gathers = B.gathers;
+    for (int l = 0; l < 3; l++) plan.jobs[l] = B.jobs[l];
+    plan.n_small_chunks = B.next_chunk;
+    plan.root_chunk = root_chunk;
+    plan.small_hashes = B.hashes;
+    return true;
+}
+
+}  // namespace ecg

@@ -1,0 +1,84 @@
+"""Host-side mirror of the reference's Merkleization entry points, backed by the HIP kernels.
+
+Names follow the reference / ssz_rs: `hash_tree_root` of the hot-path types
+(/root/reference/ethereum-consensus/src/phase0/slot_processing.rs:67,75,
+phase0/state_transition.rs:60, signing.rs:14-22), `is_valid_merkle_branch`
+(phase0/block_processing.rs:433).  Inputs are SSZ encodings (bytes); results are 32-byte roots.
+Every hash runs on the GPU through libecgpu.so; a missing library or device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+from . import _lib
+
+MAINNET, MINIMAL = 0, 1
+VALIDATOR_REGISTRY_LIMIT = 1 << 40
+
+
+class MerkleizationError(RuntimeError):
+    """ssz_rs `MerkleizationError` analogue (e.g. input exceeds the type's limit)."""
+
+
+def _buf(b: bytes):
+    return ctypes.create_string_buffer(bytes(b), len(b)) if len(b) else ctypes.create_string_buffer(1)
+
+
+def _root(call, *args) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    rc = call(*args, out)
+    if rc == -3:
+        raise MerkleizationError((_lib.load().ecgpu_last_error() or b"bad argument").decode())
+    _lib.check(rc, call.__name__)
+    return out.raw
+
+
+def hash(data: bytes) -> bytes:  # noqa: A001 - the reference's name (crypto/bls.rs:12)
+    """crypto::hash: SHA-256."""
+    L = _lib.load()
+    return _root(L.ecgpu_sha256, _buf(data), len(data))
+
+
+def merkleize(data: bytes, limit_chunks: int = 0, mix_in_length: int | None = None) -> bytes:
+    """ssz_rs `merkleize(pack(data), limit)` [+ `mix_in_length`]."""
+    L = _lib.load()
+    return _root(L.ecgpu_merkleize, _buf(data), len(data), limit_chunks, 0 if mix_in_length is None else 1,
+                 mix_in_length or 0)
+
+
+def hash_tree_root_validators(ssz121: bytes, limit: int = VALIDATOR_REGISTRY_LIMIT) -> bytes:
+    """hash_tree_root(List<Validator, limit>) from packed 121-byte records."""
+    if len(ssz121) % 121:
+        raise MerkleizationError("validator encoding is not a multiple of 121 bytes")
+    L = _lib.load()
+    return _root(L.ecgpu_htr_validators, _buf(ssz121), len(ssz121) // 121, limit)
+
+
+def hash_tree_root_beacon_block_header(ssz112: bytes) -> bytes:
+    if len(ssz112) != 112:
+        raise MerkleizationError("BeaconBlockHeader encoding must be 112 bytes")
+    L = _lib.load()
+    return _root(L.ecgpu_htr_beacon_block_header, _buf(ssz112))
+
+
+def compute_signing_root(object_root: bytes, domain: bytes) -> bytes:
+    """signing.rs:14-22 with the object's root already computed."""
+    L = _lib.load()
+    return _root(L.ecgpu_signing_root, _buf(object_root), _buf(domain))
+
+
+def hash_tree_root_beacon_state_deneb(ssz: bytes, preset: int = MAINNET) -> bytes:
+    L = _lib.load()
+    return _root(L.ecgpu_htr_beacon_state_deneb, _buf(ssz), len(ssz), preset)
+
+
+def is_valid_merkle_branch(leaf: bytes, branch, depth: int, index: int, root: bytes) -> bool:
+    L = _lib.load()
+    b = b"".join(branch[:depth])
+    rc = L.ecgpu_is_valid_merkle_branch(_buf(leaf), _buf(b), depth, index, _buf(root))
+    _lib.check(rc, "ecgpu_is_valid_merkle_branch")
+    return rc == 0
+
+
+def last_hash64_count() -> int:
+    return int(_lib.load().ecgpu_last_hash64_count())

@@ -1,0 +1,136 @@
+/* ecgpu.h -- C ABI of the MI355X (gfx950) batch-crypto backend for ralexstokes/ethereum_consensus.
+ *
+ * The reference has no FFI for these paths: `crypto::bls` calls `blst::min_pk` directly
+ * (/root/reference/ethereum-consensus/src/crypto/bls.rs:4) and Merkleization is the
+ * `ssz_rs::HashTreeRoot` trait (ssz/mod.rs:4-7).  This header is the boundary a maintainer binds
+ * with `extern "C"` in a `gpu` cargo feature of `crypto/bls.rs` and in a `[patch]`ed ssz_rs
+ * (INTEGRATION.md shows both stubs).  Each entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all buffers caller-owned; nothing allocated by the library is
+ *     handed to the caller; thread-safe (per-thread HIP stream + workspace).
+ *   - return value: 0..7 = blst BLST_ERROR numbering (so the Rust shim can rebuild
+ *     `BLSTError` strings, crypto/bls.rs:48-62); negative = backend fault.  There is NO CPU
+ *     fallback: without a usable gfx950 device every call returns ECGPU_ERR_NO_DEVICE.
+ *   - "host" entry points take host memory and copy; "_dev" entry points take device pointers
+ *     (already resident in HBM) plus the HIP stream to enqueue on (NULL = the library's per-thread
+ *     stream) and are asynchronous: results are valid after the stream is synchronized.
+ */
+#ifndef ECGPU_H
+#define ECGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* BLST_ERROR numbering (blst bindings; reference crypto/bls.rs:48-62) */
+#define ECGPU_SUCCESS 0
+#define ECGPU_BAD_ENCODING 1
+#define ECGPU_POINT_NOT_ON_CURVE 2
+#define ECGPU_POINT_NOT_IN_GROUP 3
+#define ECGPU_AGGR_TYPE_MISMATCH 4
+#define ECGPU_VERIFY_FAIL 5
+#define ECGPU_PK_IS_INFINITY 6
+#define ECGPU_BAD_SCALAR 7
+/* wrapper-level and backend conditions */
+#define ECGPU_EMPTY_AGGREGATE (-100) /* Error::EmptyAggregate, crypto/bls.rs:80-82,136-138 */
+#define ECGPU_ERR_NO_DEVICE (-1)
+#define ECGPU_ERR_HIP (-2)
+#define ECGPU_ERR_BAD_ARG (-3)
+#define ECGPU_ERR_OOM (-4)
+
+typedef void* ecgpu_stream_t; /* a hipStream_t */
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+/* Bind the calling process to HIP device `device` (-1: current device) and build the device
+ * tables (zero-hash ladder, BLS constants).  Idempotent. */
+int ecgpu_init(int device);
+int ecgpu_device_count(void);
+const char* ecgpu_version(void);
+const char* ecgpu_last_error(void); /* thread-local description of the last negative return */
+
+/* ---- SHA-256 / SSZ Merkleization ------------------------------------------------------------ */
+/* crypto::hash (crypto/bls.rs:12-20): SHA-256 of an arbitrary byte string. */
+int ecgpu_sha256(const uint8_t* data, size_t len, uint8_t out[32]);
+/* n independent SHA-256 of equal-length messages (msg i at data + i*len) -> out + 32*i. */
+int ecgpu_sha256_batch(const uint8_t* data, size_t len, uint64_t n, uint8_t* out);
+
+/* ssz_rs `merkleize(chunks, limit)` [+ `mix_in_length`]:
+ * `data` = packed bytes (`pack`: zero-padded to 32-byte chunks), limit_chunks = chunk limit of the
+ * SSZ type (0 = tight: next_pow2(n_chunks)), mix_in_len != 0 adds mix_in_length(root, len). */
+int ecgpu_merkleize(const uint8_t* data, uint64_t n_bytes, uint64_t limit_chunks, int mix_in_len,
+                    uint64_t len, uint8_t root[32]);
+int ecgpu_merkleize_dev(const uint8_t* d_data, uint64_t n_bytes, uint64_t limit_chunks,
+                        int mix_in_len, uint64_t len, uint8_t* d_root, ecgpu_stream_t stream);
+
+/* hash_tree_root(List<Validator, limit>) from n packed 121-byte SSZ Validator records
+ * (phase0/validator.rs:10-26; `validators` field, phase0/beacon_state.rs:74). */
+int ecgpu_htr_validators(const uint8_t* ssz121, uint64_t n, uint64_t limit, uint8_t root[32]);
+int ecgpu_htr_validators_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t limit, uint8_t* d_root,
+                             ecgpu_stream_t stream);
+
+/* hash_tree_root(BeaconBlockHeader) from its 112-byte SSZ encoding (phase0/beacon_block.rs:83-91;
+ * called at phase0/slot_processing.rs:75, block_processing.rs:579). */
+int ecgpu_htr_beacon_block_header(const uint8_t ssz112[112], uint8_t root[32]);
+
+/* compute_signing_root (signing.rs:14-22): htr(SigningData{object_root, domain}). */
+int ecgpu_signing_root(const uint8_t object_root[32], const uint8_t domain[32], uint8_t root[32]);
+
+/* ssz_rs `is_valid_merkle_branch` (used at phase0/block_processing.rs:433,
+ * deneb/blob_sidecar.rs:62).  Returns 0 (valid) or ECGPU_VERIFY_FAIL. */
+int ecgpu_is_valid_merkle_branch(const uint8_t leaf[32], const uint8_t* branch, uint32_t depth,
+                                 uint64_t index, const uint8_t root[32]);
+
+/* hash_tree_root(BeaconState) for the deneb fork (deneb/beacon_state.rs:13-64) from the SSZ
+ * serialization of the state; called per slot (phase0/slot_processing.rs:67) and per block
+ * (phase0/state_transition.rs:60).  preset: 0 = mainnet, 1 = minimal. */
+#define ECGPU_PRESET_MAINNET 0
+#define ECGPU_PRESET_MINIMAL 1
+int ecgpu_htr_beacon_state_deneb(const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32]);
+/* device-resident state bytes; `h_fixed` = host copy of the fixed-size part of the encoding
+ * (the first ecgpu_beacon_state_deneb_fixed_size(preset) bytes: offsets and small fields). */
+int ecgpu_htr_beacon_state_deneb_dev(const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed,
+                                     int preset, uint8_t* d_root, ecgpu_stream_t stream);
+uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);
+/* number of hash64 the last state root of this thread performed (work accounting for benches) */
+uint64_t ecgpu_last_hash64_count(void);
+
+/* ---- BLS12-381 (min_pk: 48-byte G1 public keys, 96-byte G2 signatures) ---------------------- */
+/* crypto::verify_signature (crypto/bls.rs:64-77) */
+int ecgpu_verify(const uint8_t pk[48], const uint8_t* msg, size_t msg_len, const uint8_t sig[96]);
+/* crypto::fast_aggregate_verify (:114-132); eth_variant != 0 = eth_fast_aggregate_verify (:150-160) */
+int ecgpu_fast_aggregate_verify(const uint8_t* pks48, uint32_t k, const uint8_t* msg, size_t msg_len,
+                                const uint8_t sig[96], int eth_variant);
+/* crypto::aggregate_verify (:95-112); messages concatenated, msg i = msgs[msg_off[i] .. msg_off[i+1]) */
+int ecgpu_aggregate_verify(const uint8_t* pks48, uint32_t n_pks, const uint8_t* msgs,
+                           const uint64_t* msg_off, uint32_t n_msgs, const uint8_t sig[96]);
+/* crypto::aggregate (:79-93) and crypto::eth_aggregate_public_keys (:135-148) */
+int ecgpu_aggregate_sigs(const uint8_t* sigs96, uint32_t n, uint8_t out[96]);
+int ecgpu_aggregate_pks(const uint8_t* pks48, uint32_t n, uint8_t out[48]);
+
+/* Batch entry (one call per block / per epoch instead of one call per signature):
+ * n independent fast_aggregate_verify over 32-byte messages (every in-crate caller signs a
+ * 32-byte signing root, signing.rs:14-22).  Tuple i uses public keys pk_off[i]..pk_off[i+1] of
+ * pks48 (pk_off == NULL: exactly one key per tuple), message msgs32 + 32 i, signature
+ * sigs96 + 96 i; status_out[i] receives the BLST_ERROR the scalar call would have returned. */
+int ecgpu_fast_aggregate_verify_batch(const uint8_t* pks48, const uint32_t* pk_off,
+                                      const uint8_t* msgs32, const uint8_t* sigs96, uint32_t n,
+                                      int eth_variant, uint8_t* status_out);
+int ecgpu_fast_aggregate_verify_batch_dev(const uint8_t* d_pks48, const uint32_t* d_pk_off,
+                                          uint32_t n_pks_total, const uint8_t* d_msgs32,
+                                          const uint8_t* d_sigs96, uint32_t n, int eth_variant,
+                                          uint8_t* d_status_out, ecgpu_stream_t stream);
+
+/* ---- measurement helpers (bench.py) --------------------------------------------------------- */
+/* HIP-event timing of the dominant kernel of the last *_dev call on this thread:
+ * returns the number of launches recorded and writes their total duration. */
+int ecgpu_prof_enable(int on);
+int ecgpu_prof_filter(const char* kernel_tag); /* NULL/"" = time every tagged kernel */
+int ecgpu_prof_read(const char* kernel_tag, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECGPU_H */

@@ -260,8 +260,20 @@ class Container(SSZType):
             self.fixed_size = sum(t.fixed_size for _, t in self.fields)
 
     def serialize(self, v):
-        assert self.fixed_size is not None, "only fixed-size containers are serialized on this path"
-        return b"".join(t.serialize(v[n]) for n, t in self.fields)
+        """SSZ container encoding: fixed parts (4-byte offsets for variable-size fields), then the
+        variable parts in field order."""
+        fixed_len = sum(t.fixed_size if t.fixed_size is not None else 4 for _, t in self.fields)
+        fixed, var = [], []
+        off = fixed_len
+        for n, t in self.fields:
+            if t.fixed_size is not None:
+                fixed.append(t.serialize(v[n]))
+            else:
+                body = t.serialize(v[n])
+                fixed.append(off.to_bytes(4, "little"))
+                var.append(body)
+                off += len(body)
+        return b"".join(fixed) + b"".join(var)
 
     def htr(self, v):
         return merkleize_chunks([t.htr(v[n]) for n, t in self.fields], len(self.fields))

@@ -1,0 +1,69 @@
+"""Converts ethereum_consensus_amd.synthetic field dicts into oracle.ssz values (tests only)."""
+from oracle import ssz
+
+
+def oracle_state_value(f: dict) -> dict:
+    v = f["validators"]
+    vals = [{
+        "public_key": bytes(x["public_key"]), "withdrawal_credentials": bytes(x["withdrawal_credentials"]),
+        "effective_balance": int(x["effective_balance"]), "slashed": bool(x["slashed"]),
+        "activation_eligibility_epoch": int(x["activation_eligibility_epoch"]),
+        "activation_epoch": int(x["activation_epoch"]), "exit_epoch": int(x["exit_epoch"]),
+        "withdrawable_epoch": int(x["withdrawable_epoch"])} for x in v]
+    cp = lambda c: {"epoch": c[0], "root": c[1]}
+    e1 = lambda e: {"deposit_root": e[0], "deposit_count": e[1], "block_hash": e[2]}
+    sc = lambda s: {"public_keys": [bytes(r) for r in s[0]], "aggregate_public_key": s[1]}
+    hdr = f["latest_block_header"]
+    jb = f["justification_bits"]
+    return {
+        "genesis_time": f["genesis_time"], "genesis_validators_root": f["genesis_validators_root"], "slot": f["slot"],
+        "fork": {"previous_version": f["fork"][0], "current_version": f["fork"][1], "epoch": f["fork"][2]},
+        "latest_block_header": {"slot": hdr[0], "proposer_index": hdr[1], "parent_root": hdr[2], "state_root": hdr[3],
+                                "body_root": hdr[4]},
+        "block_roots": [bytes(r) for r in f["block_roots"]], "state_roots": [bytes(r) for r in f["state_roots"]],
+        "historical_roots": [bytes(r) for r in f["historical_roots"]],
+        "eth1_data": e1(f["eth1_data"]), "eth1_data_votes": [e1(e) for e in f["eth1_data_votes"]],
+        "eth1_deposit_index": f["eth1_deposit_index"], "validators": vals,
+        "balances": [int(b) for b in f["balances"]], "randao_mixes": [bytes(r) for r in f["randao_mixes"]],
+        "slashings": [int(s) for s in f["slashings"]],
+        "previous_epoch_participation": [int(b) for b in f["previous_epoch_participation"]],
+        "current_epoch_participation": [int(b) for b in f["current_epoch_participation"]],
+        "justification_bits": [bool((jb >> k) & 1) for k in range(4)],
+        "previous_justified_checkpoint": cp(f["previous_justified_checkpoint"]),
+        "current_justified_checkpoint": cp(f["current_justified_checkpoint"]),
+        "finalized_checkpoint": cp(f["finalized_checkpoint"]),
+        "inactivity_scores": [int(s) for s in f["inactivity_scores"]],
+        "current_sync_committee": sc(f["current_sync_committee"]), "next_sync_committee": sc(f["next_sync_committee"]),
+        "latest_execution_payload_header": dict(f["payload_header"]),
+        "next_withdrawal_index": f["next_withdrawal_index"],
+        "next_withdrawal_validator_index": f["next_withdrawal_validator_index"],
+        "historical_summaries": [{"block_summary_root": bytes(r[:32]), "state_summary_root": bytes(r[32:])}
+                                 for r in f["historical_summaries"]],
+    }
+
+
+def oracle_state_root_fast(f: dict, preset_name: str) -> bytes:
+    """Whole-state root with the C restatement (oracle/c) on the big arrays and oracle/ssz.py on
+    everything else -- used where the pure-Python oracle would take minutes (N = 2^20)."""
+    from oracle import cref
+    P = ssz.MINIMAL if preset_name == "minimal" else ssz.MAINNET
+    t = ssz.BeaconStateDeneb(P)
+    light = dict(f)
+    import numpy as np
+    light["validators"] = f["validators"][:0]
+    for k in ("balances", "previous_epoch_participation", "current_epoch_participation", "inactivity_scores"):
+        light[k] = f[k][:0]
+    v = oracle_state_value(light)
+    roots = t.field_roots(v)
+    names = [n for n, _ in t.fields]
+    n = len(f["validators"])
+    roots[names.index("validators")] = cref.htr_validators(f["validators"].tobytes(), P.VALIDATOR_REGISTRY_LIMIT)[0]
+    lim8 = P.VALIDATOR_REGISTRY_LIMIT // 4
+    lim1 = P.VALIDATOR_REGISTRY_LIMIT // 32
+    roots[names.index("balances")] = cref.merkleize_bytes(f["balances"].tobytes(), lim8, n)[0]
+    roots[names.index("inactivity_scores")] = cref.merkleize_bytes(f["inactivity_scores"].tobytes(), lim8, n)[0]
+    roots[names.index("previous_epoch_participation")] = cref.merkleize_bytes(
+        f["previous_epoch_participation"].tobytes(), lim1, n)[0]
+    roots[names.index("current_epoch_participation")] = cref.merkleize_bytes(
+        f["current_epoch_participation"].tobytes(), lim1, n)[0]
+    return ssz.merkleize_chunks(roots, len(roots))

@@ -1,0 +1,159 @@
+// tests/hostsim: CPU-side simulator of the gfx950 kernels -- TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the very same ECG_HD lane programs the GPU executes (ethereum_consensus_amd/csrc/*.h)
+// with g++ and runs them lane by lane, so that the CPU test-suite (`-m "not gpu"`) can check the
+// device arithmetic against oracle/ in a container without a GPU.  Nothing in the product
+// (libecgpu.so, ethereum_consensus_amd/*.py) links or loads this file.
+#include <cstring>
+#include <vector>
+
+#include "merkle.h"
+#include "state_plan.h"
+
+using namespace ecg;
+
+static ZeroTable g_zt;
+static bool g_zt_ready = false;
+static const ZeroTable* zt() {
+    if (!g_zt_ready) {
+        Node z;
+        node_zero(z);
+        g_zt.z[0] = z;
+        for (int d = 1; d <= 64; d++) {
+            z = hash64(z, z);
+            g_zt.z[d] = z;
+        }
+        g_zt_ready = true;
+    }
+    return &g_zt;
+}
+
+template <class Leaf>
+static void run_pass(int D, const Leaf& leaf, u64 n_in, u64 n_out, u8* out, int level0) {
+    for (u64 gid = 0; gid < n_out; gid++) {
+        switch (D) {
+            case 0: lane_pass<0, Leaf>(leaf, gid, n_in, out, zt(), level0); break;
+            case 1: lane_pass<1, Leaf>(leaf, gid, n_in, out, zt(), level0); break;
+            case 2: lane_pass<2, Leaf>(leaf, gid, n_in, out, zt(), level0); break;
+            case 3: lane_pass<3, Leaf>(leaf, gid, n_in, out, zt(), level0); break;
+            case 4: lane_pass<4, Leaf>(leaf, gid, n_in, out, zt(), level0); break;
+            case 5: lane_pass<5, Leaf>(leaf, gid, n_in, out, zt(), level0); break;
+            default: lane_pass<6, Leaf>(leaf, gid, n_in, out, zt(), level0); break;
+        }
+    }
+}
+
+extern "C" {
+
+void hs_zero_table(u8* out /* 65*32 */) {
+    for (int d = 0; d <= 64; d++) node_store(zt()->z[d], out + 32 * d);
+}
+
+void hs_hash64(const u8* l, const u8* r, u8* out) {
+    Node a, b;
+    node_load(a, l);
+    node_load(b, r);
+    node_store(hash64(a, b), out);
+}
+
+void hs_sha256(const u8* data, u64 len, u8* out) {
+    Sha256Stream s;
+    sha256_init(s);
+    sha256_update(s, data, len);
+    u32 dg[8];
+    sha256_final(s, dg);
+    for (int k = 0; k < 8; k++) {
+        out[4 * k] = (u8)(dg[k] >> 24);
+        out[4 * k + 1] = (u8)(dg[k] >> 16);
+        out[4 * k + 2] = (u8)(dg[k] >> 8);
+        out[4 * k + 3] = (u8)dg[k];
+    }
+}
+
+// kind: 0 chunks, 1 nodes, 2 validators, 3 bytes48, 4 pair64, 5 eth1data (LeafKind of merkle_driver.h)
+// `in` may be an unaligned slice; out receives n_out = ceil(n_in / 2^D) nodes.
+u64 hs_pass(int kind, int D, const u8* in, u64 in_bytes, u64 n_in, u8* out, int level0) {
+    u64 n_out = (n_in + (1ull << D) - 1) >> D;
+    switch (kind) {
+        case 0: run_pass(D, ChunkLeaves{in, in_bytes}, n_in, n_out, out, level0); break;
+        case 1: run_pass(D, NodeLeaves{in}, n_in, n_out, out, level0); break;
+        case 2: run_pass(D, ValidatorLeaves{in, in_bytes}, n_in, n_out, out, level0); break;
+        case 3: run_pass(D, Bytes48Leaves{in, in_bytes}, n_in, n_out, out, level0); break;
+        case 4: run_pass(D, Pair64Leaves{in, in_bytes}, n_in, n_out, out, level0); break;
+        default: run_pass(D, Eth1DataLeaves{in, in_bytes}, n_in, n_out, out, level0); break;
+    }
+    return n_out;
+}
+
+// the finishing job exactly as k_tree_jobs runs it (level by level, zero-ladder climb, mix-in)
+void hs_tree_job(const u8* in, u32 n, u32 level, u32 depth, int mix, u64 mix_len, u8* out) {
+    std::vector<Node> nodes(n ? n : 1);
+    for (u32 i = 0; i < n; i++) node_load(nodes[i], in + 32ull * i);
+    u32 m = n, lvl = level;
+    while (m > 1) {
+        u32 pairs = (m + 1) >> 1;
+        std::vector<Node> h(pairs);
+        for (u32 i = 0; i < pairs; i++) {
+            Node l = nodes[2 * i];
+            Node r = (2 * i + 1 < m) ? nodes[2 * i + 1] : zt()->z[lvl];
+            h[i] = hash64(l, r);
+        }
+        for (u32 i = 0; i < pairs; i++) nodes[i] = h[i];
+        m = pairs;
+        lvl++;
+    }
+    Node x = (n == 0) ? zt()->z[depth] : nodes[0];
+    if (n != 0)
+        for (; lvl < depth; lvl++) x = hash64(x, zt()->z[lvl]);
+    if (mix) x = hash64(x, len_chunk(mix_len));
+    node_store(x, out);
+}
+
+
+// merkleize exactly as merkle.hip::merkleize_device schedules it (schedule_merkleize is shared)
+static void sim_merkleize(LeafKind kind, const u8* in, u64 in_bytes, u64 n0, u32 depth, bool mix, u64 mix_len,
+                          u8* out, u64* hashes) {
+    const MerkleSchedule sc = schedule_merkleize(kind, n0, depth, mix);
+    std::vector<u8> a, b;
+    const u8* cur = in;
+    for (const PassStep& p : sc.passes) {
+        std::vector<u8>& dst = (cur == a.data()) ? b : a;
+        dst.assign(32 * (p.n_out ? p.n_out : 1), 0);
+        if (p.first) hs_pass((int)kind, p.D, in, in_bytes, p.n_in, dst.data(), 0);
+        else hs_pass(1, p.D, cur, 32 * p.n_in, p.n_in, dst.data(), (int)p.level_in);
+        cur = dst.data();
+    }
+    hs_tree_job(cur, sc.job_n, sc.job_level, depth, mix ? 1 : 0, mix_len, out);
+    if (hashes) *hashes += sc.hashes;
+}
+
+u64 hs_merkleize(int kind, const u8* in, u64 in_bytes, u64 n0, u32 depth, int mix, u64 mix_len, u8* out) {
+    u64 h = 0;
+    sim_merkleize((LeafKind)kind, in, in_bytes, n0, depth, mix != 0, mix_len, out, &h);
+    return h;
+}
+
+// state_deneb.hip::state_root_device on the lane simulator: same plan, same order
+int hs_state_root_deneb(const u8* ssz, u64 n_bytes, int preset, u8* out, u64* hashes) {
+    StatePlan plan;
+    if (!build_state_plan_deneb(ssz, n_bytes, preset, plan)) return -3;
+    std::vector<u8> small(32ull * plan.n_small_chunks, 0);
+    for (const GatherDesc& g : plan.gathers) {
+        u32 d[8];
+        u64 lim = g.src_off + g.n_bytes;
+        if (lim > n_bytes) lim = n_bytes;
+        load_bytes_le<8>(d, ssz, g.src_off, lim);
+        std::memcpy(small.data() + 32ull * g.dst_chunk, d, 32);
+    }
+    u64 hc = plan.small_hashes;
+    for (const BigField& b : plan.bigs)
+        sim_merkleize(b.kind, ssz + b.src, b.bytes, b.n0, b.depth, b.mix, b.mix_len, small.data() + 32ull * b.out_chunk, &hc);
+    for (int l = 0; l < 3; l++)
+        for (const TreeJob& j : plan.jobs[l])
+            hs_tree_job(small.data() + j.in_off, j.n, j.level, j.depth, (int)j.mix, j.mix_len, small.data() + j.out_off);
+    std::memcpy(out, small.data() + 32ull * plan.root_chunk, 32);
+    if (hashes) *hashes = hc;
+    return 0;
+}
+
+}  // extern "C"

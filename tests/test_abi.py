@@ -1,0 +1,58 @@
+"""The C-ABI library loads, exports every symbol include/ecgpu.h declares, and has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ecgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ecgpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_symbols()
+    for want in ["ecgpu_verify", "ecgpu_fast_aggregate_verify", "ecgpu_aggregate_verify", "ecgpu_aggregate_sigs",
+                 "ecgpu_aggregate_pks", "ecgpu_fast_aggregate_verify_batch", "ecgpu_merkleize", "ecgpu_htr_validators",
+                 "ecgpu_htr_beacon_state_deneb", "ecgpu_sha256", "ecgpu_is_valid_merkle_branch"]:
+        assert want in names
+
+
+def test_library_exports_every_declared_symbol():
+    from ethereum_consensus_amd import _lib
+    L = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(raw, name), f"libecgpu.so does not export {name}"
+    assert b"gfx950" in L.ecgpu_version()
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ethereum_consensus_amd import _lib, ssz
+    L = _lib.load()
+    assert L.ecgpu_device_count() == 0
+    assert L.ecgpu_init(-1) == -1  # ECGPU_ERR_NO_DEVICE
+    with pytest.raises(_lib.EcgpuError):
+        ssz.merkleize(b"\x01" * 64)
+    with pytest.raises(_lib.EcgpuError):
+        ssz.hash(b"abc")
+
+
+def test_product_does_not_import_the_oracle():
+    """oracle/ and tests/hostsim are checkers: nothing in the package may load them
+    (build.py only knows how to *compile* them for the test-suite)."""
+    pkg = os.path.join(ROOT, "ethereum_consensus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".h", ".hip", ".cpp")) or f == "build.py":
+                continue
+            text = open(os.path.join(dirpath, f), errors="ignore").read()
+            for needle in ("import oracle", "from oracle", "liboracle", "libhostsim", "oracle/_build", "oracle.cref"):
+                assert needle not in text, (f, needle)

@@ -1,0 +1,150 @@
+"""GPU parity tests for the SHA-256 / SSZ Merkleization path: HIP kernels through the C ABI
+(ethereum_consensus_amd.ssz -> libecgpu.so) against the oracle on the same seeded inputs."""
+import ctypes
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cref, ssz as ossz
+from tests import test_oracle_ssz as fx
+from tests._statevalue import oracle_state_root_fast, oracle_state_value
+from tests.test_hostsim_merkle import make_validators
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from ethereum_consensus_amd import _lib, ssz
+    L = _lib.load(build_if_missing=False)
+    assert L.ecgpu_init(-1) == 0, L.ecgpu_last_error()
+    return ssz
+
+
+def rnd(n, seed):
+    return random.Random(seed).randbytes(n)
+
+
+def test_sha256(gpu):
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000):
+        d = rnd(n, n)
+        assert gpu.hash(d) == hashlib.sha256(d).digest()
+
+
+def test_reference_fixtures(gpu):
+    # sepolia BlobSidecar inclusion proof, deneb/blob_sidecar.rs:47-64,108-132
+    leaf = gpu.merkleize(fx.KZG_COMMITMENT, 2)
+    assert leaf == ossz.BlsPublicKey.htr(fx.KZG_COMMITMENT)
+    assert gpu.is_valid_merkle_branch(leaf, fx.PROOF, 17, 221184 % (1 << 17), fx.BODY_ROOT)
+    assert not gpu.is_valid_merkle_branch(leaf, fx.PROOF, 17, 221185 % (1 << 17), fx.BODY_ROOT)
+    # config 1: BeaconBlockHeader of the same fixture (blob_sidecar.rs:78-84)
+    enc = ossz.BeaconBlockHeader.serialize(fx.HEADER)
+    assert gpu.hash_tree_root_beacon_block_header(enc) == ossz.BeaconBlockHeader.htr(fx.HEADER)
+    assert gpu.hash_tree_root_beacon_block_header(bytes(112)) == ossz.BeaconBlockHeader.htr(ossz.BeaconBlockHeader.default())
+    dom = rnd(32, 5)
+    assert gpu.compute_signing_root(leaf, dom) == ossz.SigningData.htr({"object_root": leaf, "domain": dom})
+
+
+def test_headers_batch_of_random(gpu):
+    r = random.Random(3)
+    for _ in range(20):
+        h = {"slot": r.getrandbits(64), "proposer_index": r.getrandbits(64), "parent_root": r.randbytes(32),
+             "state_root": r.randbytes(32), "body_root": r.randbytes(32)}
+        assert gpu.hash_tree_root_beacon_block_header(ossz.BeaconBlockHeader.serialize(h)) == ossz.BeaconBlockHeader.htr(h)
+
+
+@pytest.mark.parametrize("nbytes,limit", [
+    (0, 0), (0, 8), (0, 1 << 40), (1, 1), (32, 1), (33, 2), (64, 2), (5 * 32, 8), (1000, 1 << 20),
+    (32 * 511, 512), (32 * 512, 512), (32 * 513, 1024), (32 * 777, 1 << 38), (8 * 4097, 1 << 38),
+    (32 * 100_003, 1 << 35), (1 << 22, 1 << 17), ((1 << 24) + 8, 1 << 38)])
+def test_merkleize_vs_oracle(gpu, nbytes, limit):
+    d = rnd(nbytes, nbytes + 1)
+    want, h = cref.merkleize_bytes(d, limit, None)
+    assert gpu.merkleize(d, limit) == want
+    assert gpu.last_hash64_count() == h
+    want2, _ = cref.merkleize_bytes(d, limit, nbytes // 8)
+    assert gpu.merkleize(d, limit, mix_in_length=nbytes // 8) == want2
+    if nbytes <= 32 * 777:
+        assert want == ossz.merkleize_bytes(d, limit if limit else None)
+
+
+def test_merkleize_rejects_over_limit(gpu):
+    with pytest.raises(gpu.MerkleizationError):
+        gpu.merkleize(bytes(96), 2)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64, 255, 256, 257, 1000, 4099, 1 << 14])
+def test_validator_list(gpu, n):
+    from ethereum_consensus_amd import synthetic as S
+    enc = S.validators(n, seed=n).tobytes()
+    want, h = cref.htr_validators(enc)
+    assert gpu.hash_tree_root_validators(enc) == want
+    assert gpu.last_hash64_count() == h
+    if n <= 64:
+        vs = make_validators(n, n)
+        enc = b"".join(ossz.Validator.serialize(v) for v in vs)
+        assert gpu.hash_tree_root_validators(enc) == ossz.SSZList(ossz.Validator, 1 << 40).htr(vs)
+
+
+def test_device_resident_unaligned_slices(gpu):
+    """_dev entry points on byte-unaligned slices of a device buffer (what the state driver does)."""
+    import torch
+    from ethereum_consensus_amd import _lib
+    L = _lib.load()
+    data = rnd(121 * 1000 + 77, 42)
+    t = torch.frombuffer(bytearray(b"\xa5" * 64 + data + b"\xa5" * 64), dtype=torch.uint8).cuda()
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for mis in (0, 1, 2, 3, 7):
+        sl = data[mis: mis + 121 * 999]
+        rc = L.ecgpu_htr_validators_dev(t.data_ptr() + 64 + mis, 999, 1 << 40, out.data_ptr(), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert bytes(out[:32].cpu().numpy()) == cref.htr_validators(sl)[0]
+        n = 32 * 300 + 5
+        rc = L.ecgpu_merkleize_dev(t.data_ptr() + 64 + mis, n, 1 << 20, 1, 9, out.data_ptr() + 32, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert bytes(out[32:].cpu().numpy()) == cref.merkleize_bytes(data[mis: mis + n], 1 << 20, 9)[0]
+
+
+@pytest.mark.parametrize("preset,n", [("minimal", 0), ("minimal", 1), ("minimal", 37), ("minimal", 2000), ("mainnet", 5),
+                                      ("mainnet", 3000)])
+def test_beacon_state_root_vs_python_oracle(gpu, preset, n):
+    from ethereum_consensus_amd import synthetic as S
+    f = S.state_fields(n, preset, seed=n + 3, n_votes=n % 7, n_hist_roots=n % 5, n_hist_summaries=n % 3,
+                       extra_data=b"x" * (n % 33))
+    enc = S.serialize_state(f)
+    P = ossz.MINIMAL if preset == "minimal" else ossz.MAINNET
+    want = ossz.BeaconStateDeneb(P).htr(oracle_state_value(f))
+    assert gpu.hash_tree_root_beacon_state_deneb(enc, S.PRESETS[preset]["id"]) == want
+    assert oracle_state_root_fast(f, preset) == want
+
+
+def test_beacon_state_root_full_size(gpu):
+    """config 3: mainnet preset, 2^20 validators (BASELINE.json configs[2])."""
+    from ethereum_consensus_amd import synthetic as S
+    n = 1 << 20
+    f = S.state_fields(n, "mainnet")
+    enc = S.serialize_state(f)
+    want = oracle_state_root_fast(f, "mainnet")
+    got = gpu.hash_tree_root_beacon_state_deneb(enc, 0)
+    assert got == want
+    hashes = gpu.last_hash64_count()
+    assert 10_000_000 < hashes < 10_300_000
+    # idempotence + sensitivity: flipping one balance bit changes the root, flipping back restores it
+    b = bytearray(enc)
+    assert gpu.hash_tree_root_beacon_state_deneb(enc, 0) == got
+    b[-1] ^= 1
+    assert gpu.hash_tree_root_beacon_state_deneb(bytes(b), 0) != got
+
+
+def test_malformed_state_is_rejected(gpu):
+    from ethereum_consensus_amd import synthetic as S
+    enc = S.beacon_state_deneb(3, "minimal")
+    with pytest.raises(gpu.MerkleizationError):
+        gpu.hash_tree_root_beacon_state_deneb(enc + b"\0", 1)
+    with pytest.raises(gpu.MerkleizationError):
+        gpu.hash_tree_root_beacon_state_deneb(enc[:100], 1)
