@@ -1,0 +1,27 @@
+"""Summarise a rocprofv3 rocpd (sqlite) kernel trace into the per-kernel table rocprofv3 --stats
+prints (name, calls, total/avg/min/max us, %), for committing under profiles/."""
+import sqlite3
+import sys
+
+
+def main(db, out=None):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, "
+                       "max(end-start)/1e3, max(vgpr_count), max(sgpr_count), max(scratch_size), max(lds_size) "
+                       "from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1.0
+    lines = [f"# kernel stats from {db} (durations in microseconds)",
+             f"{'kernel':100s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s} "
+             f"{'vgpr':>5s} {'sgpr':>5s} {'scratch':>8s} {'lds':>6s}"]
+    for r in rows:
+        lines.append(f"{r[0][:100]:100s} {r[1]:6d} {r[2]:12.1f} {r[3]:10.2f} {r[4]:10.2f} {r[5]:10.2f} {100 * r[2] / tot:6.2f} "
+                     f"{r[6]:5d} {r[7]:5d} {r[8]:8d} {r[9]:6d}")
+    text = "\n".join(lines) + "\n"
+    if out:
+        open(out, "w").write(text)
+    else:
+        sys.stdout.write(text)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:3])
