@@ -76,13 +76,23 @@ def build_lib(verbose: bool = True) -> str:
 def build_hostsim(verbose: bool = True) -> str:
     """g++ build of the same csrc headers: CPU-side kernel simulator for tests ONLY."""
     d = os.path.join(ROOT, "tests", "hostsim")
-    src = os.path.join(d, "hostsim.cpp")
+    srcs = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".cpp"))
     out = os.path.join(d, "libhostsim.so")
-    if _newer(out, [src] + _headers()):
+    os.makedirs(os.path.join(d, "obj"), exist_ok=True)
+    objs, jobs = [], []
+    for src in srcs:
+        obj = os.path.join(d, "obj", os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if _newer(obj, [src] + _headers()):
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-c", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+                         "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), src, "-o", obj])
+    if jobs:
         if verbose:
             print("[ecgpu build] building tests/hostsim", flush=True)
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-I" + CSRC,
-              "-I" + os.path.join(ROOT, "include"), src, "-o", out])
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or _newer(out, objs):
+        _run(["g++", "-shared", "-o", out] + objs)
     return out
 
 

@@ -1,0 +1,345 @@
+// G1 (E1/Fp: y^2 = x^3 + 4) and G2 (E2/Fp2: y^2 = x^3 + 4(1+i)) group arithmetic, ZCash point
+// (de)compression and subgroup checks for the gfx950 BLS path.
+//
+// Reference behaviour being replaced (all inside blst, reached from
+// /root/reference/ethereum-consensus/src/crypto/bls.rs):
+//   :279-285  PublicKey::try_from  -> blst key_validate   = g1_decompress + reject inf + subgroup
+//   :330-336  Signature::try_from  -> blst from_bytes     = g2_decompress (on-curve only)
+//   :86-90 / :141-145 aggregate / eth_aggregate_public_keys = decompress + sum + compress
+// Formulas are the standard a = 0 Jacobian ones (dbl-2009-l, add-2007-bl, madd-2007-bl); the
+// subgroup checks are the endomorphism tests (Scott, ePrint 2021/1130):
+//   G1:  phi(P) + P == [x^2] P      (phi(x,y) = (beta x, y) acts as [x^2 - 1] on G1)
+//   G2:  psi(Q) == [x] Q
+// which cost two / one 64-bit scalar multiplications instead of a 255-bit one.
+#pragma once
+#include "ecgpu.h"
+#include "bls_tower.h"
+
+namespace ecg {
+
+// ---- field-generic helpers (overloads over Fp / Fp2) ------------------------------------------
+ECG_HD Fp f_add(const Fp& a, const Fp& b) { return fp_add(a, b); }
+ECG_HD Fp f_sub(const Fp& a, const Fp& b) { return fp_sub(a, b); }
+ECG_HD Fp f_dbl(const Fp& a) { return fp_dbl(a); }
+ECG_HD Fp f_neg(const Fp& a) { return fp_neg(a); }
+ECG_HD Fp f_mul(const Fp& a, const Fp& b) { return fp_mul(a, b); }
+ECG_HD Fp f_sqr(const Fp& a) { return fp_sqr(a); }
+ECG_HD bool f_is_zero(const Fp& a) { return fp_is_zero(a); }
+ECG_HD bool f_eq(const Fp& a, const Fp& b) { return fp_eq(a, b); }
+ECG_HD void f_set_zero(Fp& a) { a = fp_zero(); }
+ECG_HD void f_set_one(Fp& a) { a = fp_one(); }
+ECG_HD Fp f_inv(const Fp& a) { return fp_inv(a); }
+
+ECG_HD Fp2 f_add(const Fp2& a, const Fp2& b) { return fp2_add(a, b); }
+ECG_HD Fp2 f_sub(const Fp2& a, const Fp2& b) { return fp2_sub(a, b); }
+ECG_HD Fp2 f_dbl(const Fp2& a) { return fp2_dbl(a); }
+ECG_HD Fp2 f_neg(const Fp2& a) { return fp2_neg(a); }
+ECG_HD Fp2 f_mul(const Fp2& a, const Fp2& b) { return fp2_mulx(a, b); }
+ECG_HD Fp2 f_sqr(const Fp2& a) { return fp2_sqrx(a); }
+ECG_HD bool f_is_zero(const Fp2& a) { return fp2_is_zero(a); }
+ECG_HD bool f_eq(const Fp2& a, const Fp2& b) { return fp2_eq(a, b); }
+ECG_HD void f_set_zero(Fp2& a) { a = fp2_zero(); }
+ECG_HD void f_set_one(Fp2& a) { a = fp2_one(); }
+ECG_HD Fp2 f_inv(const Fp2& a) { return fp2_inv(a); }
+
+template <class F>
+struct Jac {
+    F x, y, z;
+};
+template <class F>
+struct Aff {
+    F x, y;
+    u32 inf;
+};
+typedef Jac<Fp> J1;
+typedef Jac<Fp2> J2;
+typedef Aff<Fp> A1;
+typedef Aff<Fp2> A2;
+
+template <class F>
+ECG_HD void jac_set_inf(Jac<F>& r) {
+    f_set_one(r.x);
+    f_set_one(r.y);
+    f_set_zero(r.z);
+}
+template <class F>
+ECG_HD bool jac_is_inf(const Jac<F>& p) {
+    return f_is_zero(p.z);
+}
+template <class F>
+ECG_HD void jac_from_aff(Jac<F>& r, const Aff<F>& a) {
+    if (a.inf) {
+        jac_set_inf(r);
+        return;
+    }
+    r.x = a.x;
+    r.y = a.y;
+    f_set_one(r.z);
+}
+template <class F>
+ECG_HD void jac_neg(Jac<F>& r, const Jac<F>& p) {
+    r.x = p.x;
+    r.y = f_neg(p.y);
+    r.z = p.z;
+}
+
+// dbl-2009-l (a = 0).  inf -> inf; y == 0 -> inf.  r may alias p.
+template <class F>
+ECG_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+    F A = f_sqr(p.x);
+    F B = f_sqr(p.y);
+    F C = f_sqr(B);
+    F D = f_sub(f_sub(f_sqr(f_add(p.x, B)), A), C);
+    D = f_dbl(D);
+    F E = f_add(f_dbl(A), A);
+    F Fq = f_sqr(E);
+    F Z3 = f_dbl(f_mul(p.y, p.z));
+    F X3 = f_sub(Fq, f_dbl(D));
+    F C8 = f_dbl(f_dbl(f_dbl(C)));
+    r.y = f_sub(f_mul(E, f_sub(D, X3)), C8);
+    r.x = X3;
+    r.z = Z3;
+}
+
+// madd-2007-bl: Jacobian + affine (affine not infinity).  r may alias p.
+template <class F>
+ECG_HD_NOINLINE void jac_add_aff(Jac<F>& r, const Jac<F>& p, const F& qx, const F& qy) {
+    if (jac_is_inf(p)) {
+        r.x = qx;
+        r.y = qy;
+        f_set_one(r.z);
+        return;
+    }
+    F Z1Z1 = f_sqr(p.z);
+    F U2 = f_mul(qx, Z1Z1);
+    F S2 = f_mul(f_mul(qy, p.z), Z1Z1);
+    F H = f_sub(U2, p.x);
+    F rr = f_sub(S2, p.y);
+    if (f_is_zero(H)) {
+        if (f_is_zero(rr)) {
+            jac_dbl(r, p);
+        } else {
+            jac_set_inf(r);
+        }
+        return;
+    }
+    rr = f_dbl(rr);
+    F HH = f_sqr(H);
+    F I = f_dbl(f_dbl(HH));
+    F J = f_mul(H, I);
+    F V = f_mul(p.x, I);
+    F X3 = f_sub(f_sub(f_sqr(rr), J), f_dbl(V));
+    F Y3 = f_sub(f_mul(rr, f_sub(V, X3)), f_dbl(f_mul(p.y, J)));
+    F Z3 = f_sub(f_sub(f_sqr(f_add(p.z, H)), Z1Z1), HH);
+    r.x = X3;
+    r.y = Y3;
+    r.z = Z3;
+}
+
+// add-2007-bl: Jacobian + Jacobian, all special cases.  r may alias p or q.
+template <class F>
+ECG_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+    if (jac_is_inf(p)) {
+        r = q;
+        return;
+    }
+    if (jac_is_inf(q)) {
+        r = p;
+        return;
+    }
+    F Z1Z1 = f_sqr(p.z);
+    F Z2Z2 = f_sqr(q.z);
+    F U1 = f_mul(p.x, Z2Z2);
+    F U2 = f_mul(q.x, Z1Z1);
+    F S1 = f_mul(f_mul(p.y, q.z), Z2Z2);
+    F S2 = f_mul(f_mul(q.y, p.z), Z1Z1);
+    F H = f_sub(U2, U1);
+    F rr = f_sub(S2, S1);
+    if (f_is_zero(H)) {
+        if (f_is_zero(rr)) {
+            jac_dbl(r, p);
+        } else {
+            jac_set_inf(r);
+        }
+        return;
+    }
+    rr = f_dbl(rr);
+    F I = f_sqr(f_dbl(H));
+    F J = f_mul(H, I);
+    F V = f_mul(U1, I);
+    F X3 = f_sub(f_sub(f_sqr(rr), J), f_dbl(V));
+    F Y3 = f_sub(f_mul(rr, f_sub(V, X3)), f_dbl(f_mul(S1, J)));
+    F Z3 = f_mul(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), Z1Z1), Z2Z2), H);
+    r.x = X3;
+    r.y = Y3;
+    r.z = Z3;
+}
+
+template <class F>
+ECG_HD bool jac_eq(const Jac<F>& p, const Jac<F>& q) {
+    bool pi = jac_is_inf(p), qi = jac_is_inf(q);
+    if (pi || qi) return pi && qi;
+    F Z1Z1 = f_sqr(p.z), Z2Z2 = f_sqr(q.z);
+    if (!f_eq(f_mul(p.x, Z2Z2), f_mul(q.x, Z1Z1))) return false;
+    return f_eq(f_mul(f_mul(p.y, q.z), Z2Z2), f_mul(f_mul(q.y, p.z), Z1Z1));
+}
+
+template <class F>
+ECG_HD void jac_to_aff(Aff<F>& r, const Jac<F>& p) {
+    if (jac_is_inf(p)) {
+        f_set_zero(r.x);
+        f_set_zero(r.y);
+        r.inf = 1;
+        return;
+    }
+    F zi = f_inv(p.z);
+    F zi2 = f_sqr(zi);
+    r.x = f_mul(p.x, zi2);
+    r.y = f_mul(f_mul(p.y, zi2), zi);
+    r.inf = 0;
+}
+
+// [|x|] P, |x| = 0xd201000000010000 (MSB-first double-and-add: 63 doublings, 5 additions)
+template <class F>
+ECG_HD_NOINLINE void jac_mul_xabs(Jac<F>& r, const Jac<F>& p) {
+    Jac<F> acc = p;
+    for (int b = 62; b >= 0; b--) {
+        jac_dbl(acc, acc);
+        if ((blsc::X_ABS >> b) & 1) jac_add(acc, acc, p);
+    }
+    r = acc;
+}
+
+// [k] P for a scalar of `nwords` 32-bit LE words (test-vector generation: sk -> pk, signing)
+template <class F>
+ECG_HD_NOINLINE void jac_mul_scalar(Jac<F>& r, const Jac<F>& p, const u32* k, int nwords) {
+    Jac<F> acc;
+    jac_set_inf(acc);
+    for (int b = nwords * 32 - 1; b >= 0; b--) {
+        jac_dbl(acc, acc);
+        if ((k[b >> 5] >> (b & 31)) & 1) jac_add(acc, acc, p);
+    }
+    r = acc;
+}
+
+// ---- endomorphisms and subgroup checks --------------------------------------------------------
+ECG_HD bool g1_in_subgroup(const A1& p) {
+    if (p.inf) return true;
+    J1 P, t, lhs;
+    jac_from_aff(P, p);
+    jac_mul_xabs(t, P);
+    jac_mul_xabs(t, t);  // [x^2] P
+    Fp bx = fp_mul(p.x, blsc::BETA);
+    jac_add_aff(lhs, P, bx, p.y);  // P + phi(P)
+    return jac_eq(lhs, t);
+}
+
+ECG_HD void g2_psi(J2& r, const J2& p) {
+    r.x = fp2_mulx(fp2_conj(p.x), blsc::PSI_X);
+    r.y = fp2_mulx(fp2_conj(p.y), blsc::PSI_Y);
+    r.z = fp2_conj(p.z);
+}
+
+ECG_HD bool g2_in_subgroup(const A2& q) {
+    if (q.inf) return true;
+    J2 Q, t, ps;
+    jac_from_aff(Q, q);
+    jac_mul_xabs(t, Q);
+    jac_neg(t, t);  // [x] Q, x < 0
+    g2_psi(ps, Q);
+    return jac_eq(ps, t);
+}
+
+// ---- ZCash compressed encodings -> BLST_ERROR codes ---------------------
+// 0 SUCCESS, 1 BAD_ENCODING, 2 POINT_NOT_ON_CURVE, 3 POINT_NOT_IN_GROUP (x == 0), as blst's
+// Uncompress does; infinity decodes to inf = 1 with SUCCESS (the callers decide what it means).
+ECG_HD bool bytes_all_zero(const u8* b, int from, int to) {
+    u32 o = 0;
+    for (int i = from; i < to; i++) o |= b[i];
+    return o == 0;
+}
+
+ECG_HD_NOINLINE int g1_decompress(A1& r, const u8* b) {
+    r.inf = 0;
+    r.x = fp_zero();
+    r.y = fp_zero();
+    const u32 b0 = b[0];
+    if (!(b0 & 0x80)) return ECGPU_BAD_ENCODING;
+    if (b0 & 0x40) {
+        if ((b0 & 0x3f) == 0 && bytes_all_zero(b, 1, 48)) {
+            r.inf = 1;
+            return ECGPU_SUCCESS;
+        }
+        return ECGPU_BAD_ENCODING;
+    }
+    Fp raw = raw_from_be48(b, true);
+    if (raw_geq(raw, blsc::P)) return ECGPU_BAD_ENCODING;
+    Fp x = fp_from_raw(raw);
+    Fp y;
+    if (!fp_sqrt(fp_add(fp_mul(fp_sqr(x), x), blsc::B1), y)) return ECGPU_POINT_NOT_ON_CURVE;
+    if (fp_lex_largest(y) != ((b0 & 0x20) != 0)) y = fp_neg(y);
+    if (fp_is_zero(x)) return ECGPU_POINT_NOT_IN_GROUP;
+    r.x = x;
+    r.y = y;
+    return ECGPU_SUCCESS;
+}
+
+ECG_HD void g1_compress(u8* out, const A1& p) {
+    if (p.inf) {
+        out[0] = 0xc0;
+        for (int i = 1; i < 48; i++) out[i] = 0;
+        return;
+    }
+    raw_to_be48(fp_to_raw(p.x), out);
+    out[0] |= 0x80;
+    if (fp_lex_largest(p.y)) out[0] |= 0x20;
+}
+
+ECG_HD_NOINLINE int g2_decompress(A2& r, const u8* b) {
+    r.inf = 0;
+    r.x = fp2_zero();
+    r.y = fp2_zero();
+    const u32 b0 = b[0];
+    if (!(b0 & 0x80)) return ECGPU_BAD_ENCODING;
+    if (b0 & 0x40) {
+        if ((b0 & 0x3f) == 0 && bytes_all_zero(b, 1, 96)) {
+            r.inf = 1;
+            return ECGPU_SUCCESS;
+        }
+        return ECGPU_BAD_ENCODING;
+    }
+    Fp r1 = raw_from_be48(b, true);
+    Fp r0 = raw_from_be48(b + 48, false);
+    if (raw_geq(r1, blsc::P) || raw_geq(r0, blsc::P)) return ECGPU_BAD_ENCODING;
+    Fp2 x = Fp2{fp_from_raw(r0), fp_from_raw(r1)};
+    Fp2 y;
+    if (!fp2_sqrt(fp2_add(fp2_mulx(fp2_sqrx(x), x), blsc::B2), y)) return ECGPU_POINT_NOT_ON_CURVE;
+    if (fp2_lex_largest(y) != ((b0 & 0x20) != 0)) y = fp2_neg(y);
+    if (fp2_is_zero(x)) return ECGPU_POINT_NOT_IN_GROUP;
+    r.x = x;
+    r.y = y;
+    return ECGPU_SUCCESS;
+}
+
+ECG_HD void g2_compress(u8* out, const A2& p) {
+    if (p.inf) {
+        out[0] = 0xc0;
+        for (int i = 1; i < 96; i++) out[i] = 0;
+        return;
+    }
+    raw_to_be48(fp_to_raw(p.x.c1), out);
+    raw_to_be48(fp_to_raw(p.x.c0), out + 48);
+    out[0] |= 0x80;
+    if (fp2_lex_largest(p.y)) out[0] |= 0x20;
+}
+
+// blst key_validate (crypto/bls.rs:279-285): decode, reject infinity, subgroup check
+ECG_HD int g1_key_validate(A1& r, const u8* b) {
+    int st = g1_decompress(r, b);
+    if (st) return st;
+    if (r.inf) return ECGPU_PK_IS_INFINITY;
+    if (!g1_in_subgroup(r)) return ECGPU_POINT_NOT_IN_GROUP;
+    return ECGPU_SUCCESS;
+}
+
+}  // namespace ecg

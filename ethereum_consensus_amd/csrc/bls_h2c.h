@@ -1,0 +1,171 @@
+// hash_to_curve for G2, suite BLS12381G2_XMD:SHA-256_SSWU_RO_ with the Ethereum proof-of-possession
+// DST (/root/reference/ethereum-consensus/src/crypto/bls.rs:22 `BLS_DST`; performed inside blst for
+// every verify/sign call, crypto/bls.rs:71,106,126,218).  RFC 9380: expand_message_xmd ->
+// hash_to_field (2 x Fp2) -> simplified SWU on E2' -> 3-isogeny -> add -> clear cofactor
+// (Budroni-Pintore via psi).  One lane hashes one message.
+#pragma once
+#include "bls_curve.h"
+#include "sha256.h"
+
+namespace ecg {
+
+namespace blsc {
+// DST || I2OSP(len(DST), 1)
+ECG_CONST u8 DST_PRIME[44] = {'B', 'L', 'S', '_', 'S', 'I', 'G', '_', 'B', 'L', 'S', '1', '2', '3', '8',
+                              '1', 'G', '2', '_', 'X', 'M', 'D', ':', 'S', 'H', 'A', '-', '2', '5', '6',
+                              '_', 'S', 'S', 'W', 'U', '_', 'R', 'O', '_', 'P', 'O', 'P', '_', 43};
+}  // namespace blsc
+
+ECG_HD_NOINLINE void sha256_block(u32* st, u32* w) { sha256_compress(st, w); }
+
+// byte-oriented SHA-256 with the block kept in the lane's private memory
+struct Sha256B {
+    u32 st[8];
+    u8 blk[64];
+    u32 fill;
+    u64 total;
+};
+ECG_HD void shab_init(Sha256B& s) {
+    for (int i = 0; i < 8; i++) s.st[i] = SHA256_IV[i];
+    s.fill = 0;
+    s.total = 0;
+}
+ECG_HD void shab_flush(Sha256B& s) {
+    u32 w[16];
+    for (int i = 0; i < 16; i++)
+        w[i] = ((u32)s.blk[4 * i] << 24) | ((u32)s.blk[4 * i + 1] << 16) | ((u32)s.blk[4 * i + 2] << 8) | s.blk[4 * i + 3];
+    sha256_block(s.st, w);
+    s.fill = 0;
+}
+ECG_HD void shab_put(Sha256B& s, u8 b) {
+    s.blk[s.fill++] = b;
+    s.total++;
+    if (s.fill == 64) shab_flush(s);
+}
+ECG_HD void shab_update(Sha256B& s, const u8* p, size_t n) {
+    for (size_t i = 0; i < n; i++) shab_put(s, p[i]);
+}
+ECG_HD void shab_final(Sha256B& s, u8 out[32]) {
+    const u64 bits = s.total * 8;
+    shab_put(s, 0x80);
+    while (s.fill != 56) shab_put(s, 0);
+    for (int i = 7; i >= 0; i--) shab_put(s, (u8)(bits >> (8 * i)));
+    for (int i = 0; i < 8; i++) {
+        out[4 * i] = (u8)(s.st[i] >> 24);
+        out[4 * i + 1] = (u8)(s.st[i] >> 16);
+        out[4 * i + 2] = (u8)(s.st[i] >> 8);
+        out[4 * i + 3] = (u8)s.st[i];
+    }
+}
+
+// expand_message_xmd(msg, DST, 256): 3 + 8 x 2 compressions for a 32-byte message
+ECG_HD_NOINLINE void xmd_expand_256(u8* out, const u8* msg, size_t msg_len) {
+    Sha256B s;
+    u8 b0[32], bi[32];
+    shab_init(s);
+    for (int i = 0; i < 64; i++) shab_put(s, 0);  // Z_pad
+    shab_update(s, msg, msg_len);
+    shab_put(s, 0x01);  // l_i_b_str = I2OSP(256, 2)
+    shab_put(s, 0x00);
+    shab_put(s, 0x00);  // I2OSP(0, 1)
+    for (int i = 0; i < 44; i++) shab_put(s, blsc::DST_PRIME[i]);
+    shab_final(s, b0);
+    for (int k = 1; k <= 8; k++) {
+        shab_init(s);
+        for (int i = 0; i < 32; i++) shab_put(s, k == 1 ? b0[i] : (u8)(b0[i] ^ bi[i]));
+        shab_put(s, (u8)k);
+        for (int i = 0; i < 44; i++) shab_put(s, blsc::DST_PRIME[i]);
+        shab_final(s, bi);
+        for (int i = 0; i < 32; i++) out[32 * (k - 1) + i] = bi[i];
+    }
+}
+
+// OS2IP(64 bytes) mod p -> Montgomery
+ECG_HD Fp fp_from_be64(const u8* b) {
+    u32 w[12];
+    for (int i = 0; i < 12; i++) w[i] = 0;
+    for (int i = 0; i < 4; i++) {
+        const u8* q = b + 4 * (3 - i);
+        w[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | q[3];
+    }
+    Fp hi = raw_from_words(w);
+    Fp lo = raw_from_be48(b + 16, false);
+    return fp_add(fp_mul(lo, blsc::R2), fp_mul(hi, blsc::R2_384));
+}
+
+ECG_HD Fp2 fp2_horner(const Fp2* c, int deg, const Fp2& x) {
+    Fp2 acc = c[deg];
+    for (int i = deg - 1; i >= 0; i--) acc = fp2_add(fp2_mulx(acc, x), c[i]);
+    return acc;
+}
+
+// simplified SWU onto E2' (RFC 9380 6.6.2, straight-line form) then the 3-isogeny to E2, result in
+// Jacobian coordinates (no inversion for the isogeny denominators).
+ECG_HD_NOINLINE void map_to_curve_g2(J2& r, const Fp2& u) {
+    Fp2 tv1 = fp2_mulx(blsc::SSWU_Z, fp2_sqrx(u));
+    Fp2 tv2 = fp2_add(fp2_sqrx(tv1), tv1);
+    Fp2 x1;
+    if (fp2_is_zero(tv2)) {
+        x1 = blsc::SSWU_B_OVER_ZA;
+    } else {
+        x1 = fp2_mulx(blsc::SSWU_MB_OVER_A, fp2_add(fp2_one(), fp2_inv(tv2)));
+    }
+    Fp2 gx1 = fp2_add(fp2_add(fp2_mulx(fp2_sqrx(x1), x1), fp2_mulx(blsc::SSWU_A, x1)), blsc::SSWU_B);
+    Fp2 x = x1, y;
+    if (!fp2_sqrt(gx1, y)) {
+        x = fp2_mulx(tv1, x1);
+        Fp2 gx2 = fp2_add(fp2_add(fp2_mulx(fp2_sqrx(x), x), fp2_mulx(blsc::SSWU_A, x)), blsc::SSWU_B);
+        (void)fp2_sqrt(gx2, y);  // exactly one of gx1, gx2 is a square
+    }
+    if (fp2_sgn0(u) != fp2_sgn0(y)) y = fp2_neg(y);
+    // iso3: x' = xn/xd, y' = y yn/yd  ->  Jacobian with Z = xd yd
+    Fp2 xn = fp2_horner(blsc::ISO_XNUM, 3, x);
+    Fp2 xd = fp2_horner(blsc::ISO_XDEN, 2, x);
+    Fp2 yn = fp2_horner(blsc::ISO_YNUM, 3, x);
+    Fp2 yd = fp2_horner(blsc::ISO_YDEN, 3, x);
+    if (fp2_is_zero(xd) || fp2_is_zero(yd)) {
+        jac_set_inf(r);  // exceptional point of the isogeny
+        return;
+    }
+    Fp2 z = fp2_mulx(xd, yd);
+    Fp2 yd2 = fp2_sqrx(yd);
+    r.x = fp2_mulx(fp2_mulx(xn, xd), yd2);                                       // xn xd yd^2
+    r.y = fp2_mulx(fp2_mulx(fp2_mulx(y, yn), fp2_mulx(fp2_sqrx(xd), xd)), yd2);  // y yn xd^3 yd^2
+    r.z = z;
+}
+
+// h_eff multiplication by Budroni-Pintore: [x^2 - x - 1] P + [x - 1] psi(P) + psi^2(2P)
+ECG_HD_NOINLINE void g2_clear_cofactor(J2& r, const J2& p) {
+    J2 t1, t2, t3, n;
+    jac_mul_xabs(t1, p);
+    jac_neg(t1, t1);  // [x] P
+    g2_psi(t2, p);    // psi(P)
+    jac_dbl(t3, p);
+    g2_psi(t3, t3);
+    g2_psi(t3, t3);  // psi^2(2P)
+    jac_neg(n, t2);
+    jac_add(t3, t3, n);   // psi^2(2P) - psi(P)
+    jac_add(t2, t1, t2);  // [x] P + psi(P)
+    jac_mul_xabs(t2, t2);
+    jac_neg(t2, t2);  // [x^2] P + [x] psi(P)
+    jac_add(t3, t3, t2);
+    jac_neg(n, t1);
+    jac_add(t3, t3, n);
+    jac_neg(n, p);
+    jac_add(r, t3, n);
+}
+
+ECG_HD_NOINLINE void hash_to_g2(A2& r, const u8* msg, size_t msg_len) {
+    u8 xm[256];
+    xmd_expand_256(xm, msg, msg_len);
+    Fp2 u0 = Fp2{fp_from_be64(xm), fp_from_be64(xm + 64)};
+    Fp2 u1 = Fp2{fp_from_be64(xm + 128), fp_from_be64(xm + 192)};
+    J2 q0, q1;
+    map_to_curve_g2(q0, u0);
+    map_to_curve_g2(q1, u1);
+    jac_add(q0, q0, q1);
+    g2_clear_cofactor(q0, q0);
+    jac_to_aff(r, q0);
+}
+
+}  // namespace ecg

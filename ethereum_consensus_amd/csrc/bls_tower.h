@@ -1,0 +1,206 @@
+// Fp6 / Fp12 tower arithmetic for the BLS12-381 pairing on gfx950:
+//   Fp6 = Fp2[v]/(v^3 - xi), xi = 1 + i;   Fp12 = Fp6[w]/(w^2 - v).
+// (blst's fp12_tower.c layer under /root/reference/ethereum-consensus/src/crypto/bls.rs:69-71,
+// 102-106, 122-126 -- the verify calls.)  An Fp12 is 12 x 13 dwords: it never fits in VGPRs next
+// to its operands, so everything here works memory-to-memory on references (the lane's private
+// segment) and only the Fp2 products inside are register-resident.
+#pragma once
+#include "bls_fp.h"
+
+namespace ecg {
+
+// out-of-line Fp2 products: one body per kernel
+ECG_HD_NOINLINE void fp2_mul_to(Fp2& r, const Fp2& a, const Fp2& b) { r = fp2_mul(a, b); }
+ECG_HD_NOINLINE void fp2_sqr_to(Fp2& r, const Fp2& a) { r = fp2_sqr(a); }
+ECG_HD Fp2 fp2_mulx(const Fp2& a, const Fp2& b) {
+    Fp2 r;
+    fp2_mul_to(r, a, b);
+    return r;
+}
+ECG_HD Fp2 fp2_sqrx(const Fp2& a) {
+    Fp2 r;
+    fp2_sqr_to(r, a);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fp6
+// ---------------------------------------------------------------------------------------------
+ECG_HD Fp6 fp6_zero() { return Fp6{fp2_zero(), fp2_zero(), fp2_zero()}; }
+ECG_HD Fp6 fp6_one() { return Fp6{fp2_one(), fp2_zero(), fp2_zero()}; }
+ECG_HD void fp6_add(Fp6& r, const Fp6& a, const Fp6& b) {
+    r.c0 = fp2_add(a.c0, b.c0);
+    r.c1 = fp2_add(a.c1, b.c1);
+    r.c2 = fp2_add(a.c2, b.c2);
+}
+ECG_HD void fp6_sub(Fp6& r, const Fp6& a, const Fp6& b) {
+    r.c0 = fp2_sub(a.c0, b.c0);
+    r.c1 = fp2_sub(a.c1, b.c1);
+    r.c2 = fp2_sub(a.c2, b.c2);
+}
+ECG_HD void fp6_neg(Fp6& r, const Fp6& a) {
+    r.c0 = fp2_neg(a.c0);
+    r.c1 = fp2_neg(a.c1);
+    r.c2 = fp2_neg(a.c2);
+}
+// multiply by v: (a0 + a1 v + a2 v^2) v = xi a2 + a0 v + a1 v^2
+ECG_HD void fp6_mul_v(Fp6& r, const Fp6& a) {
+    Fp2 t = fp2_mul_xi(a.c2);
+    r.c2 = a.c1;
+    r.c1 = a.c0;
+    r.c0 = t;
+}
+// Karatsuba, 6 Fp2 products.  r may alias a or b.
+ECG_HD_NOINLINE void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
+    Fp2 t0 = fp2_mulx(a.c0, b.c0);
+    Fp2 t1 = fp2_mulx(a.c1, b.c1);
+    Fp2 t2 = fp2_mulx(a.c2, b.c2);
+    Fp2 m12 = fp2_mulx(fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2));
+    Fp2 m01 = fp2_mulx(fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1));
+    Fp2 m02 = fp2_mulx(fp2_add(a.c0, a.c2), fp2_add(b.c0, b.c2));
+    r.c0 = fp2_add(t0, fp2_mul_xi(fp2_sub(fp2_sub(m12, t1), t2)));
+    r.c1 = fp2_add(fp2_sub(fp2_sub(m01, t0), t1), fp2_mul_xi(t2));
+    r.c2 = fp2_add(fp2_sub(fp2_sub(m02, t0), t2), t1);
+}
+// a * (c0 + c1 v): 5 Fp2 products
+ECG_HD_NOINLINE void fp6_mul_by_01(Fp6& r, const Fp6& a, const Fp2& c0, const Fp2& c1) {
+    Fp2 t0 = fp2_mulx(a.c0, c0);
+    Fp2 t1 = fp2_mulx(a.c1, c1);
+    Fp2 mid = fp2_sub(fp2_sub(fp2_mulx(fp2_add(a.c0, a.c1), fp2_add(c0, c1)), t0), t1);
+    Fp2 s2b = fp2_mulx(a.c2, c1);
+    Fp2 s2a = fp2_mulx(a.c2, c0);
+    r.c0 = fp2_add(t0, fp2_mul_xi(s2b));
+    r.c1 = mid;
+    r.c2 = fp2_add(t1, s2a);
+}
+// a * (c1 v): 3 Fp2 products
+ECG_HD_NOINLINE void fp6_mul_by_1(Fp6& r, const Fp6& a, const Fp2& c1) {
+    Fp2 t0 = fp2_mul_xi(fp2_mulx(a.c2, c1));
+    Fp2 t1 = fp2_mulx(a.c0, c1);
+    Fp2 t2 = fp2_mulx(a.c1, c1);
+    r.c0 = t0;
+    r.c1 = t1;
+    r.c2 = t2;
+}
+ECG_HD_NOINLINE void fp6_inv(Fp6& r, const Fp6& a) {
+    Fp2 c0 = fp2_sub(fp2_sqrx(a.c0), fp2_mul_xi(fp2_mulx(a.c1, a.c2)));
+    Fp2 c1 = fp2_sub(fp2_mul_xi(fp2_sqrx(a.c2)), fp2_mulx(a.c0, a.c1));
+    Fp2 c2 = fp2_sub(fp2_sqrx(a.c1), fp2_mulx(a.c0, a.c2));
+    Fp2 t = fp2_add(fp2_mulx(a.c0, c0), fp2_mul_xi(fp2_add(fp2_mulx(a.c2, c1), fp2_mulx(a.c1, c2))));
+    Fp2 ti = fp2_inv(t);
+    r.c0 = fp2_mulx(c0, ti);
+    r.c1 = fp2_mulx(c1, ti);
+    r.c2 = fp2_mulx(c2, ti);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fp12
+// ---------------------------------------------------------------------------------------------
+ECG_HD void fp12_set_one(Fp12& r) {
+    r.c0 = fp6_one();
+    r.c1 = fp6_zero();
+}
+ECG_HD bool fp12_is_one(const Fp12& a) {
+    return fp_eq(a.c0.c0.c0, fp_one()) && fp_is_zero(a.c0.c0.c1) && fp2_is_zero(a.c0.c1) && fp2_is_zero(a.c0.c2) &&
+           fp2_is_zero(a.c1.c0) && fp2_is_zero(a.c1.c1) && fp2_is_zero(a.c1.c2);
+}
+ECG_HD void fp12_conj(Fp12& r, const Fp12& a) {
+    r.c0 = a.c0;
+    fp6_neg(r.c1, a.c1);
+}
+// 3 Fp6 products.  r may alias a or b.
+ECG_HD_NOINLINE void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
+    Fp6 t0, t1, sa, sb, m;
+    fp6_mul(t0, a.c0, b.c0);
+    fp6_mul(t1, a.c1, b.c1);
+    fp6_add(sa, a.c0, a.c1);
+    fp6_add(sb, b.c0, b.c1);
+    fp6_mul(m, sa, sb);
+    fp6_sub(m, m, t0);
+    fp6_sub(r.c1, m, t1);
+    fp6_mul_v(t1, t1);
+    fp6_add(r.c0, t0, t1);
+}
+// complex squaring, 2 Fp6 products: c0 = (a0 + a1)(a0 + v a1) - a0a1 - v a0a1, c1 = 2 a0a1
+ECG_HD_NOINLINE void fp12_sqr(Fp12& r, const Fp12& a) {
+    Fp6 ab, s, t, va1;
+    fp6_mul(ab, a.c0, a.c1);
+    fp6_add(s, a.c0, a.c1);
+    fp6_mul_v(va1, a.c1);
+    fp6_add(t, a.c0, va1);
+    fp6_mul(s, s, t);
+    fp6_sub(s, s, ab);
+    fp6_mul_v(t, ab);
+    fp6_sub(r.c0, s, t);
+    fp6_add(r.c1, ab, ab);
+}
+// f * ((l0 + l1 v) + (l2 v) w): the Miller-loop line shape on the M-twist, 13 Fp2 products.
+ECG_HD_NOINLINE void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+    Fp6 aa, bb, s, m;
+    fp6_mul_by_01(aa, f.c0, l0, l1);
+    fp6_mul_by_1(bb, f.c1, l2);
+    fp6_add(s, f.c0, f.c1);
+    fp6_mul_by_01(m, s, l0, fp2_add(l1, l2));
+    fp6_sub(m, m, aa);
+    fp6_sub(f.c1, m, bb);
+    fp6_mul_v(bb, bb);
+    fp6_add(f.c0, aa, bb);
+}
+ECG_HD_NOINLINE void fp12_inv(Fp12& r, const Fp12& a) {
+    Fp6 t0, t1;
+    fp6_mul(t0, a.c0, a.c0);
+    fp6_mul(t1, a.c1, a.c1);
+    fp6_mul_v(t1, t1);
+    fp6_sub(t0, t0, t1);
+    fp6_inv(t1, t0);
+    fp6_mul(r.c0, a.c0, t1);
+    fp6_mul(t0, a.c1, t1);
+    fp6_neg(r.c1, t0);
+}
+// Frobenius a -> a^p: with a = sum_k a_k w^k (c0 = (a0, a2, a4), c1 = (a1, a3, a5)),
+// a_k -> conj(a_k) * xi^(k (p-1)/6).
+ECG_HD_NOINLINE void fp12_frob(Fp12& r, const Fp12& a) {
+    r.c0.c0 = fp2_conj(a.c0.c0);
+    r.c1.c0 = fp2_mulx(fp2_conj(a.c1.c0), blsc::FROB_GAMMA[1]);
+    r.c0.c1 = fp2_mulx(fp2_conj(a.c0.c1), blsc::FROB_GAMMA[2]);
+    r.c1.c1 = fp2_mulx(fp2_conj(a.c1.c1), blsc::FROB_GAMMA[3]);
+    r.c0.c2 = fp2_mulx(fp2_conj(a.c0.c2), blsc::FROB_GAMMA[4]);
+    r.c1.c2 = fp2_mulx(fp2_conj(a.c1.c2), blsc::FROB_GAMMA[5]);
+}
+
+// Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the
+// final exponentiation): 3 Fp4 squarings = 9 Fp2 squarings instead of 12 Fp2 products.
+ECG_HD void fp4_sqr(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
+    Fp2 t0 = fp2_sqrx(a);
+    Fp2 t1 = fp2_sqrx(b);
+    c0 = fp2_add(fp2_mul_xi(t1), t0);
+    c1 = fp2_sub(fp2_sub(fp2_sqrx(fp2_add(a, b)), t0), t1);
+}
+ECG_HD_NOINLINE void fp12_cyclotomic_sqr(Fp12& r, const Fp12& f) {
+    Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+    Fp2 t0, t1, t2, t3;
+    fp4_sqr(t0, t1, z0, z1);
+    z0 = fp2_sub(t0, z0);
+    z0 = fp2_add(fp2_dbl(z0), t0);
+    z1 = fp2_add(t1, z1);
+    z1 = fp2_add(fp2_dbl(z1), t1);
+    fp4_sqr(t0, t1, z2, z3);
+    fp4_sqr(t2, t3, z4, z5);
+    z4 = fp2_sub(t0, z4);
+    z4 = fp2_add(fp2_dbl(z4), t0);
+    z5 = fp2_add(t1, z5);
+    z5 = fp2_add(fp2_dbl(z5), t1);
+    t0 = fp2_mul_xi(t3);
+    z2 = fp2_add(t0, z2);
+    z2 = fp2_add(fp2_dbl(z2), t0);
+    z3 = fp2_sub(t2, z3);
+    z3 = fp2_add(fp2_dbl(z3), t2);
+    r.c0.c0 = z0;
+    r.c0.c1 = z4;
+    r.c0.c2 = z3;
+    r.c1.c0 = z2;
+    r.c1.c1 = z1;
+    r.c1.c2 = z5;
+}
+
+}  // namespace ecg

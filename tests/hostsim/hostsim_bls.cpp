@@ -1,0 +1,224 @@
+// tests/hostsim (BLS half): CPU-side execution of the very same ECG_HD lane programs the gfx950
+// kernels run -- TEST INFRASTRUCTURE ONLY (see hostsim.cpp).  Values cross this boundary as
+// big-endian canonical integers so that the tests can compare with oracle/bls12_381.py directly.
+#include <cstring>
+
+#include "ecgpu.h"
+#include "bls_verify.h"
+
+using namespace ecg;
+
+static Fp in_fp(const u8* b) { return fp_from_raw(raw_from_be48(b, false)); }
+static void out_fp(const Fp& a, u8* b) { raw_to_be48(fp_to_raw(a), b); }
+static Fp2 in_fp2(const u8* b) { return Fp2{in_fp(b), in_fp(b + 48)}; }
+static void out_fp2(const Fp2& a, u8* b) {
+    out_fp(a.c0, b);
+    out_fp(a.c1, b + 48);
+}
+
+extern "C" {
+
+// op: 0 mul 1 add 2 sub 3 neg 4 inv 5 sqrt(returns 1 if square) 6 sqr 7 lex_largest 8 dbl 9 is_zero 10 eq
+int hs_fp_op(int op, const u8* a, const u8* b, u8* out) {
+    Fp x = in_fp(a), y = b ? in_fp(b) : fp_zero(), r = fp_zero();
+    int rc = 0;
+    switch (op) {
+        case 0: r = fp_mul(x, y); break;
+        case 1: r = fp_add(x, y); break;
+        case 2: r = fp_sub(x, y); break;
+        case 3: r = fp_neg(x); break;
+        case 4: r = fp_inv(x); break;
+        case 5: rc = fp_sqrt(x, r) ? 1 : 0; break;
+        case 6: r = fp_sqr(x); break;
+        case 7: rc = fp_lex_largest(x) ? 1 : 0; break;
+        case 8: r = fp_dbl(x); break;
+        case 9: rc = fp_is_zero(x) ? 1 : 0; break;
+        case 10: rc = fp_eq(x, y) ? 1 : 0; break;
+        default: return -1;
+    }
+    out_fp(r, out);
+    return rc;
+}
+
+// chained stress: r = a; repeat n times r = r*b + a - b (keeps values in the lazy [0,2p) range busy)
+void hs_fp_chain(const u8* a, const u8* b, int n, u8* out) {
+    Fp x = in_fp(a), y = in_fp(b), r = x;
+    for (int i = 0; i < n; i++) r = fp_sub(fp_add(fp_mul(r, y), x), y);
+    out_fp(r, out);
+}
+
+// op: 0 mul 1 sqr 2 inv 3 sqrt(rc=1 if square) 4 sgn0 5 lex_largest 6 mul_xi 7 add 8 sub 9 neg 10 conj
+int hs_fp2_op(int op, const u8* a, const u8* b, u8* out) {
+    Fp2 x = in_fp2(a), y = b ? in_fp2(b) : fp2_zero(), r = fp2_zero();
+    int rc = 0;
+    switch (op) {
+        case 0: r = fp2_mul(x, y); break;
+        case 1: r = fp2_sqr(x); break;
+        case 2: r = fp2_inv(x); break;
+        case 3: rc = fp2_sqrt(x, r) ? 1 : 0; break;
+        case 4: rc = (int)fp2_sgn0(x); break;
+        case 5: rc = fp2_lex_largest(x) ? 1 : 0; break;
+        case 6: r = fp2_mul_xi(x); break;
+        case 7: r = fp2_add(x, y); break;
+        case 8: r = fp2_sub(x, y); break;
+        case 9: r = fp2_neg(x); break;
+        case 10: r = fp2_conj(x); break;
+        default: return -1;
+    }
+    out_fp2(r, out);
+    return rc;
+}
+
+// ---- points ----------------------------------------------------------------------------------
+// affine points cross as x||y big-endian canonical (96 B for G1, 192 B for G2: x.c0 x.c1 y.c0 y.c1)
+static void out_a1(const A1& p, u8* b) {
+    out_fp(p.x, b);
+    out_fp(p.y, b + 48);
+}
+static void out_a2(const A2& p, u8* b) {
+    out_fp2(p.x, b);
+    out_fp2(p.y, b + 96);
+}
+static A1 in_a1(const u8* b, int inf) {
+    A1 p;
+    p.x = in_fp(b);
+    p.y = in_fp(b + 48);
+    p.inf = (u32)inf;
+    return p;
+}
+static A2 in_a2(const u8* b, int inf) {
+    A2 p;
+    p.x = in_fp2(b);
+    p.y = in_fp2(b + 96);
+    p.inf = (u32)inf;
+    return p;
+}
+
+int hs_g1_decompress(const u8* b48, u8* xy, int* inf) {
+    A1 p;
+    int st = g1_decompress(p, b48);
+    out_a1(p, xy);
+    *inf = (int)p.inf;
+    return st;
+}
+int hs_g1_key_validate(const u8* b48, u8* xy) {
+    A1 p;
+    int st = g1_key_validate(p, b48);
+    out_a1(p, xy);
+    return st;
+}
+int hs_g1_in_subgroup(const u8* xy) { return g1_in_subgroup(in_a1(xy, 0)) ? 1 : 0; }
+void hs_g1_compress(const u8* xy, int inf, u8* out48) { g1_compress(out48, in_a1(xy, inf)); }
+// sum of n affine points (inf flags in `infs`), result affine
+void hs_g1_sum(const u8* xys, const int* infs, int n, u8* xy, int* inf) {
+    J1 acc;
+    jac_set_inf(acc);
+    for (int i = 0; i < n; i++) {
+        A1 p = in_a1(xys + 96 * i, infs[i]);
+        J1 q;
+        jac_from_aff(q, p);
+        if (i & 1) jac_add(acc, acc, q);
+        else if (!p.inf) jac_add_aff(acc, acc, p.x, p.y);
+    }
+    A1 r;
+    jac_to_aff(r, acc);
+    out_a1(r, xy);
+    *inf = (int)r.inf;
+}
+void hs_g1_mul(const u8* xy, const u8* k32be, u8* out, int* inf) {
+    u32 k[8];
+    for (int i = 0; i < 8; i++) k[i] = ((u32)k32be[4 * (7 - i)] << 24) | ((u32)k32be[4 * (7 - i) + 1] << 16) | ((u32)k32be[4 * (7 - i) + 2] << 8) | k32be[4 * (7 - i) + 3];
+    J1 P, R;
+    jac_from_aff(P, in_a1(xy, 0));
+    jac_mul_scalar(R, P, k, 8);
+    A1 r;
+    jac_to_aff(r, R);
+    out_a1(r, out);
+    *inf = (int)r.inf;
+}
+
+int hs_g2_decompress(const u8* b96, u8* xy, int* inf) {
+    A2 p;
+    int st = g2_decompress(p, b96);
+    out_a2(p, xy);
+    *inf = (int)p.inf;
+    return st;
+}
+int hs_g2_in_subgroup(const u8* xy) { return g2_in_subgroup(in_a2(xy, 0)) ? 1 : 0; }
+void hs_g2_compress(const u8* xy, int inf, u8* out96) { g2_compress(out96, in_a2(xy, inf)); }
+void hs_g2_sum(const u8* xys, const int* infs, int n, u8* xy, int* inf) {
+    J2 acc;
+    jac_set_inf(acc);
+    for (int i = 0; i < n; i++) {
+        A2 p = in_a2(xys + 192 * i, infs[i]);
+        J2 q;
+        jac_from_aff(q, p);
+        if (i & 1) jac_add(acc, acc, q);
+        else if (!p.inf) jac_add_aff(acc, acc, p.x, p.y);
+    }
+    A2 r;
+    jac_to_aff(r, acc);
+    out_a2(r, xy);
+    *inf = (int)r.inf;
+}
+void hs_g2_mul(const u8* xy, const u8* k32be, u8* out, int* inf) {
+    u32 k[8];
+    for (int i = 0; i < 8; i++) k[i] = ((u32)k32be[4 * (7 - i)] << 24) | ((u32)k32be[4 * (7 - i) + 1] << 16) | ((u32)k32be[4 * (7 - i) + 2] << 8) | k32be[4 * (7 - i) + 3];
+    J2 P, R;
+    jac_from_aff(P, in_a2(xy, 0));
+    jac_mul_scalar(R, P, k, 8);
+    A2 r;
+    jac_to_aff(r, R);
+    out_a2(r, out);
+    *inf = (int)r.inf;
+}
+void hs_xmd(const u8* msg, u64 len, u8* out256) { xmd_expand_256(out256, msg, (size_t)len); }
+void hs_hash_to_g2(const u8* msg, u64 len, u8* xy, int* inf) {
+    A2 h;
+    hash_to_g2(h, msg, (size_t)len);
+    out_a2(h, xy);
+    *inf = (int)h.inf;
+}
+
+// ---- Fp12: 12 Fp coefficients in the order c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1 -------------
+static void out_fp12(const Fp12& a, u8* b) {
+    const Fp2* c[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
+    for (int i = 0; i < 6; i++) out_fp2(*c[i], b + 96 * i);
+}
+static Fp12 in_fp12(const u8* b) {
+    Fp12 a;
+    Fp2* c[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
+    for (int i = 0; i < 6; i++) *c[i] = in_fp2(b + 96 * i);
+    return a;
+}
+// op: 0 mul 1 sqr 2 inv 3 frob 4 conj 5 cyclotomic_sqr 6 final_exp 7 cyc_pow_x
+void hs_fp12_op(int op, const u8* a, const u8* b, u8* out) {
+    Fp12 x = in_fp12(a), y, r;
+    if (b) y = in_fp12(b);
+    switch (op) {
+        case 0: fp12_mul(r, x, y); break;
+        case 1: fp12_sqr(r, x); break;
+        case 2: fp12_inv(r, x); break;
+        case 3: fp12_frob(r, x); break;
+        case 4: fp12_conj(r, x); break;
+        case 5: fp12_cyclotomic_sqr(r, x); break;
+        case 6: final_exponentiation(r, x); break;
+        default: fp12_cyc_pow_x(r, x); break;
+    }
+    out_fp12(r, out);
+}
+// final_exponentiation(miller(P0,Q0) * miller(P1,Q1)); n = 1 or 2 pairs
+void hs_pairing(int n, const u8* p_xy, const int* p_inf, const u8* q_xy, const int* q_inf, u8* out) {
+    MillerPair pr[2];
+    for (int k = 0; k < n; k++) miller_pair_init(pr[k], in_a1(p_xy + 96 * k, p_inf[k]), in_a2(q_xy + 192 * k, q_inf[k]));
+    Fp12 f, e;
+    miller_loop(f, pr, n);
+    final_exponentiation(e, f);
+    out_fp12(e, out);
+}
+
+int hs_fast_aggregate_verify(const u8* pks48, u32 k, const u8* msg, u64 msg_len, const u8* sig96, int eth) {
+    return fav_tuple_serial(pks48, k, msg, (size_t)msg_len, sig96, eth != 0);
+}
+
+}  // extern "C"
