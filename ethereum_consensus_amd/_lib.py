@@ -61,6 +61,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_fast_aggregate_verify_batch": (c_int, [u8p, ctypes.c_void_p, u8p, u8p, c_u32, c_int, u8p]),
         "ecgpu_fast_aggregate_verify_batch_dev": (c_int, [u8p, ctypes.c_void_p, c_u32, u8p, u8p, c_u32, c_int, u8p,
                                                           ctypes.c_void_p]),
+        "ecgpu_sk_to_pk_batch": (c_int, [u8p, c_u32, u8p]),
+        "ecgpu_sign_batch": (c_int, [u8p, u8p, ctypes.c_void_p, c_u32, u8p]),
+        "ecgpu_sk_to_pk_batch_dev": (c_int, [u8p, c_u32, u8p, ctypes.c_void_p]),
+        "ecgpu_sign_batch_dev": (c_int, [u8p, c_u32, u8p, c_u32, u8p, ctypes.c_void_p]),
         "ecgpu_prof_enable": (c_int, [c_int]),
         "ecgpu_prof_filter": (c_int, [ctypes.c_char_p]),
         "ecgpu_prof_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_u64)]),

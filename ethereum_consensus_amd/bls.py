@@ -1,0 +1,208 @@
+"""Host-side mirror of `ethereum_consensus::crypto` (BLS half), backed by the HIP kernels.
+
+Same names, argument meaning and error behaviour as the reference wrappers in
+/root/reference/ethereum-consensus/src/crypto/bls.rs:
+    verify_signature :64-77, aggregate :79-93, aggregate_verify :95-112,
+    fast_aggregate_verify :114-132, eth_aggregate_public_keys :135-148,
+    eth_fast_aggregate_verify :150-160, Error :27-42, BLSTError :44-62.
+Public keys are 48 bytes, signatures 96 bytes (`ByteVector<48|96>`, bls.rs:239,290): any other length
+is rejected here exactly as the reference's constructors reject it (bls.rs:372-406,463-487).
+Everything is computed on the GPU through libecgpu.so; a missing library or device raises.
+The `*_batch` functions are the extension the GPU backend exists for: one call per block / epoch.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Sequence
+
+from . import _lib
+
+BLS_DST = b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"  # bls.rs:22
+PUBLIC_KEY_BYTES_LEN = 48
+SIGNATURE_BYTES_LEN = 96
+INFINITY_COMPRESSED_SIGNATURE = bytes([0xC0]) + bytes(95)  # bls.rs:338-343
+
+_BLST_STRINGS = {  # bls.rs:48-62
+    1: "bad encoding",
+    2: "point not on curve",
+    3: "point not in group",
+    4: "aggregation type mismatch",
+    5: "verification failed",
+    6: "public key is infinity",
+    7: "bad scalar",
+}
+_DECODE_CODES = (1, 2, 3, 6)  # raised by TryFrom<&PublicKey>/<&Signature> -> Error::BLST
+EMPTY_AGGREGATE = -100
+
+
+class Error(Exception):
+    """crypto::Error (bls.rs:27-42)."""
+
+
+class InvalidSignature(Error):
+    def __init__(self):
+        super().__init__("invalid signature")
+
+
+class EmptyAggregate(Error):
+    def __init__(self):
+        super().__init__("attempt to aggregate empty set")
+
+
+class BLSTError(Error):
+    def __init__(self, code: int):
+        self.code = code
+        super().__init__(_BLST_STRINGS.get(code, f"unknown blst error {code}"))
+
+
+class InvalidLength(Error):
+    """ByteVector<N> construction failure (ssz/byte_vector.rs:24-30)."""
+
+
+def _pk(b: bytes) -> bytes:
+    b = bytes(b)
+    if len(b) != PUBLIC_KEY_BYTES_LEN:
+        raise InvalidLength(f"public key must be {PUBLIC_KEY_BYTES_LEN} bytes, got {len(b)}")
+    return b
+
+
+def _sig(b: bytes) -> bytes:
+    b = bytes(b)
+    if len(b) != SIGNATURE_BYTES_LEN:
+        raise InvalidLength(f"signature must be {SIGNATURE_BYTES_LEN} bytes, got {len(b)}")
+    return b
+
+
+def _buf(b: bytes):
+    return ctypes.create_string_buffer(bytes(b), len(b)) if len(b) else ctypes.create_string_buffer(1)
+
+
+def _raise_for(code: int) -> None:
+    """Map a BLST_ERROR to the reference's Result: decode errors -> Error::BLST, else InvalidSignature."""
+    if code == 0:
+        return
+    if code == EMPTY_AGGREGATE:
+        raise EmptyAggregate()
+    if code in _DECODE_CODES:
+        raise BLSTError(code)
+    raise InvalidSignature()
+
+
+# ---- status-returning layer (what the C ABI returns; used by the parity tests) -------------------
+def verify_signature_status(public_key: bytes, msg: bytes, signature: bytes) -> int:
+    L = _lib.load()
+    return _lib.check(L.ecgpu_verify(_buf(_pk(public_key)), _buf(msg), len(msg), _buf(_sig(signature))), "ecgpu_verify")
+
+
+def fast_aggregate_verify_status(public_keys: Sequence[bytes], msg: bytes, signature: bytes, eth: bool = False) -> int:
+    L = _lib.load()
+    pks = b"".join(_pk(p) for p in public_keys)
+    return _lib.check(L.ecgpu_fast_aggregate_verify(_buf(pks), len(public_keys), _buf(msg), len(msg), _buf(_sig(signature)),
+                                                    1 if eth else 0), "ecgpu_fast_aggregate_verify")
+
+
+def aggregate_verify_status(public_keys: Sequence[bytes], msgs: Sequence[bytes], signature: bytes) -> int:
+    L = _lib.load()
+    pks = b"".join(_pk(p) for p in public_keys)
+    off = [0]
+    for m in msgs:
+        off.append(off[-1] + len(m))
+    off_arr = (ctypes.c_uint64 * len(off))(*off)
+    return _lib.check(L.ecgpu_aggregate_verify(_buf(pks), len(public_keys), _buf(b"".join(msgs)), off_arr, len(msgs),
+                                               _buf(_sig(signature))), "ecgpu_aggregate_verify")
+
+
+def aggregate_status(signatures: Sequence[bytes]):
+    L = _lib.load()
+    out = ctypes.create_string_buffer(96)
+    rc = L.ecgpu_aggregate_sigs(_buf(b"".join(_sig(s) for s in signatures)), len(signatures), out)
+    _lib.check(rc, "ecgpu_aggregate_sigs")
+    return rc, (out.raw if rc == 0 else None)
+
+
+def eth_aggregate_public_keys_status(public_keys: Sequence[bytes]):
+    L = _lib.load()
+    out = ctypes.create_string_buffer(48)
+    rc = L.ecgpu_aggregate_pks(_buf(b"".join(_pk(p) for p in public_keys)), len(public_keys), out)
+    _lib.check(rc, "ecgpu_aggregate_pks")
+    return rc, (out.raw if rc == 0 else None)
+
+
+# ---- the reference's API ----------------------------------------------------------------------------
+def verify_signature(public_key: bytes, msg: bytes, signature: bytes) -> None:
+    """bls.rs:64-77: Ok(()) or Err."""
+    _raise_for(verify_signature_status(public_key, msg, signature))
+
+
+def aggregate(signatures: Sequence[bytes]) -> bytes:
+    """bls.rs:79-93."""
+    rc, out = aggregate_status(signatures)
+    _raise_for(rc)
+    return out
+
+
+def aggregate_verify(public_keys: Sequence[bytes], msgs: Sequence[bytes], signature: bytes) -> None:
+    """bls.rs:95-112."""
+    _raise_for(aggregate_verify_status(public_keys, msgs, signature))
+
+
+def fast_aggregate_verify(public_keys: Sequence[bytes], msg: bytes, signature: bytes) -> None:
+    """bls.rs:114-132."""
+    _raise_for(fast_aggregate_verify_status(public_keys, msg, signature))
+
+
+def eth_aggregate_public_keys(public_keys: Sequence[bytes]) -> bytes:
+    """bls.rs:135-148."""
+    rc, out = eth_aggregate_public_keys_status(public_keys)
+    _raise_for(rc)
+    return out
+
+
+def eth_fast_aggregate_verify(public_keys: Sequence[bytes], msg: bytes, signature: bytes) -> None:
+    """bls.rs:150-160."""
+    _raise_for(fast_aggregate_verify_status(public_keys, msg, signature, eth=True))
+
+
+# ---- batch extension + SecretKey side ------------------------------------------------------------------
+def fast_aggregate_verify_batch(public_keys: bytes, pk_offsets, msgs32: bytes, signatures: bytes, eth: bool = False) -> bytes:
+    """n independent fast_aggregate_verify over 32-byte messages.  `public_keys` = concatenated 48-byte
+    keys; tuple i uses keys pk_offsets[i]..pk_offsets[i+1] (None: one key per tuple).  Returns n status
+    bytes (BLST_ERROR numbering), each what the scalar call would have produced."""
+    L = _lib.load()
+    n = len(signatures) // 96
+    if len(signatures) != 96 * n or len(msgs32) != 32 * n or len(public_keys) % 48:
+        raise InvalidLength("batch buffers must hold 96-byte signatures, 32-byte messages, 48-byte keys")
+    off = None
+    if pk_offsets is not None:
+        if len(pk_offsets) != n + 1 or pk_offsets[-1] * 48 != len(public_keys):
+            raise InvalidLength("pk_offsets must have n+1 entries ending at the key count")
+        off = (ctypes.c_uint32 * (n + 1))(*pk_offsets)
+    elif len(public_keys) != 48 * n:
+        raise InvalidLength("one key per tuple expected")
+    out = ctypes.create_string_buffer(max(n, 1))
+    _lib.check(L.ecgpu_fast_aggregate_verify_batch(_buf(public_keys), off, _buf(msgs32), _buf(signatures), n, 1 if eth else 0,
+                                                   out), "ecgpu_fast_aggregate_verify_batch")
+    return out.raw[:n]
+
+
+def sk_to_pk_batch(secret_keys32: bytes) -> bytes:
+    """SecretKey::public_key (bls.rs:193-197) for n 32-byte big-endian secret keys."""
+    L = _lib.load()
+    n = len(secret_keys32) // 32
+    out = ctypes.create_string_buffer(max(48 * n, 1))
+    _lib.check(L.ecgpu_sk_to_pk_batch(_buf(secret_keys32), n, out), "ecgpu_sk_to_pk_batch")
+    return out.raw[:48 * n]
+
+
+def sign_batch(secret_keys32: bytes, msgs: Sequence[bytes]) -> bytes:
+    """SecretKey::sign (bls.rs:213-219): sig_i = [sk_i] hash_to_G2(msg_i)."""
+    L = _lib.load()
+    n = len(secret_keys32) // 32
+    assert n == len(msgs)
+    off = [0]
+    for m in msgs:
+        off.append(off[-1] + len(m))
+    off_arr = (ctypes.c_uint64 * len(off))(*off)
+    out = ctypes.create_string_buffer(max(96 * n, 1))
+    _lib.check(L.ecgpu_sign_batch(_buf(secret_keys32), _buf(b"".join(msgs)), off_arr, n, out), "ecgpu_sign_batch")
+    return out.raw[:96 * n]

@@ -123,6 +123,17 @@ int ecgpu_fast_aggregate_verify_batch_dev(const uint8_t* d_pks48, const uint32_t
                                           const uint8_t* d_sigs96, uint32_t n, int eth_variant,
                                           uint8_t* d_status_out, ecgpu_stream_t stream);
 
+/* SecretKey side, used to generate workloads and test vectors on the device:
+ * SecretKey::public_key (crypto/bls.rs:193-197) and SecretKey::sign (:213-219).  sk = 32 big-endian
+ * bytes, taken as given (pass sk < r).  msg_off == NULL: 32-byte messages at msgs + 32 i.
+ * sk_stride (dev variant) = byte distance between consecutive secret keys (0: one key signs all). */
+int ecgpu_sk_to_pk_batch(const uint8_t* sks32, uint32_t n, uint8_t* pks48);
+int ecgpu_sign_batch(const uint8_t* sks32, const uint8_t* msgs, const uint64_t* msg_off, uint32_t n,
+                     uint8_t* sigs96);
+int ecgpu_sk_to_pk_batch_dev(const uint8_t* d_sks32, uint32_t n, uint8_t* d_pks48, ecgpu_stream_t stream);
+int ecgpu_sign_batch_dev(const uint8_t* d_sks32, uint32_t sk_stride, const uint8_t* d_msgs32, uint32_t n,
+                         uint8_t* d_sigs96, ecgpu_stream_t stream);
+
 /* ---- measurement helpers (bench.py) --------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel of the last *_dev call on this thread:
  * returns the number of launches recorded and writes their total duration. */

@@ -1,0 +1,275 @@
+"""CPU checks of the BLS12-381 lane programs (the ECG_HD code the gfx950 kernels run, compiled by g++
+into tests/hostsim) against oracle/bls12_381.py: field tower, curve ops, encodings, subgroup
+checks, hash-to-G2, pairing, and the status algebra of the reference wrappers."""
+import ctypes
+import random
+
+import pytest
+
+from oracle import bls12_381 as B
+from tests import _blscases as C
+from tests._hostsim import lib
+
+P = B.P
+
+
+def b48(x):
+    return x.to_bytes(48, "big")
+
+
+def a1(pt):
+    return b48(pt[0]) + b48(pt[1]) if pt else bytes(96)
+
+
+def a2(pt):
+    return (b48(pt[0][0]) + b48(pt[0][1]) + b48(pt[1][0]) + b48(pt[1][1])) if pt else bytes(192)
+
+
+def un1(b):
+    return (int.from_bytes(b[:48], "big"), int.from_bytes(b[48:96], "big"))
+
+
+def un2(b):
+    return ((int.from_bytes(b[:48], "big"), int.from_bytes(b[48:96], "big")),
+            (int.from_bytes(b[96:144], "big"), int.from_bytes(b[144:192], "big")))
+
+
+def fp_op(op, a, b=None):
+    out = ctypes.create_string_buffer(48)
+    rc = lib().hs_fp_op(op, b48(a), b48(b) if b is not None else None, out)
+    return rc, int.from_bytes(out.raw, "big")
+
+
+def fp2_op(op, a, b=None):
+    out = ctypes.create_string_buffer(96)
+    rc = lib().hs_fp2_op(op, b48(a[0]) + b48(a[1]), (b48(b[0]) + b48(b[1])) if b is not None else None, out)
+    return rc, (int.from_bytes(out.raw[:48], "big"), int.from_bytes(out.raw[48:], "big"))
+
+
+def test_fp_arithmetic_and_lazy_range():
+    r = random.Random(1)
+    edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 380]
+    vals = edge + [r.randrange(P) for _ in range(200)]
+    for _ in range(600):
+        a, b = r.choice(vals), r.choice(vals)
+        assert fp_op(0, a, b)[1] == a * b % P
+        assert fp_op(1, a, b)[1] == (a + b) % P
+        assert fp_op(2, a, b)[1] == (a - b) % P
+        assert fp_op(3, a)[1] == (-a) % P
+        assert fp_op(6, a)[1] == a * a % P
+        assert fp_op(8, a)[1] == 2 * a % P
+        assert fp_op(7, a)[0] == int(a > (P - 1) // 2)
+        assert fp_op(9, a)[0] == int(a == 0)
+        assert fp_op(10, a, b)[0] == int(a == b)
+    for a in vals[:40]:
+        assert fp_op(4, a)[1] == pow(a, P - 2, P)
+        rc, v = fp_op(5, a)
+        sq = a == 0 or pow(a, (P - 1) // 2, P) == 1
+        assert rc == int(sq)
+        if sq:
+            assert v * v % P == a
+    out = ctypes.create_string_buffer(48)
+    for _ in range(20):  # long chains keep values in the lazy [0, 2p) representation
+        a, b = r.randrange(P), r.randrange(P)
+        lib().hs_fp_chain(b48(a), b48(b), 200, out)
+        x = a
+        for _i in range(200):
+            x = (x * b + a - b) % P
+        assert int.from_bytes(out.raw, "big") == x
+
+
+def test_fp2_arithmetic():
+    r = random.Random(2)
+    v2 = [(0, 0), (1, 0), (0, 1), (P - 1, 0), (0, P - 1), (5, 0), (0, 7)] + [(r.randrange(P), r.randrange(P)) for _ in range(60)]
+    for _ in range(200):
+        a, b = r.choice(v2), r.choice(v2)
+        assert fp2_op(0, a, b)[1] == B.f2_mul(a, b)
+        assert fp2_op(1, a)[1] == B.f2_sqr(a)
+        assert fp2_op(4, a)[0] == B.f2_sgn0(a)
+        assert fp2_op(5, a)[0] == int(B.f2_lex_largest(a))
+        assert fp2_op(6, a)[1] == B.f2_mul_xi(a)
+        assert fp2_op(7, a, b)[1] == B.f2_add(a, b)
+        assert fp2_op(8, a, b)[1] == B.f2_sub(a, b)
+        assert fp2_op(9, a)[1] == B.f2_neg(a)
+        assert fp2_op(10, a)[1] == B.f2_conj(a)
+    for a in v2[:30]:
+        if a != (0, 0):
+            assert fp2_op(2, a)[1] == B.f2_inv(a)
+        rc, s = fp2_op(3, a)
+        assert rc == int(B.f2_sqrt(a) is not None)
+        if rc:
+            assert B.f2_sqr(s) == a
+        sq = B.f2_sqr(a)
+        rc, s = fp2_op(3, sq)
+        assert rc == 1 and B.f2_sqr(s) == sq
+
+
+def test_g1_decode_validate_compress():
+    r = random.Random(5)
+    L = lib()
+    cases = [B.sk_to_pk(r.randrange(1, B.R)) for _ in range(8)]
+    cases += [B.g1_compress(C.rand_g1_curve_point(r)) for _ in range(8)]
+    cases += C.malformed_g1(r)
+    for c in cases:
+        xy = ctypes.create_string_buffer(96)
+        inf = ctypes.c_int(0)
+        st = L.hs_g1_decompress(c, xy, ctypes.byref(inf))
+        wst, wpt = B.g1_decompress(c)
+        assert st == wst, c.hex()
+        if st == 0:
+            assert bool(inf.value) == (wpt is None)
+            if wpt:
+                assert un1(xy.raw) == wpt
+        st = L.hs_g1_key_validate(c, xy)
+        wst, wpt = B.key_validate(c)
+        assert st == wst, c.hex()
+        if wpt:
+            out = ctypes.create_string_buffer(48)
+            L.hs_g1_compress(a1(wpt), 0, out)
+            assert out.raw == c
+    out = ctypes.create_string_buffer(48)
+    L.hs_g1_compress(bytes(96), 1, out)
+    assert out.raw == B.INFINITY_PUBLIC_KEY
+
+
+def test_g1_group_law_special_cases():
+    r = random.Random(6)
+    L = lib()
+    g = B.G1
+    pts = [B.g1_mul(g, r.randrange(1, B.R)) for _ in range(6)]
+    lists = [pts, [pts[0], pts[0]], [pts[0], B.g1_neg(pts[0])], [pts[0]] * 3, [None, pts[1]], [pts[1], None], [pts[2]],
+             [pts[0], B.g1_neg(pts[0]), pts[3]], [pts[0], pts[1], B.g1_neg(B.g1_add(pts[0], pts[1]))]]
+    for lst in lists:
+        buf = b"".join(a1(p) for p in lst)
+        infs = (ctypes.c_int * len(lst))(*[0 if p else 1 for p in lst])
+        xy = ctypes.create_string_buffer(96)
+        inf = ctypes.c_int(0)
+        L.hs_g1_sum(buf, infs, len(lst), xy, ctypes.byref(inf))
+        want = None
+        for p in lst:
+            want = B.g1_add(want, p)
+        assert bool(inf.value) == (want is None)
+        if want:
+            assert un1(xy.raw) == want
+    k = r.randrange(B.R)
+    xy = ctypes.create_string_buffer(96)
+    inf = ctypes.c_int(0)
+    L.hs_g1_mul(a1(g), k.to_bytes(32, "big"), xy, ctypes.byref(inf))
+    assert un1(xy.raw) == B.g1_mul(g, k)
+    # EIP-2335 keystore KAT (bin/ec/validator/keystores.rs:240-249) through the lane programs
+    L.hs_g1_mul(a1(g), C.EIP2335_SK.to_bytes(32, "big"), xy, ctypes.byref(inf))
+    out = ctypes.create_string_buffer(48)
+    L.hs_g1_compress(xy.raw, 0, out)
+    assert out.raw == C.EIP2335_PK
+    for p in [C.rand_g1_curve_point(r) for _ in range(6)] + pts:
+        assert L.hs_g1_in_subgroup(a1(p)) == int(B.g1_in_subgroup(p))
+
+
+def test_g2_decode_subgroup_compress_and_group_law():
+    r = random.Random(7)
+    L = lib()
+    sigpts = [B.g2_mul(B.G2, r.randrange(1, B.R)) for _ in range(5)]
+    off = [C.rand_g2_curve_point(r) for _ in range(5)]
+    cases = [B.g2_compress(p) for p in sigpts + off] + C.malformed_g2(r)
+    for c in cases:
+        xy = ctypes.create_string_buffer(192)
+        inf = ctypes.c_int(0)
+        st = L.hs_g2_decompress(c, xy, ctypes.byref(inf))
+        wst, wpt = B.g2_decompress(c)
+        assert st == wst, c.hex()
+        if st == 0:
+            assert bool(inf.value) == (wpt is None)
+            if wpt:
+                assert un2(xy.raw) == wpt
+                assert L.hs_g2_in_subgroup(a2(wpt)) == int(B.g2_in_subgroup(wpt))
+                out = ctypes.create_string_buffer(96)
+                L.hs_g2_compress(a2(wpt), 0, out)
+                assert out.raw == c
+    lists = [sigpts, [sigpts[0], sigpts[0]], [sigpts[0], B.g2_neg(sigpts[0])], [None, sigpts[1]],
+             [sigpts[1], None, sigpts[1]], off[:3]]
+    for lst in lists:
+        buf = b"".join(a2(p) for p in lst)
+        infs = (ctypes.c_int * len(lst))(*[0 if p else 1 for p in lst])
+        xy = ctypes.create_string_buffer(192)
+        inf = ctypes.c_int(0)
+        L.hs_g2_sum(buf, infs, len(lst), xy, ctypes.byref(inf))
+        want = None
+        for p in lst:
+            want = B.g2_add(want, p)
+        assert bool(inf.value) == (want is None)
+        if want:
+            assert un2(xy.raw) == want
+
+
+def test_expand_message_and_hash_to_g2():
+    r = random.Random(8)
+    L = lib()
+    for msg in [b"", b"abc", C.CAN_SIGN_MSG, bytes(32), r.randbytes(32), r.randbytes(100), r.randbytes(55),
+                r.randbytes(56), r.randbytes(64)]:
+        out = ctypes.create_string_buffer(256)
+        L.hs_xmd(msg, len(msg), out)
+        assert out.raw == B.expand_message_xmd(msg, B.DST, 256)
+        xy = ctypes.create_string_buffer(192)
+        inf = ctypes.c_int(0)
+        L.hs_hash_to_g2(msg, len(msg), xy, ctypes.byref(inf))
+        assert un2(xy.raw) == B.hash_to_g2(msg)
+    # crypto/bls.rs:530-544 test_can_sign through the lane programs: [sk] H(msg) compressed
+    xy = ctypes.create_string_buffer(192)
+    inf = ctypes.c_int(0)
+    L.hs_hash_to_g2(C.CAN_SIGN_MSG, len(C.CAN_SIGN_MSG), xy, ctypes.byref(inf))
+    out = ctypes.create_string_buffer(192)
+    L.hs_g2_mul(xy.raw, C.CAN_SIGN_SK.to_bytes(32, "big"), out, ctypes.byref(inf))
+    sig = ctypes.create_string_buffer(96)
+    L.hs_g2_compress(out.raw, 0, sig)
+    assert sig.raw == C.CAN_SIGN_SIG
+
+
+def f12_flat(a):
+    return b"".join(b48(c) for f6 in a for f2 in f6 for c in f2)
+
+
+def f12_un(b):
+    v = [int.from_bytes(b[48 * i:48 * i + 48], "big") for i in range(12)]
+    return (((v[0], v[1]), (v[2], v[3]), (v[4], v[5])), ((v[6], v[7]), (v[8], v[9]), (v[10], v[11])))
+
+
+def op12(op, a, b=None):
+    out = ctypes.create_string_buffer(576)
+    lib().hs_fp12_op(op, f12_flat(a), f12_flat(b) if b else None, out)
+    return f12_un(out.raw)
+
+
+def test_fp12_tower_and_pairing():
+    r = random.Random(11)
+    L = lib()
+
+    def rnd12():
+        return tuple(tuple((r.randrange(P), r.randrange(P)) for _ in range(3)) for _ in range(2))
+
+    a, b = rnd12(), rnd12()
+    assert op12(0, a, b) == B.f12_mul(a, b)
+    assert op12(1, a) == B.f12_sqr(a)
+    assert op12(2, a) == B.f12_inv(a)
+    assert op12(3, a) == B.f12_frob(a)
+    assert op12(4, a) == B.f12_conj(a)
+    fe = B.final_exponentiation(a)
+    assert op12(6, a) == fe
+    assert op12(5, fe) == B.f12_sqr(fe)  # Granger-Scott squaring on a cyclotomic element
+    assert op12(7, fe) == B._cyc_pow_x(fe)
+    Pt, Q = B.g1_mul(B.G1, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R))
+    out = ctypes.create_string_buffer(576)
+    L.hs_pairing(1, a1(Pt), (ctypes.c_int * 1)(0), a2(Q), (ctypes.c_int * 1)(0), out)
+    assert f12_un(out.raw) == B.pairing(Pt, Q)
+    P2, Q2 = B.g1_mul(B.G1, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R))
+    L.hs_pairing(2, a1(Pt) + a1(P2), (ctypes.c_int * 2)(0, 0), a2(Q) + a2(Q2), (ctypes.c_int * 2)(0, 0), out)
+    assert f12_un(out.raw) == B.final_exponentiation(B.f12_mul(B.miller_loop(Pt, Q), B.miller_loop(P2, Q2)))
+    # a pair with a point at infinity contributes 1
+    L.hs_pairing(2, a1(Pt) + a1(None), (ctypes.c_int * 2)(0, 1), a2(Q) + a2(Q2), (ctypes.c_int * 2)(0, 0), out)
+    assert f12_un(out.raw) == B.pairing(Pt, Q)
+
+
+def test_fast_aggregate_verify_status_algebra():
+    L = lib()
+    for pks, msg, sig, eth in C.fav_cases():
+        got = L.hs_fast_aggregate_verify(b"".join(pks), len(pks), msg, len(msg), sig, eth)
+        assert got == C.oracle_fav(pks, msg, sig, eth), (len(pks), eth)
