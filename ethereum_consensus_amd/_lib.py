@@ -5,7 +5,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libecgpu.so")
+# ECGPU_LIB: development override (kernel-variant experiments); the product path is the in-tree build
+LIB_PATH = os.environ.get("ECGPU_LIB") or os.path.join(_HERE, "lib", "libecgpu.so")
 
 u8p = ctypes.c_void_p
 _lib = None

@@ -16,6 +16,16 @@ namespace ecg {
 constexpr u32 FP_MASK = 0x3fffffffu;
 constexpr int FP_N = 13;
 
+// op census for the roofline arithmetic in DESIGN.md / bench.py: host lane simulator only
+#if !defined(__HIPCC__) && defined(ECG_COUNT_OPS)
+extern unsigned long long g_ecg_fp_mul_count, g_ecg_fp_sqr_count;
+#define ECG_COUNT_MUL() (++g_ecg_fp_mul_count)
+#define ECG_COUNT_SQR() (++g_ecg_fp_sqr_count)
+#else
+#define ECG_COUNT_MUL() ((void)0)
+#define ECG_COUNT_SQR() ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Fp
 // ---------------------------------------------------------------------------------------------
@@ -100,6 +110,7 @@ ECG_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 
 // Montgomery product a*b/R mod p (result < 2p for a, b < 2p; raw inputs up to 2^384 are fine too).
 ECG_HD_NOINLINE Fp fp_mul(Fp a, Fp b) {
+    ECG_COUNT_MUL();
     u64 T[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) T[i] = 0;
@@ -134,6 +145,7 @@ ECG_HD_NOINLINE Fp fp_mul(Fp a, Fp b) {
 // Montgomery square: 91 a_i*a_j products (off-diagonal ones doubled) + one carry pass, then the
 // 13 reduction rows: 260 multiplies instead of 351.
 ECG_HD_NOINLINE Fp fp_sqr(Fp a) {
+    ECG_COUNT_SQR();
     u64 T[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) T[i] = 0;

@@ -3,10 +3,15 @@
 // big-endian canonical integers so that the tests can compare with oracle/bls12_381.py directly.
 #include <cstring>
 
+#define ECG_COUNT_OPS 1
 #include "ecgpu.h"
 #include "bls_verify.h"
 
 using namespace ecg;
+
+namespace ecg {
+unsigned long long g_ecg_fp_mul_count = 0, g_ecg_fp_sqr_count = 0;
+}
 
 static Fp in_fp(const u8* b) { return fp_from_raw(raw_from_be48(b, false)); }
 static void out_fp(const Fp& a, u8* b) { raw_to_be48(fp_to_raw(a), b); }
@@ -215,6 +220,35 @@ void hs_pairing(int n, const u8* p_xy, const int* p_inf, const u8* q_xy, const i
     miller_loop(f, pr, n);
     final_exponentiation(e, f);
     out_fp12(e, out);
+}
+
+// Fp product census of the stages of one K = 1 verification (valid inputs): out[2*s] = fp_mul calls,
+// out[2*s+1] = fp_sqr calls for s = pk_validate, sig (decode + group check), hash_to_g2, pairing.
+void hs_op_census(const u8* pk48, const u8* msg, u64 msg_len, const u8* sig96, u64* out) {
+    auto snap = [&](int s) {
+        out[2 * s] = g_ecg_fp_mul_count;
+        out[2 * s + 1] = g_ecg_fp_sqr_count;
+        g_ecg_fp_mul_count = g_ecg_fp_sqr_count = 0;
+    };
+    g_ecg_fp_mul_count = g_ecg_fp_sqr_count = 0;
+    A1 p;
+    stage_pk_validate(p, pk48);
+    snap(0);
+    A2 sg;
+    u8 sd, sgr;
+    stage_sig(sg, sd, sgr, sig96);
+    snap(1);
+    A2 h;
+    hash_to_g2(h, msg, (size_t)msg_len);
+    snap(2);
+    stage_pairing(p, h, sg);
+    snap(3);
+}
+
+void hs_census_reset() { g_ecg_fp_mul_count = g_ecg_fp_sqr_count = 0; }
+void hs_census_read(u64* out) {
+    out[0] = g_ecg_fp_mul_count;
+    out[1] = g_ecg_fp_sqr_count;
 }
 
 int hs_fast_aggregate_verify(const u8* pks48, u32 k, const u8* msg, u64 msg_len, const u8* sig96, int eth) {

@@ -54,5 +54,5 @@ def run(n):
         L.ecgpu_prof_enable(0)
 
 
-for n in (1024, 16384, 65536):
+for n in [int(a) for a in sys.argv[1:]] or (1024, 16384, 65536):
     run(n)
