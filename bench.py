@@ -183,7 +183,7 @@ def run_bls(args, L, torch, dist, rank, world):
         msgs[32 * i] ^= 1
     d_msg = torch.frombuffer(msgs, dtype=torch.uint8).to(dev)
     d_st = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)
-    gathered = torch.empty(n * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    from ethereum_consensus_amd import shard
     torch.cuda.synchronize()
 
     def step():
@@ -193,7 +193,7 @@ def run_bls(args, L, torch, dist, rank, world):
             raise RuntimeError(f"ecgpu_fast_aggregate_verify_batch_dev -> {rc}: {L.ecgpu_last_error()}")
         if world > 1:
             # the path's only collective: every rank learns every shard's verify statuses
-            dist.all_gather_into_tensor(gathered, d_st)
+            shard.all_gather_bytes(dist, d_st, world)
 
     for _ in range(max(args.warmup, 1)):
         step()
