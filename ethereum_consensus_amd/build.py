@@ -21,6 +21,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libecgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
+VM_GEN_ARGS = ["--lanes", "16", "--window", "400"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -49,8 +50,26 @@ def _run(cmd):
         sys.stderr.write(r.stderr)
 
 
+def generate_vm_programs(verbose: bool = True) -> str:
+    """csrc/bls_vm_prog.h (2 MB of generated tables) is produced by tools/gen_bls_vm.py, not committed."""
+    gen = os.path.join(ROOT, "tools", "gen_bls_vm.py")
+    out = os.path.join(CSRC, "bls_vm_prog.h")
+    if _newer(out, [gen]):
+        if verbose:
+            print("[ecgpu build] generating csrc/bls_vm_prog.h", flush=True)
+        r = subprocess.run([sys.executable, gen] + VM_GEN_ARGS, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise RuntimeError("tools/gen_bls_vm.py failed")
+        with open(out + ".tmp", "w") as f:
+            f.write(r.stdout)
+        os.replace(out + ".tmp", out)
+    return out
+
+
 def build_lib(verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
+    generate_vm_programs(verbose)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = _headers()
     jobs = []
@@ -76,6 +95,7 @@ def build_lib(verbose: bool = True) -> str:
 def build_hostsim(verbose: bool = True) -> str:
     """g++ build of the same csrc headers: CPU-side kernel simulator for tests ONLY."""
     d = os.path.join(ROOT, "tests", "hostsim")
+    generate_vm_programs(verbose)
     srcs = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".cpp"))
     out = os.path.join(d, "libhostsim.so")
     os.makedirs(os.path.join(d, "obj"), exist_ok=True)

@@ -16,15 +16,20 @@
 // exchange are noise next to the ALU time -- the path is integer-VALU bound, not HBM bound
 // (DESIGN.md has the numbers).  No CPU fallback: without a gfx950 device every entry point fails.
 #include "bls_verify.h"
+#include "bls_vm_host.h"
 #include "runtime.h"
+
+#include <cstdlib>
 
 namespace ecg {
 
-int init_bls_tables(hipStream_t) { return ECGPU_SUCCESS; }  // constants are compile-time tables
+int init_vm_tables();  // bls_vm.hip
+int init_bls_tables(hipStream_t) { return init_vm_tables(); }
 
 constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches over every CU
 #ifndef ECG_BLS_WAVES
-#define ECG_BLS_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
+#define ECG_BLS_WAVES 2  // waves per SIMD the register allocator must leave room for (256 VGPRs): measured 12-25 % faster than 4
+                         // (profiles/r01b_bls_occupancy_probe.txt) -- these lane kernels are bound by private-segment traffic
 #endif
 
 // ---- stage kernels ---------------------------------------------------------------------------
@@ -112,9 +117,10 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_h2c(const u8* msgs
 // k_of: number of keys of tuple i = pk_off ? pk_off[i+1]-pk_off[i] : 1.
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts,
                                                         const A2* sigpts, const u8* st_dec, const u8* st_grp, const u8* sigs96,
-                                                        u32 n, int eth_variant, u8* status_out) {
+                                                        u32 n, int eth_variant, u8* status_out, int only_marked) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (only_marked && status_out[i] != VM_NEEDS_LANE_PATH) return;
     const u32 k = pk_off ? pk_off[i + 1] - pk_off[i] : 1;
     const bool sig_inf_bytes = sig_is_infinity_bytes(sigs96 + 96 * (size_t)i);
     const bool agg_inf = agg[i].inf != 0;
@@ -254,8 +260,13 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sign(const u8* sks
 static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
-    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + 4096;
+    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + vm_xfer_bytes(n) + 8192;
 }
+// development switch (ECGPU_LANE_PAIRING=1): the round-1a one-lane-per-tuple pairing kernel for every tuple
+static const bool g_use_lane_pairing = [] {
+    const char* e = getenv("ECGPU_LANE_PAIRING");
+    return e && e[0] == '1';
+}();
 
 // all pointers device-resident; ws from the caller's arena
 static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_off, u32 n_pks, const u8* d_msgs, const u64* d_msg_off,
@@ -293,8 +304,19 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     }
     {
         ProfScope ps("bls_pairing", s);
-        hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
-                           (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status);
+        if (g_use_lane_pairing) {
+            hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
+                               (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, 0);
+        } else {
+            u32* xfer = (u32*)ar.take(vm_xfer_bytes(n));
+            if (!xfer) return ECGPU_ERR_OOM;
+            int rc = vm_pairing_launch(s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec,
+                                       (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
+            if (rc) return rc;
+            // tuples with a point at infinity in the pairing (signature 0xc0.., H(m) = inf): rare, branchy lane kernel
+            hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
+                               (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, 1);
+        }
     }
     ECG_HIP_CHECK(hipGetLastError());
     return ECGPU_SUCCESS;
