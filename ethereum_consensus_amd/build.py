@@ -22,6 +22,7 @@ LIB = os.path.join(LIBDIR, "libecgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 VM_GEN_ARGS = ["--lanes", "16", "--window", "400"]
+VM2_GEN_ARGS = os.environ.get("ECGPU_VM2_GEN_ARGS", "--lanes 16 --window 200").split()
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -51,19 +52,26 @@ def _run(cmd):
 
 
 def generate_vm_programs(verbose: bool = True) -> str:
-    """csrc/bls_vm_prog.h (2 MB of generated tables) is produced by tools/gen_bls_vm.py, not committed."""
-    gen = os.path.join(ROOT, "tools", "gen_bls_vm.py")
-    out = os.path.join(CSRC, "bls_vm_prog.h")
-    if _newer(out, [gen]):
-        if verbose:
-            print("[ecgpu build] generating csrc/bls_vm_prog.h", flush=True)
-        r = subprocess.run([sys.executable, gen] + VM_GEN_ARGS, capture_output=True, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(r.stderr)
-            raise RuntimeError("tools/gen_bls_vm.py failed")
-        with open(out + ".tmp", "w") as f:
-            f.write(r.stdout)
-        os.replace(out + ".tmp", out)
+    """csrc/bls_vm_prog.h / bls_vm2_prog.h (generated tables) are produced by tools/gen_bls_vm*.py, not committed."""
+    out = None
+    for script, header, gen_args in (("gen_bls_vm.py", "bls_vm_prog.h", VM_GEN_ARGS), ("gen_bls_vm2.py", "bls_vm2_prog.h", VM2_GEN_ARGS)):
+        gen = os.path.join(ROOT, "tools", script)
+        out = os.path.join(CSRC, header)
+        stamp = out + ".args"
+        want = " ".join(gen_args)
+        have = open(stamp).read() if os.path.exists(stamp) else None
+        if _newer(out, [gen]) or have != want:
+            if verbose:
+                print("[ecgpu build] generating csrc/" + header, flush=True)
+            r = subprocess.run([sys.executable, gen] + gen_args, capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stderr)
+                raise RuntimeError("tools/" + script + " failed")
+            with open(out + ".tmp", "w") as f:
+                f.write(r.stdout)
+            os.replace(out + ".tmp", out)
+            with open(stamp, "w") as f:
+                f.write(want)
     return out
 
 

@@ -20,11 +20,15 @@
 #include "runtime.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace ecg {
 
 int init_vm_tables();  // bls_vm.hip
-int init_bls_tables(hipStream_t) { return init_vm_tables(); }
+int init_bls_tables(hipStream_t) {
+    int rc = init_vm_tables();
+    return rc ? rc : init_vm2_tables();
+}
 
 constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches over every CU
 #ifndef ECG_BLS_WAVES
@@ -260,12 +264,14 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sign(const u8* sks
 static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
-    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + vm_xfer_bytes(n) + 8192;
+    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + vm_xfer_bytes(n) + vm2_xfer_bytes(n) + 8192;
 }
-// development switch (ECGPU_LANE_PAIRING=1): the round-1a one-lane-per-tuple pairing kernel for every tuple
-static const bool g_use_lane_pairing = [] {
-    const char* e = getenv("ECGPU_LANE_PAIRING");
-    return e && e[0] == '1';
+// development switch ECGPU_PAIRING = lane | vm | vm2 (default): which pairing-check kernels run
+static const int g_pairing_mode = [] {
+    const char* e = getenv("ECGPU_PAIRING");
+    if (e && !strcmp(e, "lane")) return 0;
+    if (e && !strcmp(e, "vm")) return 1;
+    return 2;
 }();
 
 // all pointers device-resident; ws from the caller's arena
@@ -304,14 +310,15 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     }
     {
         ProfScope ps("bls_pairing", s);
-        if (g_use_lane_pairing) {
+        if (g_pairing_mode == 0) {
             hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
                                (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, 0);
         } else {
-            u32* xfer = (u32*)ar.take(vm_xfer_bytes(n));
+            u32* xfer = (u32*)ar.take(g_pairing_mode == 1 ? vm_xfer_bytes(n) : vm2_xfer_bytes(n));
             if (!xfer) return ECGPU_ERR_OOM;
-            int rc = vm_pairing_launch(s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec,
-                                       (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
+            int rc = (g_pairing_mode == 1 ? vm_pairing_launch : vm2_pairing_launch)(s, (const A1*)agg, (const u8*)st_pk, d_pk_off,
+                                                                                    (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec,
+                                                                                    (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
             if (rc) return rc;
             // tuples with a point at infinity in the pairing (signature 0xc0.., H(m) = inf): rare, branchy lane kernel
             hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,

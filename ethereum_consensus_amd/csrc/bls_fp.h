@@ -109,8 +109,7 @@ ECG_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 ECG_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 
 // Montgomery product a*b/R mod p (result < 2p for a, b < 2p; raw inputs up to 2^384 are fine too).
-ECG_HD_NOINLINE Fp fp_mul(Fp a, Fp b) {
-    ECG_COUNT_MUL();
+ECG_HD Fp fp_mul_body(const Fp& a, const Fp& b) {
     u64 T[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) T[i] = 0;
@@ -141,6 +140,43 @@ ECG_HD_NOINLINE Fp fp_mul(Fp a, Fp b) {
     r.l[12] = (u32)T[25];
     return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The out-of-line call takes its operands as two 13-element vectors: clang's AMDGPU ABI gives a
+// function 16 argument registers for aggregates, so the second `Fp` struct of fp_mul(Fp, Fp) travelled
+// through the stack (13 dwords of scratch store + load per product); vectors are passed in VGPRs.
+typedef u32 fp_vec13 __attribute__((ext_vector_type(13)));
+static __device__ __attribute__((noinline)) fp_vec13 fp_mul_call(fp_vec13 a, fp_vec13 b) {
+    Fp x, y;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        x.l[i] = a[i];
+        y.l[i] = b[i];
+    }
+    const Fp r = fp_mul_body(x, y);
+    fp_vec13 o;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) o[i] = r.l[i];
+    return o;
+}
+ECG_HD Fp fp_mul(const Fp& a, const Fp& b) {
+    fp_vec13 x, y;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        x[i] = a.l[i];
+        y[i] = b.l[i];
+    }
+    const fp_vec13 o = fp_mul_call(x, y);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = o[i];
+    return r;
+}
+#else
+ECG_HD_NOINLINE Fp fp_mul(Fp a, Fp b) {
+    ECG_COUNT_MUL();
+    return fp_mul_body(a, b);
+}
+#endif
 
 // Montgomery square: 91 a_i*a_j products (off-diagonal ones doubled) + one carry pass, then the
 // 13 reduction rows: 260 multiplies instead of 351.

@@ -15,4 +15,10 @@ size_t vm_xfer_bytes(u32 n);
 int vm_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts,
                       const u8* st_dec, const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer);
 
+// Fp2-granular successor (bls_vm2.hip): same contract, xfer = vm2_xfer_bytes(n)
+int init_vm2_tables();
+size_t vm2_xfer_bytes(u32 n);
+int vm2_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
+                       const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer);
+
 }  // namespace ecg

@@ -226,4 +226,21 @@ struct TreeJob {
 };
 constexpr u32 TREEJOB_MAX_NODES = 512;
 
+// A tile stage: workgroup `first_wg + t` reduces the 1024 level-`level0` nodes [1024 t, 1024 t + 1024) of one
+// field -- 4 per lane depth-first in registers (the field's leaf functor runs here), then up to 8 levels through
+// LDS -- and stores ONE node at level min(top, level0 + 10).  Several fields share one launch (k_tree_tiles),
+// so a narrow tree costs two dependent launches (tiles, finishing job) instead of one per level.
+struct TileDesc {
+    const u8* in;    // field bytes (leaf functor input) or level-`level0` nodes
+    u64 in_bytes;
+    u64 n0;          // number of level-`level0` nodes
+    u8* out;         // one 32-byte node per tile
+    u32 kind;        // LeafKind (not LEAF_VALIDATORS: that functor has a pass of its own)
+    u32 level0;      // absolute level of the inputs
+    u32 top;         // absolute level of the field's root (= depth)
+    u32 first_wg;    // first workgroup of this field in the launch
+};
+constexpr u32 TILE_LANES = 256, TILE_D = 2, TILE_NODES = TILE_LANES << TILE_D, TILE_LEVELS = TILE_D + 8;
+constexpr u64 TILE_MAX_IN = (u64)TREEJOB_MAX_NODES * TILE_NODES;
+
 }  // namespace ecg

@@ -98,6 +98,54 @@ __global__ void __launch_bounds__(JOB_BLOCK) k_tree_job1(TreeJob job, u8* buf, c
     run_tree_job(job, buf, zt);
 }
 
+// Tile stage (merkle.h TileDesc): blockIdx -> (field, tile) by a scan of the few descriptors; the leaf functor is
+// selected per workgroup (uniform branch).  Pairs of virtual nodes are ladder entries, not hashed.
+template <class Leaf>
+__device__ __forceinline__ Node tile_lane_node(const Leaf& leaf, u64 first, u64 n, const ZeroTable* zt, int level0) {
+    return Subtree<TILE_D, Leaf>::run(leaf, first, n, zt, level0);
+}
+__device__ __forceinline__ void run_tile(const TileDesc& d, const ZeroTable* zt) {
+    __shared__ Node nodes[TILE_LANES];
+    const u32 t = threadIdx.x;
+    const u64 tile = blockIdx.x - d.first_wg;
+    const u64 first = tile * TILE_NODES + ((u64)t << TILE_D);
+    const int l0 = (int)d.level0;
+    Node x;
+    switch (d.kind) {
+        case LEAF_NODES: x = tile_lane_node(NodeLeaves{d.in}, first, d.n0, zt, l0); break;
+        case LEAF_BYTES48: x = tile_lane_node(Bytes48Leaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
+        case LEAF_PAIR64: x = tile_lane_node(Pair64Leaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
+        case LEAF_ETH1DATA: x = tile_lane_node(Eth1DataLeaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
+        default: x = tile_lane_node(ChunkLeaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
+    }
+    nodes[t] = x;
+    __syncthreads();
+    u32 lvl = d.level0 + TILE_D, m = TILE_LANES;
+    while (lvl < d.top && m > 1) {
+        const u32 pairs = m >> 1;
+        Node h;
+        if (t < pairs) {
+            // left child = node 2t of this level: virtual iff its first level0 node is past the end
+            const u64 left_first = tile * TILE_NODES + ((u64)(2 * t) << (lvl - d.level0));
+            h = left_first >= d.n0 ? zt->z[lvl + 1] : hash64(nodes[2 * t], nodes[2 * t + 1]);
+        }
+        __syncthreads();
+        if (t < pairs) nodes[t] = h;
+        __syncthreads();
+        m = pairs;
+        lvl++;
+    }
+    if (t == 0) node_store(nodes[0], d.out + 32ull * tile);
+}
+__global__ void __launch_bounds__(TILE_LANES) k_tree_tiles(const TileDesc* descs, u32 n_desc, const ZeroTable* zt) {
+    u32 f = 0;
+    for (u32 i = 1; i < n_desc; i++)
+        if (blockIdx.x >= descs[i].first_wg) f = i;
+    const TileDesc d = descs[f];
+    run_tile(d, zt);
+}
+__global__ void __launch_bounds__(TILE_LANES) k_tree_tiles1(TileDesc d, const ZeroTable* zt) { run_tile(d, zt); }
+
 __global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u32 n, u8* dst) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -173,8 +221,25 @@ static int launch_pass(hipStream_t s, int D, const Leaf& leaf, u64 n_in, u64 n_o
     return ECGPU_SUCCESS;
 }
 
+// single-descriptor form of the tile stage: the descriptor travels as a kernel argument
+static int launch_tiles_inline(hipStream_t s, const TileDesc& td, u32 n_wg) {
+    if (n_wg == 0) return ECGPU_SUCCESS;
+    ProfScope ps("merkle_tree_tiles", s);
+    hipLaunchKernelGGL(k_tree_tiles1, dim3(n_wg), dim3(TILE_LANES), 0, s, td, device_zero_table());
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
+int launch_tiles(hipStream_t s, const TileDesc* d_descs, u32 n_desc, u32 n_wg) {
+    if (n_wg == 0 || n_desc == 0) return ECGPU_SUCCESS;
+    ProfScope ps("merkle_tree_tiles", s);
+    hipLaunchKernelGGL(k_tree_tiles, dim3(n_wg), dim3(TILE_LANES), 0, s, d_descs, n_desc, device_zero_table());
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
 int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes, u64 n0, u32 depth, bool mix,
-                     u64 mix_len, u8* d_out, u8* ws, u64* hash_count) {
+                     u64 mix_len, u8* d_out, u8* ws, u64* hash_count, TreeJob* deferred, const u8* job_base, bool background) {
     if (depth > 64) {
         set_last_error("limit too large");
         return ECGPU_ERR_BAD_ARG;
@@ -183,7 +248,7 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
         set_last_error("more level-0 nodes than the limit allows");
         return ECGPU_ERR_BAD_ARG;
     }
-    const MerkleSchedule sc = schedule_merkleize(kind, n0, depth, mix);
+    const MerkleSchedule sc = schedule_merkleize(kind, n0, depth, mix, background);
     const u64 half = ((n0 + 1) / 2 + 64) * 32;
     u8* bufA = ws;
     u8* bufB = ws + half;
@@ -205,6 +270,23 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
         if (rc) return rc;
         cur = out;
     }
+    if (sc.tile) {
+        // one workgroup per 1024 nodes; the descriptor rides in the unused tail of the workspace
+        u8* out = (cur == bufA) ? bufB : bufA;
+        TileDesc td;
+        td.in = sc.tile_first ? d_in : cur;
+        td.in_bytes = sc.tile_first ? in_bytes : 32ull * sc.tile_n_in;
+        td.n0 = sc.tile_n_in;
+        td.out = out;
+        td.kind = sc.tile_first ? (u32)kind : (u32)LEAF_NODES;
+        td.level0 = sc.tile_level_in;
+        td.top = depth;
+        td.first_wg = 0;
+        const u32 n_wg = (u32)((sc.tile_n_in + TILE_NODES - 1) / TILE_NODES);
+        int rc = launch_tiles_inline(s, td, n_wg);
+        if (rc) return rc;
+        cur = out;
+    }
     // finishing job: <= 512 nodes at job_level (or the empty tree) -> climb -> mix-in -> d_out
     TreeJob job;
     u8* jbase = const_cast<u8*>(cur);
@@ -215,7 +297,11 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
     job.depth = depth;
     job.mix = mix ? 1 : 0;
     job.mix_len = mix_len;
-    {
+    if (deferred) {
+        job.in_off = (u64)((uintptr_t)jbase - (uintptr_t)job_base);
+        job.out_off = (u64)((uintptr_t)d_out - (uintptr_t)job_base);
+        *deferred = job;
+    } else {
         ProfScope ps("merkle_tree_job", s);
         hipLaunchKernelGGL(k_tree_job1, dim3(1), dim3(JOB_BLOCK), 0, s, job, jbase, device_zero_table());
     }

@@ -43,8 +43,19 @@ struct PinnedBuf {
     int reserve(size_t bytes);
 };
 
+// Fork/join helper: a few auxiliary streams per host thread so that independent launch chains of one
+// call (the fields of a BeaconState) overlap on the device instead of queueing behind each other.
+constexpr int N_AUX_STREAMS = 3;
+struct AuxStreams {
+    hipStream_t st[N_AUX_STREAMS] = {};
+    hipEvent_t fork = nullptr, done[N_AUX_STREAMS] = {};
+    bool ready = false;
+    int init();
+};
+
 struct ThreadCtx {
     hipStream_t own_stream = nullptr;
+    AuxStreams aux;
     std::map<hipStream_t, Arena> arenas;
     PinnedBuf staging;      // host-pinned staging for small H2D/D2H payloads
     u64 last_hash64 = 0;

@@ -76,6 +76,17 @@ hipStream_t ThreadCtx::stream_or_own(ecgpu_stream_t s) {
     return own_stream;
 }
 
+int AuxStreams::init() {
+    if (ready) return ECGPU_SUCCESS;
+    ECG_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (int i = 0; i < N_AUX_STREAMS; i++) {
+        ECG_HIP_CHECK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+        ECG_HIP_CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    ready = true;
+    return ECGPU_SUCCESS;
+}
+
 int Arena::reserve(size_t bytes) {
     if (bytes <= cap) return ECGPU_SUCCESS;
     if (base) {

@@ -25,8 +25,8 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     size_t need = 4096;
     for (auto& b : plan.bigs) need += merkle_ws_bytes(b.n0) + 512;
     const size_t small_bytes = 32ull * plan.n_small_chunks;
-    const size_t n_jobs = plan.jobs[0].size() + plan.jobs[1].size() + plan.jobs[2].size();
-    need += small_bytes + n_jobs * sizeof(TreeJob) + plan.gathers.size() * sizeof(GatherDesc) + 2048;
+    const size_t n_jobs = plan.jobs[0].size() + plan.jobs[1].size() + plan.jobs[2].size() + plan.bigs.size();
+    need += small_bytes + n_jobs * sizeof(TreeJob) + plan.gathers.size() * sizeof(GatherDesc) + plan.bigs.size() * (sizeof(TileDesc) + 256) + 2048;
     int rc = ar.reserve(need);
     if (rc) return rc;
     u8* d_small = ar.take(small_bytes);
@@ -34,27 +34,103 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     GatherDesc* d_gath = (GatherDesc*)ar.take(plan.gathers.size() * sizeof(GatherDesc));
     // descriptors travel through pageable memory: hipMemcpyAsync stages them before returning,
     // so the host vectors may die at the end of this call while the stream is still running.
-    std::vector<TreeJob> all_jobs;
-    for (int l = 0; l < 3; l++) all_jobs.insert(all_jobs.end(), plan.jobs[l].begin(), plan.jobs[l].end());
-    ECG_HIP_CHECK(hipMemcpyAsync(d_jobs, all_jobs.data(), n_jobs * sizeof(TreeJob), hipMemcpyHostToDevice, s));
     ECG_HIP_CHECK(hipMemcpyAsync(d_gath, plan.gathers.data(), plan.gathers.size() * sizeof(GatherDesc),
                                  hipMemcpyHostToDevice, s));
     ECG_HIP_CHECK(hipMemsetAsync(d_small, 0, small_bytes, s));
     rc = launch_gather(s, d_ssz, n_bytes, d_gath, (u32)plan.gathers.size(), d_small);
     if (rc) return rc;
     u64 hc = plan.small_hashes;
-    for (auto& b : plan.bigs) {
-        u8* ws = ar.take(merkle_ws_bytes(b.n0));
-        rc = merkleize_device(s, b.kind, d_ssz + b.src, b.bytes, b.n0, b.depth, b.mix, b.mix_len,
-                              d_small + 32ull * b.out_chunk, ws, &hc);
+    // The 14 big fields are independent trees and so are the leaf-container jobs; only the nested containers
+    // and the 28-field state container wait for them.  The validator registry (93 % of the hashes) runs on the
+    // caller's stream, launched first; every other field runs underneath it on two auxiliary streams with the
+    // fewer-launches schedule, and their finishing jobs (<= 512 nodes -> zero-ladder climb -> mix-in, a chain of
+    // ~30 sequential hash64 each) are batched with the leaf-container jobs into ONE launch instead of fourteen
+    // back-to-back single-workgroup kernels.
+    AuxStreams& ax = c->aux;
+    rc = ax.init();
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
+    for (int i = 0; i < 2; i++) ECG_HIP_CHECK(hipStreamWaitEvent(ax.st[i], ax.fork, 0));
+    size_t biggest = 0;
+    for (size_t i = 1; i < plan.bigs.size(); i++)
+        if (plan.bigs[i].bytes > plan.bigs[biggest].bytes) biggest = i;
+    std::vector<u8*> wss(plan.bigs.size());
+    for (size_t i = 0; i < plan.bigs.size(); i++) wss[i] = ar.take(merkle_ws_bytes(plan.bigs[i].n0));
+    {
+        const BigField& b = plan.bigs[biggest];
+        rc = merkleize_device(s, b.kind, d_ssz + b.src, b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk,
+                              wss[biggest], &hc);
         if (rc) return rc;
     }
-    size_t jo = 0;
+    std::vector<TreeJob> first_jobs;  // deferred finishing jobs of the other big fields + dependency level 0
+    std::vector<TileDesc> tdescs;     // their tile stages, one launch for all of them
+    u32 tile_wgs = 0;
+    for (size_t i = 0; i < plan.bigs.size(); i++) {
+        if (i == biggest) continue;
+        const BigField& b = plan.bigs[i];
+        const MerkleSchedule sc = schedule_merkleize(b.kind, b.n0, b.depth, b.mix, true);
+        TreeJob dj;
+        if (sc.passes.empty()) {
+            // <= 2^19 leaves: leaf functor + 10 levels in the shared tile launch, then the batched finishing job
+            if (sc.tile) {
+                tdescs.push_back({d_ssz + b.src, b.bytes, b.n0, wss[i], (u32)b.kind, 0u, b.depth, tile_wgs});
+                tile_wgs += (u32)((b.n0 + TILE_NODES - 1) / TILE_NODES);
+            }
+            dj.in_off = (u64)(wss[i] - ar.base);
+            dj.out_off = (u64)(d_small + 32ull * b.out_chunk - ar.base);
+            dj.mix_len = b.mix_len;
+            dj.n = sc.job_n;
+            dj.level = sc.job_level;
+            dj.depth = b.depth;
+            dj.mix = b.mix ? 1 : 0;
+            hc += sc.hashes;
+        } else {
+            rc = merkleize_device(ax.st[1], b.kind, d_ssz + b.src, b.bytes, b.n0, b.depth, b.mix, b.mix_len,
+                                  d_small + 32ull * b.out_chunk, wss[i], &hc, &dj, ar.base, true);
+            if (rc) return rc;
+        }
+        first_jobs.push_back(dj);
+    }
+    if (!tdescs.empty()) {
+        TileDesc* d_td = (TileDesc*)ar.take(tdescs.size() * sizeof(TileDesc));
+        if (!d_td) return ECGPU_ERR_OOM;
+        ECG_HIP_CHECK(hipMemcpyAsync(d_td, tdescs.data(), tdescs.size() * sizeof(TileDesc), hipMemcpyHostToDevice, ax.st[0]));
+        rc = launch_tiles(ax.st[0], d_td, (u32)tdescs.size(), tile_wgs);
+        if (rc) return rc;
+    }
+    // level jobs were planned relative to the small-chunk buffer: rebase them onto the arena like the deferred ones
+    const u64 small_off = (u64)(d_small - ar.base);
+    std::vector<TreeJob> all_jobs = first_jobs;
+    size_t level_start[4];
+    level_start[0] = 0;
     for (int l = 0; l < 3; l++) {
-        rc = launch_tree_jobs(s, d_jobs + jo, (u32)plan.jobs[l].size(), d_small);
-        if (rc) return rc;
-        jo += plan.jobs[l].size();
+        for (TreeJob j : plan.jobs[l]) {
+            j.in_off += small_off;
+            j.out_off += small_off;
+            all_jobs.push_back(j);
+        }
+        level_start[l + 1] = all_jobs.size();
     }
+    ECG_HIP_CHECK(hipEventRecord(ax.done[1], ax.st[1]));
+    ECG_HIP_CHECK(hipStreamWaitEvent(ax.st[0], ax.done[1], 0));
+    ECG_HIP_CHECK(hipMemcpyAsync(d_jobs, all_jobs.data(), all_jobs.size() * sizeof(TreeJob), hipMemcpyHostToDevice, ax.st[0]));
+    rc = launch_tree_jobs(ax.st[0], d_jobs, (u32)level_start[1], ar.base);
+    if (rc) return rc;
+    // nested containers (sync committees, payload header): off the critical path too, unless the field on the
+    // caller's stream is itself an input of one (its root is not one of the 28 state-container chunks)
+    const bool lvl1_on_main = plan.bigs[biggest].out_chunk >= 32;
+    if (!lvl1_on_main) {
+        rc = launch_tree_jobs(ax.st[0], d_jobs + level_start[1], (u32)(level_start[2] - level_start[1]), ar.base);
+        if (rc) return rc;
+    }
+    ECG_HIP_CHECK(hipEventRecord(ax.done[0], ax.st[0]));
+    ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[0], 0));
+    if (lvl1_on_main) {
+        rc = launch_tree_jobs(s, d_jobs + level_start[1], (u32)(level_start[2] - level_start[1]), ar.base);
+        if (rc) return rc;
+    }
+    rc = launch_tree_jobs(s, d_jobs + level_start[2], (u32)(level_start[3] - level_start[2]), ar.base);
+    if (rc) return rc;
     ECG_HIP_CHECK(hipMemcpyAsync(d_root, d_small + 32ull * plan.root_chunk, 32, hipMemcpyDeviceToDevice, s));
     c->last_hash64 = hc;
     return ECGPU_SUCCESS;

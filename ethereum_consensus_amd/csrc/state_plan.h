@@ -33,10 +33,12 @@ inline u32 ceil_log2_u64(u64 x) {
 // ---- pass schedule of one merkleize ----------------------------------------------------------
 // Height of the subtree one lane reduces in a pass over `n` inputs: keep >= 2^18 lanes in flight
 // (4 waves per SIMD on 256 CUs) while the tree is wide, go level by level once it is narrow
-// (a narrow level is latency-bound by one hash64 per lane whatever D is).
-inline int choose_pass_height(u64 n) {
+// (a narrow level is latency-bound by one hash64 per lane whatever D is).  `background` trees run
+// underneath a bigger one on another stream: their latency is hidden, so they trade it for fewer
+// launches (>= 2^14 lanes per pass).
+inline int choose_pass_height(u64 n, bool background = false) {
     int lg = 63 - __builtin_clzll(n | 1);
-    int d = lg - 18;
+    int d = lg - (background ? 14 : 18);
     if (d < 1) d = 1;
     if (d > 6) d = 6;
     return d;
@@ -52,8 +54,13 @@ struct PassStep {
 
 struct MerkleSchedule {
     std::vector<PassStep> passes;
+    // optional tile stage (merkle.h TileDesc) between the passes and the finishing job
+    bool tile = false;
+    bool tile_first = false;   // the tile stage runs the field's leaf functor (no pass before it)
+    u64 tile_n_in = 0;
+    u32 tile_level_in = 0;
     u32 job_n, job_level;  // finishing job: job_n nodes at job_level -> depth (+ mix-in)
-    u64 hashes;            // hash64 executed, leaf functors included
+    u64 hashes;            // hash64 of the tree (schedule-independent): leaf functors + every non-virtual node
 };
 
 inline u64 leaf_hash_cost(LeafKind k) {
@@ -66,36 +73,55 @@ inline u64 leaf_hash_cost(LeafKind k) {
     }
 }
 
-inline MerkleSchedule schedule_merkleize(LeafKind kind, u64 n0, u32 depth, bool mix) {
+inline u64 tree_hash_count(LeafKind kind, u64 n0, u32 depth, bool mix) {
+    u64 h = n0 * leaf_hash_cost(kind);
+    u64 c = n0;
+    if (n0)
+        for (u32 l = 0; l < depth; l++) {
+            c = (c + 1) / 2;
+            h += c;
+        }
+    return h + (mix ? 1 : 0);
+}
+
+// Wide levels: depth-first passes (>= 2^18 lanes each) until at most TILE_MAX_IN nodes are left; then ONE tile
+// stage (1024 nodes per workgroup, 10 levels) and the finishing job.  Validator records always get a pass of their
+// own (8 hash64 per record, 92 VGPRs: it is the kernel the roofline is quoted on).
+inline MerkleSchedule schedule_merkleize(LeafKind kind, u64 n0, u32 depth, bool mix, bool background = false) {
     MerkleSchedule sc;
-    sc.hashes = n0 * leaf_hash_cost(kind);
+    sc.hashes = tree_hash_count(kind, n0, depth, mix);
     u64 n = n0;
     u32 level = 0;
     bool first = (kind != LEAF_NODES);  // a leaf functor still has to run
-    while (n > 0 && (first || n > TREEJOB_MAX_NODES)) {
-        int D = choose_pass_height(n);
-        if ((u32)D > depth - level) D = (int)(depth - level);
-        if (!first && D == 0) break;
+    auto push_pass = [&](int D) {
         const u64 n_out = (n + (1ull << D) - 1) >> D;
         sc.passes.push_back({D, n, n_out, level, first});
-        u64 c = n;  // hash64 of the pass: every non-virtual node of levels 1..D
-        for (int d = 0; d < D; d++) {
-            c = (c + 1) / 2;
-            sc.hashes += c;
-        }
         level += (u32)D;
         n = n_out;
         first = false;
+    };
+    while (n > 0 && ((first && kind == LEAF_VALIDATORS) || n > TILE_MAX_IN)) {
+        int D = choose_pass_height(n, background);
+        if ((u32)D > depth - level) D = (int)(depth - level);
+        if (!first && D == 0) break;
+        push_pass(D);
+    }
+    if (n > 0 && (first || n > TREEJOB_MAX_NODES)) {
+        if (depth - level >= TILE_D) {
+            sc.tile = true;
+            sc.tile_first = first;
+            sc.tile_n_in = n;
+            sc.tile_level_in = level;
+            const u32 up = depth - level < TILE_LEVELS ? depth - level : TILE_LEVELS;
+            n = up == TILE_LEVELS ? (n + TILE_NODES - 1) / TILE_NODES : 1;
+            level += up;
+            first = false;
+        } else {
+            push_pass((int)(depth - level));  // trees of height 0 or 1 behind a leaf functor
+        }
     }
     sc.job_n = (u32)n;
     sc.job_level = level;
-    if (n > 0) {
-        u64 c = n;
-        u32 l = level;
-        while (c > 1) { c = (c + 1) / 2; sc.hashes += c; l++; }
-        sc.hashes += depth - l;
-    }
-    if (mix) sc.hashes += 1;
     return sc;
 }
 

@@ -43,6 +43,11 @@ static void run_pass(int D, const Leaf& leaf, u64 n_in, u64 n_out, u8* out, int 
     }
 }
 
+template <class Leaf>
+static Node tile_lane(const Leaf& leaf, u64 first, u64 n, int level0) {
+    return Subtree<TILE_D, Leaf>::run(leaf, first, n, zt(), level0);
+}
+
 extern "C" {
 
 void hs_zero_table(u8* out /* 65*32 */) {
@@ -85,6 +90,39 @@ u64 hs_pass(int kind, int D, const u8* in, u64 in_bytes, u64 n_in, u8* out, int 
     return n_out;
 }
 
+// the tile stage exactly as k_tree_tiles runs it (merkle.h TileDesc): per tile 256 lanes x Subtree<2>, then up to
+// 8 levels pairwise with the virtual-pair shortcut; one node per tile at level min(top, level0 + 10)
+u64 hs_tiles(int kind, const u8* in, u64 in_bytes, u64 n0, u32 level0, u32 top, u8* out) {
+    const u64 n_tiles = (n0 + TILE_NODES - 1) / TILE_NODES;
+    for (u64 tile = 0; tile < n_tiles; tile++) {
+        std::vector<Node> nodes(TILE_LANES);
+        for (u32 t = 0; t < TILE_LANES; t++) {
+            const u64 first = tile * TILE_NODES + ((u64)t << TILE_D);
+            switch (kind) {
+                case 1: nodes[t] = tile_lane(NodeLeaves{in}, first, n0, (int)level0); break;
+                case 3: nodes[t] = tile_lane(Bytes48Leaves{in, in_bytes}, first, n0, (int)level0); break;
+                case 4: nodes[t] = tile_lane(Pair64Leaves{in, in_bytes}, first, n0, (int)level0); break;
+                case 5: nodes[t] = tile_lane(Eth1DataLeaves{in, in_bytes}, first, n0, (int)level0); break;
+                default: nodes[t] = tile_lane(ChunkLeaves{in, in_bytes}, first, n0, (int)level0); break;
+            }
+        }
+        u32 lvl = level0 + TILE_D, m = TILE_LANES;
+        while (lvl < top && m > 1) {
+            const u32 pairs = m >> 1;
+            std::vector<Node> h(pairs);
+            for (u32 t = 0; t < pairs; t++) {
+                const u64 left_first = tile * TILE_NODES + ((u64)(2 * t) << (lvl - level0));
+                h[t] = left_first >= n0 ? zt()->z[lvl + 1] : hash64(nodes[2 * t], nodes[2 * t + 1]);
+            }
+            for (u32 t = 0; t < pairs; t++) nodes[t] = h[t];
+            m = pairs;
+            lvl++;
+        }
+        node_store(nodes[0], out + 32ull * tile);
+    }
+    return n_tiles;
+}
+
 // the finishing job exactly as k_tree_jobs runs it (level by level, zero-ladder climb, mix-in)
 void hs_tree_job(const u8* in, u32 n, u32 level, u32 depth, int mix, u64 mix_len, u8* out) {
     std::vector<Node> nodes(n ? n : 1);
@@ -121,6 +159,13 @@ static void sim_merkleize(LeafKind kind, const u8* in, u64 in_bytes, u64 n0, u32
         dst.assign(32 * (p.n_out ? p.n_out : 1), 0);
         if (p.first) hs_pass((int)kind, p.D, in, in_bytes, p.n_in, dst.data(), 0);
         else hs_pass(1, p.D, cur, 32 * p.n_in, p.n_in, dst.data(), (int)p.level_in);
+        cur = dst.data();
+    }
+    if (sc.tile) {
+        std::vector<u8>& dst = (cur == a.data()) ? b : a;
+        dst.assign(32 * ((sc.tile_n_in + TILE_NODES - 1) / TILE_NODES + 1), 0);
+        if (sc.tile_first) hs_tiles((int)kind, in, in_bytes, sc.tile_n_in, sc.tile_level_in, depth, dst.data());
+        else hs_tiles(1, cur, 32 * sc.tile_n_in, sc.tile_n_in, sc.tile_level_in, depth, dst.data());
         cur = dst.data();
     }
     hs_tree_job(cur, sc.job_n, sc.job_level, depth, mix ? 1 : 0, mix_len, out);

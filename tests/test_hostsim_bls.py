@@ -273,3 +273,29 @@ def test_fast_aggregate_verify_status_algebra():
     for pks, msg, sig, eth in C.fav_cases():
         got = L.hs_fast_aggregate_verify(b"".join(pks), len(pks), msg, len(msg), sig, eth)
         assert got == C.oracle_fav(pks, msg, sig, eth), (len(pks), eth)
+
+
+@pytest.mark.parametrize("entry", ["hs_vm_pairing", "hs_vm2_pairing"])
+def test_lane_group_vm_pairing_programs(entry):
+    """The generated lane-group programs (tools/gen_bls_vm.py, gen_bls_vm2.py) executed with the kernel's
+    lock-step semantics: e(P, H) e(-g1, S) after the final exponentiation, coefficient by coefficient."""
+    r = random.Random(23)
+    L = lib()
+    fn = getattr(L, entry)
+    fn.restype = ctypes.c_int
+    out = ctypes.create_string_buffer(576)
+    neg_g1 = (B.G1[0], (P - B.G1[1]) % P)
+    # a valid (pk, H(m), sig) triple: the product is one
+    sk = r.randrange(1, B.R)
+    pk = B.g1_mul(B.G1, sk)
+    H = B.hash_to_g2(b"vm program check")
+    sig = B.g2_mul(H, sk)
+    assert fn(a1(pk), a2(H), a2(sig), out) == 1
+    assert f12_un(out.raw) == B.F12_ONE
+    # unrelated points: equal to the oracle's value, not one
+    Pt, Q, S = B.g1_mul(B.G1, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R))
+    assert fn(a1(Pt), a2(Q), a2(S), out) == 0
+    want = B.final_exponentiation(B.f12_mul(B.miller_loop(Pt, Q), B.miller_loop(neg_g1, S)))
+    got = f12_un(out.raw)
+    # the programs compute f^(3 (p^12 - 1)/r) like csrc/bls_pairing.h (the factor 3 keeps == 1 intact)
+    assert got == B.f12_mul(B.f12_sqr(want), want) or got == want

@@ -135,3 +135,19 @@ def test_beacon_state_plan_rejects_malformed():
     enc = bytearray(S.beacon_state_deneb(3, "minimal"))
     assert hs.state_root_deneb(bytes(enc[:100]), 1)[0] == -3
     assert hs.state_root_deneb(bytes(enc) + b"\0", 1)[0] == -3  # historical_summaries not a multiple of 64
+
+
+@pytest.mark.parametrize("n0,limit", [(513, 1024), (1023, 1024), (1024, 1024), (1025, 2048), (2049, 1 << 40), (5000, 8192),
+                                      (3 * 1024, 1 << 38), (600, 1 << 10)])
+def test_tile_stage_schedule(n0, limit):
+    """Trees wider than one finishing job go through the tile stage (merkle.h TileDesc: 1024 nodes per workgroup,
+    virtual pairs taken from the zero ladder): ragged tails, exact powers of two, shallow and deep limits."""
+    data = rnd(32 * n0 - 5, n0)
+    depth = ssz._depth_for(limit)
+    got, h = hs.merkleize_scheduled(0, data, n0, depth, True, n0, 3)
+    assert got == ssz.mix_in_length(ssz.merkleize_bytes(data, limit), n0)
+    assert h == ssz.hash64_count(n0, limit) + 1
+    # record functors inside the tile stage: 48-byte keys and Eth1Data records
+    keys = rnd(48 * n0, n0 + 1)
+    got, _ = hs.merkleize_scheduled(3, keys, n0, depth, False, 0)
+    assert got == ssz.merkleize_chunks([ssz.merkleize_bytes(keys[48 * i: 48 * i + 48], 2) for i in range(n0)], limit)
