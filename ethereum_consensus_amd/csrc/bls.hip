@@ -32,8 +32,9 @@ int init_bls_tables(hipStream_t) {
 
 constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches over every CU
 #ifndef ECG_BLS_WAVES
-#define ECG_BLS_WAVES 2  // waves per SIMD the register allocator must leave room for (256 VGPRs): measured 12-25 % faster than 4
-                         // (profiles/r01b_bls_occupancy_probe.txt) -- these lane kernels are bound by private-segment traffic
+#define ECG_BLS_WAVES 1  // waves per SIMD the register allocator must leave room for: 1 = the whole 512-entry VGPR+AGPR file.
+                         // These lane kernels are bound by private-segment traffic, so registers beat occupancy
+                         // (65 ms vs 76 ms per 65 536 tuples at 1 vs 2 waves/SIMD, profiles/r01k_bls_probe_*.txt)
 #endif
 
 // ---- stage kernels ---------------------------------------------------------------------------
@@ -266,12 +267,13 @@ static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
     return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + vm_xfer_bytes(n) + vm2_xfer_bytes(n) + 8192;
 }
-// development switch ECGPU_PAIRING = lane | vm | vm2 (default): which pairing-check kernels run
+// development switch ECGPU_PAIRING = lane (default) | vm | vm2: which pairing-check kernels run.  The lane-group
+// VMs are correct but measured slower than the lane kernel (profiles/r01e_bls_probe_*.txt): experiments only.
 static const int g_pairing_mode = [] {
     const char* e = getenv("ECGPU_PAIRING");
-    if (e && !strcmp(e, "lane")) return 0;
     if (e && !strcmp(e, "vm")) return 1;
-    return 2;
+    if (e && !strcmp(e, "vm2")) return 2;
+    return 0;
 }();
 
 // all pointers device-resident; ws from the caller's arena
