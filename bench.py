@@ -23,7 +23,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s, 6.29 measured copy)
-INT_VALU_PEAK_TOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, full-rate 32-bit integer ops
+# Measured ALU ceilings of the two paths' inner loops on MI355X (tools/fpbench.hip, register-resident chains at 8 waves/SIMD):
+HASH64_PEAK_GHS = 17.66    # profiles/r01h_hash64_rate_vs_occupancy.txt: 2410 VALU instructions per hash64 at ~3.7 cycles each
+MUL_PIPE_PEAK_TOPS = 31.0  # profiles/r01a_int_issue_rate_microbench.txt: v_mad_u64_u32 issue rate (fp_mul sustains 28 T, r01f)
+
+
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate runs, see
+    profiles/pmc_traffic.json and tools/gpu_round1*.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the factor 2 is the gfx950
+    FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  None when no pass has been recorded for this kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(kernel_key)
+    except (OSError, ValueError):
+        return None
+    if not rec:
+        return None
+    return {"bytes_per_launch": int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024), "fetch_size_kib": rec["fetch_kib"],
+            "write_size_kib": rec["write_kib"], "source": rec.get("source"), "note": "separate rocprofv3 --pmc passes; FETCH_SIZE doubled (gfx950)"}
 
 
 def parse():
@@ -35,6 +52,7 @@ def parse():
     ap.add_argument("--validators", type=int, default=1 << 20)
     ap.add_argument("--tuples", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aggregates", action="store_true", help="skip the secondary K = 2048 aggregates line")
     return ap.parse_args()
 
 
@@ -112,12 +130,16 @@ def run_merkle(args, L, torch, dist, rank, world):
         config={"workload": f"hash_tree_root(BeaconState) deneb mainnet, {n} validators, SSZ-encoded state "
                             f"({len(enc)} B) resident in HBM", "hash64_per_state": hashes, "state_bytes": len(enc),
                 "sharding": "one independent state per GPU; all-gather of the 32-byte roots"},
-        roofline={"bound": "hbm", "kernel": "k_merkle_pass<ValidatorLeaves>", "achieved": achieved,
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        roofline={"bound": "hbm", "kernel": "k_merkle_pass<2, ValidatorLeaves>", "achieved": achieved,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                  "traffic": pmc_traffic("k_merkle_pass<2, ValidatorLeaves>"),
                   "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches_timed": int(nl.value),
-                  "valu_int": {"achieved_Tops": val_hashes * 2410 / (kern_ms * 1e-3) / 1e12 if kern_ms else 0.0,
-                               "peak_Tops": INT_VALU_PEAK_TOPS,
-                               "note": "2410 VALU instructions per hash64 (ISA count of ecg::hash64)"}},
+                  "valu_int": {"unit": "G hash64/s", "achieved": val_hashes / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0,
+                               "peak": HASH64_PEAK_GHS,
+                               "frac": (val_hashes / (kern_ms * 1e-3) / 1e9 / HASH64_PEAK_GHS) if kern_ms else 0.0,
+                               "whole_state_frac": hashes / (dt / args.steps) / 1e9 / HASH64_PEAK_GHS,
+                               "note": "the path is integer-VALU bound: 2410 VALU instructions per 64-byte hash64; peak = "
+                                       "register-resident hash64 chains at 8 waves/SIMD (tools/fpbench.hip)"}},
         root=bytes(d_root.cpu().numpy()).hex(),
     )
 
@@ -127,7 +149,6 @@ R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 # (tests/hostsim hs_op_census, valid tuple): (fp_mul, fp_sqr) per stage.  A product is 351 (273 for
 # a square) quarter-rate integer multiplies (v_mad_u64_u32 / v_mul_lo_u32), see csrc/bls_fp.h.
 BLS_OPS = {"bls_pk_validate": (485, 1064), "bls_sig": (1583, 1133), "bls_h2c": (3896, 3414), "bls_pairing": (19643, 382)}
-MUL_PIPE_PEAK_TOPS = 31.0  # measured v_mad_u64_u32 issue rate, profiles/r01a_int_issue_rate_microbench.txt
 BLS_BYTES_PER_SIG = 48 + 32 + 96 + 1  # K = 1 tuple in, status byte out
 
 
@@ -160,9 +181,28 @@ def cpu_baseline_bls(budget_s: float = 15.0):
         assert B.fast_aggregate_verify([pk], m, sg) == 0
         done += 1
     dt = time.time() - t0
-    return {"value": done / dt, "unit": "sigs/s", "cores": 1, "kind": "port",
-            "sample": f"{done} fast_aggregate_verify calls (K = 1, tuples 0..7 of the same workload) in {dt:.1f} s, "
-                      "oracle/bls12_381.py (pure Python big-int; blst itself is not available offline)"}
+    out = {"value": done / dt, "unit": "sigs/s", "cores": 1, "kind": "port",
+           "sample": f"{done} fast_aggregate_verify calls (K = 1, tuples 0..7 of the same workload) in {dt:.1f} s, "
+                     "oracle/bls12_381.py (pure Python big-int; blst itself is not available offline)"}
+    # extra, not the baseline: the device lane programs themselves compiled for the host by g++ -O2 (tests/hostsim)
+    try:
+        from tests import _hostsim
+        H = _hostsim.lib()
+        ncore = min(8, len(os.sched_getaffinity(0)))
+        m = 16 * ncore
+        pks = b"".join(t[0] for t in tuples) * (m // 8)
+        ms_ = b"".join(t[1] for t in tuples) * (m // 8)
+        sgs = b"".join(t[2] for t in tuples) * (m // 8)
+        st = ctypes.create_string_buffer(m)
+        t0 = time.time()
+        H.hs_fav_batch_k1(pks, ms_, sgs, m, ncore, st)
+        dt2 = time.time() - t0
+        if set(st.raw) == {0}:
+            out["lane_programs_on_host"] = {"value": m / dt2, "unit": "sigs/s", "cores": ncore,
+                                            "sample": f"{m} tuples, csrc/bls_*.h compiled by g++ -O2 (13 x 30-bit limbs, no SIMD), {ncore} threads"}
+    except Exception as e:  # the simulator is test infrastructure: its absence must not fail the bench
+        out["lane_programs_on_host"] = {"error": str(e)[:200]}
+    return out
 
 
 def run_bls(args, L, torch, dist, rank, world):
@@ -233,13 +273,65 @@ def run_bls(args, L, torch, dist, rank, world):
                                           "decompressed + subgroup-checked, every message hashed to G2, per-tuple pairing check",
                 "sharding": "one independent batch per GPU; all-gather of the status bytes every step"},
         roofline={"bound": "hbm", "kernel": "k_pairing", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                  "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_pairing"), "algorithmic_bytes_per_launch": alg_bytes,
                   "avg_launch_ms": kern_ms, "stage_ms": stages,
                   "valu_int": {"unit": "T multiplies/s (v_mad_u64_u32 + v_mul_lo_u32)", "peak": MUL_PIPE_PEAK_TOPS,
                                "achieved": {k: (mul_ops[k] / (stages[k] * 1e-3) / 1e12 if stages[k] > 0 else 0.0) for k in stages},
                                "note": "the path is integer-multiplier bound, not HBM bound: 10.6 M multiplies vs 177 B per signature"}},
         check={"statuses_match_construction": ok, "expected_failures": int(want.astype(bool).sum())},
     )
+
+
+def run_bls_aggregate(args, L, torch, dist, rank, world, n_agg=256, k=2048):
+    """BASELINE.json configs[3] per-GPU share: 256 committee aggregates of K = 2048 keys each (32 slots x 64 committees
+    over 8 GPUs), reference semantics (every key decompressed + subgroup-checked on every call).  Secondary line."""
+    import numpy as np
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+    n_keys = n_agg * k
+    sks, _ = bls_inputs(n_keys, rank * n_keys)
+    d_sk = torch.frombuffer(bytearray(sks), dtype=torch.uint8).to(dev)
+    d_pk = torch.empty(48 * n_keys, dtype=torch.uint8, device=dev)
+    assert L.ecgpu_sk_to_pk_batch_dev(d_sk.data_ptr(), n_keys, d_pk.data_ptr(), stream) == 0
+    agg_sk = b"".join((sum(int.from_bytes(sks[32 * j:32 * j + 32], "big") for j in range(c * k, (c + 1) * k)) % R_ORDER).to_bytes(32, "big")
+                      for c in range(n_agg))
+    msgs = bytearray(b"".join(S(b"att", rank * n_agg + c) for c in range(n_agg)))
+    d_ask = torch.frombuffer(bytearray(agg_sk), dtype=torch.uint8).to(dev)
+    d_msg_clean = torch.frombuffer(bytearray(msgs), dtype=torch.uint8).to(dev)
+    d_sig = torch.empty(96 * n_agg, dtype=torch.uint8, device=dev)
+    assert L.ecgpu_sign_batch_dev(d_ask.data_ptr(), 32, d_msg_clean.data_ptr(), n_agg, d_sig.data_ptr(), stream) == 0
+    for c in range(0, n_agg, 64):  # 1/64 committees verify a message that was not signed
+        msgs[32 * c] ^= 1
+    d_msg = torch.frombuffer(msgs, dtype=torch.uint8).to(dev)
+    d_off = torch.from_numpy(np.arange(0, n_keys + 1, k, dtype=np.uint32)).to(dev)
+    d_st = torch.full((n_agg,), 0xFF, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        rc = L.ecgpu_fast_aggregate_verify_batch_dev(d_pk.data_ptr(), d_off.data_ptr(), n_keys, d_msg.data_ptr(), d_sig.data_ptr(),
+                                                     n_agg, 0, d_st.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(f"ecgpu_fast_aggregate_verify_batch_dev -> {rc}: {L.ecgpu_last_error()}")
+
+    step()
+    torch.cuda.synchronize()
+    steps = max(3, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    want = np.zeros(n_agg, dtype=np.uint8)
+    want[::64] = 5
+    ok = bool((d_st.cpu().numpy() == want).all())
+    return {"metric": "bls_signatures_verified_per_sec (K = 2048 aggregates)", "value": n_keys / dt, "unit": "sigs/s",
+            "aggregates_per_s": n_agg / dt, "ms_per_step": dt * 1e3, "n_gpus": 1,
+            "config": {"workload": f"fast_aggregate_verify of {n_agg} aggregates x {k} keys (configs[3] per-GPU share), "
+                                   "reference semantics, 1/64 aggregates carry a wrong message"},
+            "roofline": {"bound": "hbm", "achieved": (48 * n_keys + 129 * n_agg) / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (48 * n_keys + 129 * n_agg) / dt / 1e9 / HBM_PEAK_GBS,
+                         "note": "48.06 B per signature (SURVEY.md 8d); the work is the per-key decompress + subgroup check"},
+            "check": {"statuses_match_construction": ok}}
 
 
 def _prof(L, tag):
@@ -295,6 +387,8 @@ def main():
     line = None
     if workload in ("bls", "both"):
         line = finish(run_bls(args, L, torch, dist, rank, world))
+        if world == 1 and not args.no_aggregates:
+            line["aggregates_k2048"] = run_bls_aggregate(args, L, torch, dist, rank, world)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_bls()
     if workload in ("merkle", "both"):

@@ -21,7 +21,6 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libecgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-VM_GEN_ARGS = ["--lanes", "16", "--window", "400"]
 VM2_GEN_ARGS = os.environ.get("ECGPU_VM2_GEN_ARGS", "--lanes 16 --window 200").split()
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
@@ -52,9 +51,9 @@ def _run(cmd):
 
 
 def generate_vm_programs(verbose: bool = True) -> str:
-    """csrc/bls_vm_prog.h / bls_vm2_prog.h (generated tables) are produced by tools/gen_bls_vm*.py, not committed."""
+    """csrc/bls_vm2_prog.h (generated tables) is produced by tools/gen_bls_vm2.py, not committed."""
     out = None
-    for script, header, gen_args in (("gen_bls_vm.py", "bls_vm_prog.h", VM_GEN_ARGS), ("gen_bls_vm2.py", "bls_vm2_prog.h", VM2_GEN_ARGS)):
+    for script, header, gen_args in (("gen_bls_vm2.py", "bls_vm2_prog.h", VM2_GEN_ARGS),):
         gen = os.path.join(ROOT, "tools", script)
         out = os.path.join(CSRC, header)
         stamp = out + ".args"
@@ -112,7 +111,7 @@ def build_hostsim(verbose: bool = True) -> str:
         obj = os.path.join(d, "obj", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if _newer(obj, [src] + _headers()):
-            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-c", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
                          "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), src, "-o", obj])
     if jobs:
         if verbose:
@@ -120,7 +119,7 @@ def build_hostsim(verbose: bool = True) -> str:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(_run, jobs))
     if jobs or _newer(out, objs):
-        _run(["g++", "-shared", "-o", out] + objs)
+        _run(["g++", "-shared", "-pthread", "-o", out] + objs)
     return out
 
 

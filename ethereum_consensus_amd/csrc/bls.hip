@@ -24,11 +24,7 @@
 
 namespace ecg {
 
-int init_vm_tables();  // bls_vm.hip
-int init_bls_tables(hipStream_t) {
-    int rc = init_vm_tables();
-    return rc ? rc : init_vm2_tables();
-}
+int init_bls_tables(hipStream_t) { return init_vm2_tables(); }
 
 constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches over every CU
 #ifndef ECG_BLS_WAVES
@@ -48,11 +44,12 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pk_validate(const 
 }
 
 // sum of affine points lo..hi per tuple; first non-zero status (lowest index) wins.
-// off == nullptr: a single range [0, n_total).
-template <class F>
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts, const u8* st, const u32* off, u32 n_total, Aff<F>* out,
-                                                    u8* out_st) {
-    __shared__ Jac<F> sh[BLS_BLOCK];
+// off == nullptr: a single range [0, n_total).  BLOCK lanes per tuple: 64 when there are many short tuples, 256 for
+// a few long ones (256 committees of 2048 keys on 64 lanes each would leave three quarters of the SIMDs idle).
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts, const u8* st, const u32* off, u32 n_total, Aff<F>* out,
+                                                            u8* out_st) {
+    __shared__ Jac<F> sh[BLOCK];
     __shared__ u32 first_bad;
     const u32 t = blockIdx.x, tid = threadIdx.x;
     const u32 lo = off ? off[t] : 0, hi = off ? off[t + 1] : n_total;
@@ -60,7 +57,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* 
     __syncthreads();
     Jac<F> acc;
     jac_set_inf(acc);
-    for (u32 i = lo + tid; i < hi; i += BLS_BLOCK) {
+    for (u32 i = lo + tid; i < hi; i += BLOCK) {
         if (st && st[i]) {
             atomicMin(&first_bad, i);
             continue;
@@ -72,7 +69,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* 
     }
     sh[tid] = acc;
     __syncthreads();
-    for (u32 stride = BLS_BLOCK / 2; stride > 0; stride >>= 1) {
+    for (u32 stride = BLOCK / 2; stride > 0; stride >>= 1) {
         if (tid < stride) {
             Jac<F> o = sh[tid + stride];
             jac_add(acc, acc, o);
@@ -94,6 +91,14 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* 
         out[t] = r;
         if (out_st) out_st[t] = s;
     }
+}
+template <class F>
+static void launch_sum(hipStream_t s, u32 n_tuples, u32 n_pts, const Aff<F>* pts, const u8* st, const u32* off, Aff<F>* out, u8* out_st) {
+    const bool wide = (u64)n_pts >= 512ull * n_tuples && n_tuples < 4096;
+    if (wide)
+        hipLaunchKernelGGL((k_sum<F, 256>), dim3(n_tuples), dim3(256), 0, s, pts, st, off, n_pts, out, out_st);
+    else
+        hipLaunchKernelGGL((k_sum<F, 64>), dim3(n_tuples), dim3(64), 0, s, pts, st, off, n_pts, out, out_st);
 }
 
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sig(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp) {
@@ -265,20 +270,26 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sign(const u8* sks
 static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
-    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + vm_xfer_bytes(n) + vm2_xfer_bytes(n) + 8192;
+    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + vm2_xfer_bytes(n) + 8192;
 }
-// development switch ECGPU_PAIRING = lane (default) | vm | vm2: which pairing-check kernels run.  The lane-group
-// VMs are correct but measured slower than the lane kernel (profiles/r01e_bls_probe_*.txt): experiments only.
+// Which kernels run the pairing check.  The lane kernel (one lane per tuple, state in VGPRs/AGPRs + private segment)
+// has the best throughput but one tuple's check is a 35 ms dependent chain, so a batch of a few thousand tuples
+// leaves most SIMDs idle; the lane-group Fp2 VM (bls_vm2.hip, 16 lanes per tuple) has a third of the throughput and
+// a quarter of the latency.  ECGPU_PAIRING = auto (default: VM below ECGPU_VM2_MAX tuples) | lane | vm2.
 static const int g_pairing_mode = [] {
     const char* e = getenv("ECGPU_PAIRING");
-    if (e && !strcmp(e, "vm")) return 1;
+    if (e && !strcmp(e, "lane")) return 0;
     if (e && !strcmp(e, "vm2")) return 2;
-    return 0;
+    return 3;
+}();
+static const u32 g_vm2_max_tuples = [] {
+    const char* e = getenv("ECGPU_VM2_MAX");
+    return e ? (u32)strtoul(e, nullptr, 10) : 12288u;
 }();
 
 // all pointers device-resident; ws from the caller's arena
 static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_off, u32 n_pks, const u8* d_msgs, const u64* d_msg_off,
-                            const u8* d_sigs96, u32 n, int eth_variant, u8* d_status, Arena& ar) {
+                            const u8* d_sigs96, u32 n, int eth_variant, u8* d_status, Arena& ar, AuxStreams& ax) {
     if (n == 0) return ECGPU_SUCCESS;
     A1* pts = (A1*)ar.take((size_t)(n_pks ? n_pks : 1) * sizeof(A1));
     u8* st = ar.take(n_pks ? n_pks : 1);
@@ -294,33 +305,48 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         if (!agg || !st_pk) return ECGPU_ERR_OOM;
     }
     if (!pts || !st || !sigpts || !hpts || !st_dec || !st_grp) return ECGPU_ERR_OOM;
+    // Key-heavy batches (committees): the signature and message stages do not depend on the keys, so they run on an
+    // auxiliary stream underneath the key validation + aggregation and join before the pairing check.
+    const bool fork = d_pk_off && n_pks >= 4ull * n;
+    hipStream_t s2 = s;
+    if (fork) {
+        int rc = ax.init();
+        if (rc) return rc;
+        s2 = ax.st[0];
+        ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
+        ECG_HIP_CHECK(hipStreamWaitEvent(s2, ax.fork, 0));
+    }
     if (n_pks) {
         ProfScope ps("bls_pk_validate", s);
         hipLaunchKernelGGL(k_pk_validate, grid_for(n_pks), dim3(BLS_BLOCK), 0, s, d_pks48, n_pks, pts, st);
     }
     if (d_pk_off) {
         ProfScope ps("bls_pk_aggregate", s);
-        hipLaunchKernelGGL(k_sum<Fp>, dim3(n), dim3(BLS_BLOCK), 0, s, (const A1*)pts, (const u8*)st, d_pk_off, n_pks, agg, st_pk);
+        launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk);
     }
     {
-        ProfScope ps("bls_sig", s);
-        hipLaunchKernelGGL(k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s, d_sigs96, n, sigpts, st_dec, st_grp);
+        ProfScope ps("bls_sig", s2);
+        hipLaunchKernelGGL(k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_sigs96, n, sigpts, st_dec, st_grp);
     }
     {
-        ProfScope ps("bls_h2c", s);
-        hipLaunchKernelGGL(k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s, d_msgs, d_msg_off, n, hpts);
+        ProfScope ps("bls_h2c", s2);
+        hipLaunchKernelGGL(k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
+    }
+    if (fork) {
+        ECG_HIP_CHECK(hipEventRecord(ax.done[0], s2));
+        ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[0], 0));
     }
     {
         ProfScope ps("bls_pairing", s);
-        if (g_pairing_mode == 0) {
+        const bool use_vm = g_pairing_mode == 2 || (g_pairing_mode == 3 && n <= g_vm2_max_tuples);
+        if (!use_vm) {
             hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
                                (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, 0);
         } else {
-            u32* xfer = (u32*)ar.take(g_pairing_mode == 1 ? vm_xfer_bytes(n) : vm2_xfer_bytes(n));
+            u32* xfer = (u32*)ar.take(vm2_xfer_bytes(n));
             if (!xfer) return ECGPU_ERR_OOM;
-            int rc = (g_pairing_mode == 1 ? vm_pairing_launch : vm2_pairing_launch)(s, (const A1*)agg, (const u8*)st_pk, d_pk_off,
-                                                                                    (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec,
-                                                                                    (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
+            int rc = vm2_pairing_launch(s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec,
+                                        (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
             if (rc) return rc;
             // tuples with a point at infinity in the pairing (signature 0xc0.., H(m) = inf): rare, branchy lane kernel
             hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
@@ -368,7 +394,7 @@ static int fav_batch_host(const u8* pks48, const u32* pk_off, u32 n_pks, const u
     if (msg_off && (rc = h2d(k, d_moff, msg_off, (size_t)(n + 1) * 8))) return rc;
     u8* d_status = k.ar->take(n);
     if (!d_status) return ECGPU_ERR_OOM;
-    rc = fav_batch_device(k.s, d_pks, (const u32*)d_off, n_pks, d_msgs, (const u64*)d_moff, d_sigs, n, eth_variant, d_status, *k.ar);
+    rc = fav_batch_device(k.s, d_pks, (const u32*)d_off, n_pks, d_msgs, (const u64*)d_moff, d_sigs, n, eth_variant, d_status, *k.ar, k.c->aux);
     if (rc) return rc;
     ECG_HIP_CHECK(hipMemcpyAsync(status_out, d_status, n, hipMemcpyDeviceToHost, k.s));
     ECG_HIP_CHECK(hipStreamSynchronize(k.s));
@@ -398,7 +424,7 @@ int ecgpu_fast_aggregate_verify_batch_dev(const uint8_t* d_pks48, const uint32_t
     CallCtx k;
     int rc = begin_call(k, stream, fav_ws_bytes(n, n_pks_total));
     if (rc) return rc;
-    return fav_batch_device(k.s, d_pks48, d_pk_off, n_pks_total, d_msgs32, nullptr, d_sigs96, n, eth_variant, d_status_out, *k.ar);
+    return fav_batch_device(k.s, d_pks48, d_pk_off, n_pks_total, d_msgs32, nullptr, d_sigs96, n, eth_variant, d_status_out, *k.ar, k.c->aux);
 }
 
 int ecgpu_fast_aggregate_verify(const uint8_t* pks48, uint32_t k, const uint8_t* msg, size_t msg_len, const uint8_t* sig96,
@@ -473,8 +499,7 @@ int ecgpu_aggregate_sigs(const uint8_t* sigs96, uint32_t n, uint8_t* out96) {
     if (!pts || !st_dec || !st_grp || !sum || !d_out) return ECGPU_ERR_OOM;
     hipLaunchKernelGGL(k_sig, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_sigs, n, pts, st_dec, st_grp);
     hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(64), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
-    hipLaunchKernelGGL(k_sum<Fp2>, dim3(1), dim3(BLS_BLOCK), 0, k.s, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, n, sum,
-                       (u8*)nullptr);
+    launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr);
     hipLaunchKernelGGL(k_compress_g2, dim3(1), dim3(64), 0, k.s, (const A2*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
     u8 h[97];
@@ -499,7 +524,7 @@ int ecgpu_aggregate_pks(const uint8_t* pks48, uint32_t n, uint8_t* out48) {
     u8* d_out = k.ar->take(48 + 1);
     if (!pts || !st || !sum || !d_out) return ECGPU_ERR_OOM;
     hipLaunchKernelGGL(k_pk_validate, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_pks, n, pts, st);
-    hipLaunchKernelGGL(k_sum<Fp>, dim3(1), dim3(BLS_BLOCK), 0, k.s, (const A1*)pts, (const u8*)st, (const u32*)nullptr, n, sum, d_out + 48);
+    launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48);
     hipLaunchKernelGGL(k_compress_g1, dim3(1), dim3(64), 0, k.s, (const A1*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
     u8 h[49];

@@ -7,8 +7,8 @@
 #define ECG_COUNT_OPS 1
 #include "ecgpu.h"
 #include "bls_verify.h"
-#include "bls_vm.h"
-#include "bls_vm_prog.h"
+#include <thread>
+
 #include "bls_vm2.h"
 #include "bls_vm2_prog.h"
 
@@ -250,33 +250,8 @@ void hs_op_census(const u8* pk48, const u8* msg, u64 msg_len, const u8* sig96, u
     snap(3);
 }
 
-// The lane-group pairing programs (tools/gen_bls_vm.py) executed with lock-step semantics on one tuple:
-// part A, the Fp inversion, part C.  Inputs/outputs canonical big-endian like hs_pairing.
-int hs_vm_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
-    std::vector<u32> RA((size_t)ECG_VM_A_NREG * 13, 0), RC((size_t)ECG_VM_C_NREG * 13, 0);
-    for (int c = 0; c < ECG_VM_A_NCONST; c++)
-        for (int i = 0; i < 13; i++) RA[(size_t)ECG_VM_A_CONST_REG[c] * 13 + i] = ECG_VM_A_CONST_VAL[c * 13 + i];
-    for (int c = 0; c < ECG_VM_C_NCONST; c++)
-        for (int i = 0; i < 13; i++) RC[(size_t)ECG_VM_C_CONST_REG[c] * 13 + i] = ECG_VM_C_CONST_VAL[c * 13 + i];
-    A1 p = in_a1(p_xy, 0);
-    A2 h = in_a2(h_xy, 0), sg = in_a2(s_xy, 0);
-    const Fp in[10] = {p.x, p.y, h.x.c0, h.x.c1, h.y.c0, h.y.c1, sg.x.c0, sg.x.c1, sg.y.c0, sg.y.c1};
-    for (int k = 0; k < 10; k++) vm_store(RA.data(), ECG_VM_A_IN[k], in[k]);
-    vm_run_serial(ECG_VM_A_PROG, ECG_VM_A_ROUNDS, ECG_VM_LANES, RA.data());
-    for (int k = 0; k < 12; k++) vm_store(RC.data(), ECG_VM_C_IN[k], vm_load(RA.data(), ECG_VM_A_OUT[k]));
-    vm_store(RC.data(), ECG_VM_C_IN[12], fp_inv(vm_load(RA.data(), ECG_VM_A_OUT[12])));
-    vm_run_serial(ECG_VM_C_PROG, ECG_VM_C_ROUNDS, ECG_VM_LANES, RC.data());
-    Fp12 e;
-    Fp2* c[6] = {&e.c0.c0, &e.c0.c1, &e.c0.c2, &e.c1.c0, &e.c1.c1, &e.c1.c2};
-    for (int k = 0; k < 6; k++) {
-        c[k]->c0 = vm_load(RC.data(), ECG_VM_C_OUT[2 * k]);
-        c[k]->c1 = vm_load(RC.data(), ECG_VM_C_OUT[2 * k + 1]);
-    }
-    out_fp12(e, out576);
-    return fp12_is_one(e) ? 1 : 0;
-}
-
-// The Fp2 lane-group programs (tools/gen_bls_vm2.py), same contract as hs_vm_pairing.
+// The Fp2 lane-group programs (tools/gen_bls_vm2.py) executed with lock-step semantics on one tuple: part A, the Fp
+// inversion, part C.  Inputs/outputs canonical big-endian like hs_pairing.
 int hs_vm2_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
     std::vector<u32> RA((size_t)ECG_VM2_A_NREG * 26, 0), RC((size_t)ECG_VM2_C_NREG * 26, 0);
     for (int c = 0; c < ECG_VM2_A_NCONST; c++)
@@ -308,6 +283,19 @@ void hs_census_read(u64* out) {
 
 int hs_fast_aggregate_verify(const u8* pks48, u32 k, const u8* msg, u64 msg_len, const u8* sig96, int eth) {
     return fav_tuple_serial(pks48, k, msg, (size_t)msg_len, sig96, eth != 0);
+}
+
+// n independent K = 1 tuples with 32-byte messages on `threads` host threads (bench.py's "device lane programs on the
+// host cores" line; the independent oracle is oracle/bls12_381.py)
+void hs_fav_batch_k1(const u8* pks48, const u8* msgs32, const u8* sigs96, u32 n, int threads, u8* status) {
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([=] {
+            for (u32 i = (u32)t; i < n; i += (u32)threads)
+                status[i] = fav_tuple_serial(pks48 + 48 * (size_t)i, 1, msgs32 + 32 * (size_t)i, 32, sigs96 + 96 * (size_t)i, false);
+        });
+    for (auto& x : th) x.join();
 }
 
 }  // extern "C"

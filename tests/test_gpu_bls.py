@@ -2,6 +2,7 @@
 (ethereum_consensus_amd.bls -> libecgpu.so) against oracle/bls12_381.py on the same inputs, the
 reference's own fixed vectors (crypto/bls.rs:530-544, bin/ec/validator/keystores.rs:240-249), and --
 at batch sizes the Python oracle cannot reach -- statuses known by construction of the batch."""
+import ctypes
 import hashlib
 import random
 
@@ -195,3 +196,101 @@ def test_batch_4096_with_fault_injection(gpu):
     clean = gpu.sk_to_pk_batch(skb[:32 * 64])
     assert gpu.fast_aggregate_verify_batch(clean[:48 * 63], [0, 63], m, agg) == bytes([B.BLST_VERIFY_FAIL])
     assert gpu.fast_aggregate_verify_batch(clean, [0, 64], m, agg) == b"\x00"
+
+
+def test_committee_aggregates_config4_shape(gpu):
+    """BASELINE.json configs[3] shape scaled to one GPU-second: committees of K keys drawn from a registry with each
+    validator in several committees, sig_c = (sum of the members' secret keys) * H(msg_c); one committee in eight
+    is corrupted (a wrong member key / a wrong message / an off-subgroup key in the MIDDLE of the list).  Statuses are
+    known by construction; two small committees are re-verified by the Python oracle."""
+    n_reg, n_comm = 2048, 24
+    ks = [2048, 512] + [256] * 20 + [8, 5]
+    sks = [1 + int.from_bytes(S(b"sk", i), "big") % (B.R - 1) for i in range(n_reg)]
+    reg = gpu.sk_to_pk_batch(b"".join(sk_bytes(s) for s in sks))
+    r = random.Random(77)
+    off_g1 = B.g1_compress(C.rand_g1_curve_point(r))
+    members, agg_sk, msgs = [], [], []
+    for c in range(n_comm):
+        idx = [(257 * c + 3 * j) % n_reg for j in range(ks[c])]
+        members.append(idx)
+        agg_sk.append(sum(sks[i] for i in idx) % B.R)
+        msgs.append(S(b"att", c))
+    sigs = gpu.sign_batch(b"".join(sk_bytes(s) for s in agg_sk), msgs)
+    pk_buf, offs, want = bytearray(), [0], bytearray(n_comm)
+    msgb = bytearray(b"".join(msgs))
+    for c in range(n_comm):
+        keys = [reg[48 * i:48 * i + 48] for i in members[c]]
+        if c % 8 == 1:  # one member replaced by a key that did not sign
+            keys[len(keys) // 2] = reg[48 * ((members[c][0] + 1) % n_reg):48 * ((members[c][0] + 1) % n_reg) + 48]
+            want[c] = B.BLST_VERIFY_FAIL
+        elif c % 8 == 3:  # wrong message
+            msgb[32 * c + 5] ^= 0x40
+            want[c] = B.BLST_VERIFY_FAIL
+        elif c % 8 == 5:  # a key outside G1 in the middle of the list: its decode error wins over everything later
+            keys[len(keys) // 3] = off_g1
+            want[c] = B.BLST_POINT_NOT_IN_GROUP
+        pk_buf += b"".join(keys)
+        offs.append(offs[-1] + len(keys))
+    got = gpu.fast_aggregate_verify_batch(bytes(pk_buf), offs, bytes(msgb), sigs)
+    assert got == bytes(want)
+    for c in (n_comm - 2, n_comm - 1):
+        keys = [bytes(pk_buf[48 * i:48 * i + 48]) for i in range(offs[c], offs[c + 1])]
+        assert B.fast_aggregate_verify(keys, bytes(msgb[32 * c:32 * c + 32]), sigs[96 * c:96 * c + 96]) == got[c]
+    # scalar entry on the largest committee == its batch status
+    c = 0
+    keys = [bytes(pk_buf[48 * i:48 * i + 48]) for i in range(offs[c], offs[c + 1])]
+    gpu.fast_aggregate_verify(keys, bytes(msgb[:32]), sigs[:96])
+
+
+def test_slot_pipeline_config5_shape(gpu):
+    """BASELINE.json configs[4] shape: per slot one eth_fast_aggregate_verify over the participating keys of a 512-key
+    sync committee (Bitvector<512> at ~95 %, altair/block_processing.rs:216-236) and one state root after mutating
+    balances, enqueued on two different HIP streams so that they overlap; both results must equal what the calls
+    produce one after the other."""
+    import torch
+    from ethereum_consensus_amd import _lib, ssz, synthetic
+    L = _lib.load(build_if_missing=False)
+    n_sc = 512
+    sks = [1 + int.from_bytes(S(b"sync", i), "big") % (B.R - 1) for i in range(n_sc)]
+    pks = gpu.sk_to_pk_batch(b"".join(sk_bytes(s) for s in sks))
+    dev = torch.device("cuda:0")
+    s_bls, s_mk = torch.cuda.Stream(), torch.cuda.Stream()
+    f = synthetic.state_fields(3000, "minimal", seed=5)
+    fixed = int(L.ecgpu_beacon_state_deneb_fixed_size(1))
+    r = random.Random(9)
+    for slot in range(4):
+        bits = [r.random() < 0.95 for _ in range(n_sc)]
+        if slot == 2:
+            bits = [False] * n_sc  # empty participation + infinity signature is valid for the eth_ variant (bls.rs:150-160)
+        part = [i for i in range(n_sc) if bits[i]]
+        msg = S(b"slot", slot)
+        if part:
+            sig = gpu.sign_batch(sk_bytes(sum(sks[i] for i in part) % B.R), [msg])
+        else:
+            sig = B.INFINITY_SIGNATURE
+        if slot == 3:
+            part = part[:-1]  # one participant missing: must fail
+        keys = b"".join(pks[48 * i:48 * i + 48] for i in part)
+        for k in range(64):  # the block's effect on the state: a few balances move
+            f["balances"][r.randrange(len(f["balances"]))] += 1 + k
+        enc = synthetic.serialize_state(f)
+        h_fixed = ctypes.create_string_buffer(enc[:fixed], fixed)
+        d_state = torch.frombuffer(bytearray(enc), dtype=torch.uint8).to(dev)
+        d_root = torch.zeros(32, dtype=torch.uint8, device=dev)
+        d_keys = torch.frombuffer(bytearray(keys) or bytearray(1), dtype=torch.uint8).to(dev)
+        d_off = torch.tensor([0, len(part)], dtype=torch.int32, device=dev)
+        d_msg = torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev)
+        d_sig = torch.frombuffer(bytearray(sig), dtype=torch.uint8).to(dev)
+        d_st = torch.full((1,), 0xFF, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        rc1 = L.ecgpu_fast_aggregate_verify_batch_dev(d_keys.data_ptr(), d_off.data_ptr(), len(part), d_msg.data_ptr(), d_sig.data_ptr(), 1, 1,
+                                                      d_st.data_ptr(), s_bls.cuda_stream)
+        rc2 = L.ecgpu_htr_beacon_state_deneb_dev(d_state.data_ptr(), len(enc), h_fixed, 1, d_root.data_ptr(), s_mk.cuda_stream)
+        assert rc1 == 0 and rc2 == 0, L.ecgpu_last_error()
+        torch.cuda.synchronize()
+        assert int(d_st.item()) == (B.BLST_VERIFY_FAIL if slot == 3 else 0)
+        assert bytes(d_root.cpu().numpy()) == ssz.hash_tree_root_beacon_state_deneb(enc, ssz.MINIMAL)
+        if slot == 0:
+            from oracle import ssz as ossz
+            from tests._statevalue import oracle_state_value
+            assert bytes(d_root.cpu().numpy()) == ossz.BeaconStateDeneb(ossz.MINIMAL).htr(oracle_state_value(f))

@@ -275,9 +275,9 @@ def test_fast_aggregate_verify_status_algebra():
         assert got == C.oracle_fav(pks, msg, sig, eth), (len(pks), eth)
 
 
-@pytest.mark.parametrize("entry", ["hs_vm_pairing", "hs_vm2_pairing"])
+@pytest.mark.parametrize("entry", ["hs_vm2_pairing"])
 def test_lane_group_vm_pairing_programs(entry):
-    """The generated lane-group programs (tools/gen_bls_vm.py, gen_bls_vm2.py) executed with the kernel's
+    """The generated lane-group programs (tools/gen_bls_vm2.py) executed with the kernel's
     lock-step semantics: e(P, H) e(-g1, S) after the final exponentiation, coefficient by coefficient."""
     r = random.Random(23)
     L = lib()

@@ -4,7 +4,7 @@ check for the gfx950 "Fp2 VM" kernels (csrc/bls_vm2.h, bls_vm2.hip).
 
 Why (measured, profiles/r01b_bls_occupancy_probe.txt, r01c): one lane per pairing keeps every Fp12
 temporary in the private segment and is bound by scratch traffic to HBM (92 ms / 65 536 checks);
-the first lane-group VM (Fp registers, one Fp operation per lane per round, tools/gen_bls_vm.py)
+the first lane-group VM (Fp registers, one Fp operation per lane per round, removed after r01e)
 removed the scratch but paid one LDS round trip + barrier per ~50-instruction addition round
 (110 ms).  This generator raises the unit of work to Fp2:
 
