@@ -62,6 +62,14 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_fast_aggregate_verify_batch": (c_int, [u8p, ctypes.c_void_p, u8p, u8p, c_u32, c_int, u8p]),
         "ecgpu_fast_aggregate_verify_batch_dev": (c_int, [u8p, ctypes.c_void_p, c_u32, u8p, u8p, c_u32, c_int, u8p,
                                                           ctypes.c_void_p]),
+        "ecgpu_registry_create": (c_int, [c_u64, ctypes.POINTER(ctypes.c_void_p)]),
+        "ecgpu_registry_destroy": (None, [ctypes.c_void_p]),
+        "ecgpu_registry_set": (c_int, [ctypes.c_void_p, c_u64, u8p, c_u64]),
+        "ecgpu_registry_set_dev": (c_int, [ctypes.c_void_p, c_u64, u8p, c_u64, ctypes.c_void_p]),
+        "ecgpu_fast_aggregate_verify_indexed_batch": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, u8p, u8p, c_u32, c_int,
+                                                              u8p]),
+        "ecgpu_fast_aggregate_verify_indexed_batch_dev": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_u32, u8p, u8p,
+                                                                  c_u32, c_int, u8p, ctypes.c_void_p]),
         "ecgpu_sk_to_pk_batch": (c_int, [u8p, c_u32, u8p]),
         "ecgpu_sign_batch": (c_int, [u8p, u8p, ctypes.c_void_p, c_u32, u8p]),
         "ecgpu_sk_to_pk_batch_dev": (c_int, [u8p, c_u32, u8p, ctypes.c_void_p]),

@@ -185,6 +185,49 @@ def fast_aggregate_verify_batch(public_keys: bytes, pk_offsets, msgs32: bytes, s
     return out.raw[:n]
 
 
+class ValidatorKeyRegistry:
+    """Device-resident result of `PublicKey -> blst key` (bls.rs:279-285) per validator index: the affine point, or
+    the BLSTError the conversion raises.  `fast_aggregate_verify_batch(indices...)` then returns exactly what the
+    reference returns for the same keys without decompressing them again.  `set` is the hook
+    for `add_validator_to_registry` (phase0/block_processing.rs:317-349)."""
+
+    def __init__(self, capacity: int):
+        self._L = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self._L.ecgpu_registry_create(capacity, ctypes.byref(h)), "ecgpu_registry_create")
+        self._h = h
+        self.capacity = capacity
+
+    def close(self):
+        if self._h:
+            self._L.ecgpu_registry_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set(self, first_index: int, public_keys: bytes) -> None:
+        if len(public_keys) % 48:
+            raise InvalidLength("48-byte keys expected")
+        _lib.check(self._L.ecgpu_registry_set(self._h, first_index, _buf(public_keys), len(public_keys) // 48), "ecgpu_registry_set")
+
+    def fast_aggregate_verify_batch(self, indices: Sequence[int], idx_offsets: Sequence[int], msgs32: bytes, signatures: bytes,
+                                    eth: bool = False) -> bytes:
+        n = len(signatures) // 96
+        if len(signatures) != 96 * n or len(msgs32) != 32 * n or len(idx_offsets) != n + 1 or idx_offsets[-1] != len(indices):
+            raise InvalidLength("n signatures, n messages, n+1 offsets ending at the index count")
+        idx = (ctypes.c_uint32 * max(len(indices), 1))(*indices)
+        off = (ctypes.c_uint32 * (n + 1))(*idx_offsets)
+        out = ctypes.create_string_buffer(max(n, 1))
+        _lib.check(self._L.ecgpu_fast_aggregate_verify_indexed_batch(self._h, idx, off, _buf(msgs32), _buf(signatures), n,
+                                                                     1 if eth else 0, out), "ecgpu_fast_aggregate_verify_indexed_batch")
+        return out.raw[:n]
+
+
 def sk_to_pk_batch(secret_keys32: bytes) -> bytes:
     """SecretKey::public_key (bls.rs:193-197) for n 32-byte big-endian secret keys."""
     L = _lib.load()

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pk_validate(const 
 // a few long ones (256 committees of 2048 keys on 64 lanes each would leave three quarters of the SIMDs idle).
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts, const u8* st, const u32* off, u32 n_total, Aff<F>* out,
-                                                            u8* out_st) {
+                                                            u8* out_st, const u32* idx, u32 idx_limit) {
     __shared__ Jac<F> sh[BLOCK];
     __shared__ u32 first_bad;
     const u32 t = blockIdx.x, tid = threadIdx.x;
@@ -57,13 +57,20 @@ __global__ void __launch_bounds__(BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts,
     __syncthreads();
     Jac<F> acc;
     jac_set_inf(acc);
+    // idx != nullptr: element i of the list is registry entry idx[i] (validated-key registry); an index past the
+    // registry is a caller error reported as BAD_ENCODING for that position
     for (u32 i = lo + tid; i < hi; i += BLOCK) {
-        if (st && st[i]) {
+        const u32 j = idx ? idx[i] : i;
+        if (idx && j >= idx_limit) {
             atomicMin(&first_bad, i);
             continue;
         }
-        if (!pts[i].inf) {
-            F x = pts[i].x, y = pts[i].y;
+        if (st && st[j]) {
+            atomicMin(&first_bad, i);
+            continue;
+        }
+        if (!pts[j].inf) {
+            F x = pts[j].x, y = pts[j].y;
             jac_add_aff(acc, acc, x, y);
         }
     }
@@ -81,7 +88,8 @@ __global__ void __launch_bounds__(BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts,
         Aff<F> r;
         u8 s = 0;
         if (first_bad != 0xffffffffu) {
-            s = st[first_bad];
+            const u32 jb = idx ? idx[first_bad] : first_bad;
+            s = (idx && jb >= idx_limit) ? (u8)ECGPU_BAD_ENCODING : st[jb];
             f_set_zero(r.x);
             f_set_zero(r.y);
             r.inf = 1;
@@ -93,12 +101,13 @@ __global__ void __launch_bounds__(BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts,
     }
 }
 template <class F>
-static void launch_sum(hipStream_t s, u32 n_tuples, u32 n_pts, const Aff<F>* pts, const u8* st, const u32* off, Aff<F>* out, u8* out_st) {
+static void launch_sum(hipStream_t s, u32 n_tuples, u32 n_pts, const Aff<F>* pts, const u8* st, const u32* off, Aff<F>* out, u8* out_st,
+                       const u32* idx = nullptr, u32 idx_limit = 0) {
     const bool wide = (u64)n_pts >= 512ull * n_tuples && n_tuples < 4096;
     if (wide)
-        hipLaunchKernelGGL((k_sum<F, 256>), dim3(n_tuples), dim3(256), 0, s, pts, st, off, n_pts, out, out_st);
+        hipLaunchKernelGGL((k_sum<F, 256>), dim3(n_tuples), dim3(256), 0, s, pts, st, off, n_pts, out, out_st, idx, idx_limit);
     else
-        hipLaunchKernelGGL((k_sum<F, 64>), dim3(n_tuples), dim3(64), 0, s, pts, st, off, n_pts, out, out_st);
+        hipLaunchKernelGGL((k_sum<F, 64>), dim3(n_tuples), dim3(64), 0, s, pts, st, off, n_pts, out, out_st, idx, idx_limit);
 }
 
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sig(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp) {
@@ -287,12 +296,23 @@ static const u32 g_vm2_max_tuples = [] {
     return e ? (u32)strtoul(e, nullptr, 10) : 12288u;
 }();
 
-// all pointers device-resident; ws from the caller's arena
+}  // namespace ecg
+// validated-key registry (include/ecgpu.h): per validator index the affine key or the status its conversion raises
+struct ecgpu_registry {
+    ecg::A1* pts = nullptr;
+    u8* st = nullptr;
+    uint64_t capacity = 0;
+};
+namespace ecg {
+
+// all pointers device-resident; ws from the caller's arena.  reg != nullptr: d_pks48 is unused, the key list of
+// tuple i is registry[d_idx[d_pk_off[i] .. d_pk_off[i+1])] and no key is decompressed here.
 static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_off, u32 n_pks, const u8* d_msgs, const u64* d_msg_off,
-                            const u8* d_sigs96, u32 n, int eth_variant, u8* d_status, Arena& ar, AuxStreams& ax) {
+                            const u8* d_sigs96, u32 n, int eth_variant, u8* d_status, Arena& ar, AuxStreams& ax,
+                            const ecgpu_registry* reg = nullptr, const u32* d_idx = nullptr) {
     if (n == 0) return ECGPU_SUCCESS;
-    A1* pts = (A1*)ar.take((size_t)(n_pks ? n_pks : 1) * sizeof(A1));
-    u8* st = ar.take(n_pks ? n_pks : 1);
+    A1* pts = reg ? reg->pts : (A1*)ar.take((size_t)(n_pks ? n_pks : 1) * sizeof(A1));
+    u8* st = reg ? reg->st : ar.take(n_pks ? n_pks : 1);
     A2* sigpts = (A2*)ar.take((size_t)n * sizeof(A2));
     A2* hpts = (A2*)ar.take((size_t)n * sizeof(A2));
     u8* st_dec = ar.take(n);
@@ -307,7 +327,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     if (!pts || !st || !sigpts || !hpts || !st_dec || !st_grp) return ECGPU_ERR_OOM;
     // Key-heavy batches (committees): the signature and message stages do not depend on the keys, so they run on an
     // auxiliary stream underneath the key validation + aggregation and join before the pairing check.
-    const bool fork = d_pk_off && n_pks >= 4ull * n;
+    const bool fork = d_pk_off && !reg && n_pks >= 4ull * n;
     hipStream_t s2 = s;
     if (fork) {
         int rc = ax.init();
@@ -316,13 +336,13 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
         ECG_HIP_CHECK(hipStreamWaitEvent(s2, ax.fork, 0));
     }
-    if (n_pks) {
+    if (n_pks && !reg) {
         ProfScope ps("bls_pk_validate", s);
         hipLaunchKernelGGL(k_pk_validate, grid_for(n_pks), dim3(BLS_BLOCK), 0, s, d_pks48, n_pks, pts, st);
     }
     if (d_pk_off) {
         ProfScope ps("bls_pk_aggregate", s);
-        launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk);
+        launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
     }
     {
         ProfScope ps("bls_sig", s2);
@@ -425,6 +445,92 @@ int ecgpu_fast_aggregate_verify_batch_dev(const uint8_t* d_pks48, const uint32_t
     int rc = begin_call(k, stream, fav_ws_bytes(n, n_pks_total));
     if (rc) return rc;
     return fav_batch_device(k.s, d_pks48, d_pk_off, n_pks_total, d_msgs32, nullptr, d_sigs96, n, eth_variant, d_status_out, *k.ar, k.c->aux);
+}
+
+int ecgpu_registry_create(uint64_t capacity, ecgpu_registry_t** out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!out || capacity == 0 || capacity > 0xffffffffull) return ECGPU_ERR_BAD_ARG;
+    ecgpu_registry* r = new ecgpu_registry();
+    r->capacity = capacity;
+    ECG_HIP_CHECK(hipMalloc((void**)&r->pts, capacity * sizeof(A1)));
+    ECG_HIP_CHECK(hipMalloc((void**)&r->st, capacity));
+    // an index never set behaves like an undecodable key
+    ECG_HIP_CHECK(hipMemset(r->st, ECGPU_BAD_ENCODING, capacity));
+    *out = r;
+    return ECGPU_SUCCESS;
+}
+
+void ecgpu_registry_destroy(ecgpu_registry_t* reg) {
+    if (!reg) return;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(reg->pts);
+    (void)hipFree(reg->st);
+    delete reg;
+}
+
+int ecgpu_registry_set_dev(ecgpu_registry_t* reg, uint64_t first_index, const uint8_t* d_pks48, uint64_t n, ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!reg || first_index + n > reg->capacity || (n && !d_pks48)) return ECGPU_ERR_BAD_ARG;
+    if (!n) return ECGPU_SUCCESS;
+    hipStream_t s = tctx()->stream_or_own(stream);
+    ProfScope ps("bls_pk_validate", s);
+    hipLaunchKernelGGL(k_pk_validate, grid_for((u32)n), dim3(BLS_BLOCK), 0, s, d_pks48, (u32)n, reg->pts + first_index, reg->st + first_index);
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
+int ecgpu_registry_set(ecgpu_registry_t* reg, uint64_t first_index, const uint8_t* pks48, uint64_t n) {
+    if (!reg || first_index + n > reg->capacity || (n && !pks48)) return ECGPU_ERR_BAD_ARG;
+    if (!n) return ECGPU_SUCCESS;
+    CallCtx k;
+    int rc = begin_call(k, nullptr, (size_t)n * 48 + 4096);
+    if (rc) return rc;
+    u8* d_pks;
+    if ((rc = h2d(k, d_pks, pks48, (size_t)n * 48))) return rc;
+    rc = ecgpu_registry_set_dev(reg, first_index, d_pks, n, k.s);
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipStreamSynchronize(k.s));
+    return ECGPU_SUCCESS;
+}
+
+int ecgpu_fast_aggregate_verify_indexed_batch_dev(const ecgpu_registry_t* reg, const uint32_t* d_indices, const uint32_t* d_idx_off,
+                                                  uint32_t n_indices_total, const uint8_t* d_msgs32, const uint8_t* d_sigs96, uint32_t n,
+                                                  int eth_variant, uint8_t* d_status_out, ecgpu_stream_t stream) {
+    if (!reg || (n && (!d_idx_off || !d_msgs32 || !d_sigs96 || !d_status_out)) || (n_indices_total && !d_indices)) return ECGPU_ERR_BAD_ARG;
+    CallCtx k;
+    int rc = begin_call(k, stream, fav_ws_bytes(n, 0));
+    if (rc) return rc;
+    return fav_batch_device(k.s, nullptr, d_idx_off, n_indices_total, d_msgs32, nullptr, d_sigs96, n, eth_variant, d_status_out, *k.ar,
+                            k.c->aux, reg, d_indices);
+}
+
+int ecgpu_fast_aggregate_verify_indexed_batch(const ecgpu_registry_t* reg, const uint32_t* indices, const uint32_t* idx_off,
+                                              const uint8_t* msgs32, const uint8_t* sigs96, uint32_t n, int eth_variant,
+                                              uint8_t* status_out) {
+    if (!reg || (n && (!idx_off || !msgs32 || !sigs96 || !status_out))) return ECGPU_ERR_BAD_ARG;
+    if (n == 0) return ECGPU_SUCCESS;
+    for (u32 i = 0; i < n; i++)
+        if (idx_off[i + 1] < idx_off[i]) return ECGPU_ERR_BAD_ARG;
+    const u32 n_idx = idx_off[n];
+    if (n_idx && !indices) return ECGPU_ERR_BAD_ARG;
+    CallCtx k;
+    int rc = begin_call(k, nullptr, fav_ws_bytes(n, 0) + (size_t)n_idx * 4 + (size_t)n * (32 + 96 + 1 + 4) + 8192);
+    if (rc) return rc;
+    u8 *d_idx, *d_off, *d_msgs, *d_sigs;
+    if ((rc = h2d(k, d_idx, indices, (size_t)n_idx * 4))) return rc;
+    if ((rc = h2d(k, d_off, idx_off, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = h2d(k, d_msgs, msgs32, (size_t)n * 32))) return rc;
+    if ((rc = h2d(k, d_sigs, sigs96, (size_t)n * 96))) return rc;
+    u8* d_status = k.ar->take(n);
+    if (!d_status) return ECGPU_ERR_OOM;
+    rc = fav_batch_device(k.s, nullptr, (const u32*)d_off, n_idx, d_msgs, nullptr, d_sigs, n, eth_variant, d_status, *k.ar, k.c->aux, reg,
+                          (const u32*)d_idx);
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipMemcpyAsync(status_out, d_status, n, hipMemcpyDeviceToHost, k.s));
+    ECG_HIP_CHECK(hipStreamSynchronize(k.s));
+    return ECGPU_SUCCESS;
 }
 
 int ecgpu_fast_aggregate_verify(const uint8_t* pks48, uint32_t k, const uint8_t* msg, size_t msg_len, const uint8_t* sig96,

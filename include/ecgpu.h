@@ -123,6 +123,30 @@ int ecgpu_fast_aggregate_verify_batch_dev(const uint8_t* d_pks48, const uint32_t
                                           const uint8_t* d_sigs96, uint32_t n, int eth_variant,
                                           uint8_t* d_status_out, ecgpu_stream_t stream);
 
+/* Validated-key registry.  The reference decompresses and subgroup-checks every public key
+ * on every call (`TryFrom<&PublicKey>`, crypto/bls.rs:279-285, reached from :122 for each key gathered out of
+ * `state.validators` at phase0/helpers.rs:123-131): > 95 % of the work of a 2 048-key committee.  A registry keeps
+ * the RESULT of that conversion per validator index on the device -- the affine point, or the BLST_ERROR the
+ * conversion would raise -- so that an indexed verify returns exactly what the reference call over the same keys
+ * returns.  `set` is the invalidation hook (`add_validator_to_registry`, phase0/block_processing.rs:317-349);
+ * it must not run concurrently with a verify on the same registry.  Handles are process-wide. */
+typedef struct ecgpu_registry ecgpu_registry_t;
+int ecgpu_registry_create(uint64_t capacity, ecgpu_registry_t** out);
+void ecgpu_registry_destroy(ecgpu_registry_t* reg);
+/* keys first_index .. first_index + n: decompress + validate on the GPU, store point or error */
+int ecgpu_registry_set(ecgpu_registry_t* reg, uint64_t first_index, const uint8_t* pks48, uint64_t n);
+int ecgpu_registry_set_dev(ecgpu_registry_t* reg, uint64_t first_index, const uint8_t* d_pks48, uint64_t n,
+                           ecgpu_stream_t stream);
+/* ecgpu_fast_aggregate_verify_batch with tuple i's keys = registry[indices[idx_off[i] .. idx_off[i+1])] */
+int ecgpu_fast_aggregate_verify_indexed_batch(const ecgpu_registry_t* reg, const uint32_t* indices,
+                                              const uint32_t* idx_off, const uint8_t* msgs32,
+                                              const uint8_t* sigs96, uint32_t n, int eth_variant,
+                                              uint8_t* status_out);
+int ecgpu_fast_aggregate_verify_indexed_batch_dev(const ecgpu_registry_t* reg, const uint32_t* d_indices,
+                                                  const uint32_t* d_idx_off, uint32_t n_indices_total,
+                                                  const uint8_t* d_msgs32, const uint8_t* d_sigs96, uint32_t n,
+                                                  int eth_variant, uint8_t* d_status_out, ecgpu_stream_t stream);
+
 /* SecretKey side, used to generate workloads and test vectors on the device:
  * SecretKey::public_key (crypto/bls.rs:193-197) and SecretKey::sign (:213-219).  sk = 32 big-endian
  * bytes, taken as given (pass sk < r).  msg_off == NULL: 32-byte messages at msgs + 32 i.

@@ -294,3 +294,43 @@ def test_slot_pipeline_config5_shape(gpu):
             from oracle import ssz as ossz
             from tests._statevalue import oracle_state_value
             assert bytes(d_root.cpu().numpy()) == ossz.BeaconStateDeneb(ossz.MINIMAL).htr(oracle_state_value(f))
+
+
+def test_validated_key_registry_matches_the_uncached_path(gpu):
+    """the registry stores, per validator index, what `PublicKey -> blst key` yields (point or
+    BLSTError).  Indexed verification must return byte for byte what the uncached batch returns for the same keys --
+    including which error wins when a bad key sits in the list, repeated members, the empty list and the eth_ variant."""
+    n_reg = 600
+    r = random.Random(5)
+    sks = [1 + int.from_bytes(S(b"reg", i), "big") % (B.R - 1) for i in range(n_reg)]
+    keys = [gpu.sk_to_pk_batch(sk_bytes(s)) for s in sks[:8]]
+    reg_keys = bytearray(gpu.sk_to_pk_batch(b"".join(sk_bytes(s) for s in sks)))
+    assert bytes(reg_keys[:48 * 8]) == b"".join(keys)
+    bad = {17: B.g1_compress(C.rand_g1_curve_point(r)), 23: B.INFINITY_PUBLIC_KEY, 40: bytes(48), 41: bytes([0x9F]) + b"\xff" * 47}
+    for i, k in bad.items():
+        reg_keys[48 * i:48 * i + 48] = k
+    reg = gpu.ValidatorKeyRegistry(n_reg + 8)  # the last 8 slots are never set
+    reg.set(0, bytes(reg_keys[:48 * 300]))
+    reg.set(300, bytes(reg_keys[48 * 300:]))
+    lists = [list(range(50, 50 + 128)), [3, 3, 3, 9], [5], [], list(range(10, 30)), [23, 17], [17, 23], [40, 41, 7], [1, 2, n_reg + 2],
+             [r.randrange(n_reg) for _ in range(300)], list(range(100, 100 + 64))]
+    msgs = [S(b"regmsg", c) for c in range(len(lists))]
+    agg = [sum(sks[i] for i in l if i < n_reg) % B.R for l in lists]
+    sigs = bytearray(gpu.sign_batch(b"".join(sk_bytes(a if a else 1) for a in agg), msgs))
+    sigs[96 * 3:96 * 4] = B.INFINITY_SIGNATURE  # empty list + infinity signature
+    msgb = bytearray(b"".join(msgs))
+    msgb[32 * 10] ^= 1  # last committee: wrong message
+    idx, off = [], [0]
+    for l in lists:
+        idx += l
+        off.append(len(idx))
+    for eth in (False, True):
+        got = reg.fast_aggregate_verify_batch(idx, off, bytes(msgb), bytes(sigs), eth=eth)
+        # the uncached path over the same key bytes (slot n_reg + 2 was never set: reported as an undecodable key)
+        pk_buf = b"".join(bytes(reg_keys[48 * i:48 * i + 48]) if i < n_reg else bytes(48) for i in idx)
+        want = gpu.fast_aggregate_verify_batch(pk_buf, off, bytes(msgb), bytes(sigs), eth=eth)
+        assert got == want, (eth, got.hex(), want.hex())
+        assert got[0] == 0 and got[1] == 0 and got[2] == 0 and got[10] == B.BLST_VERIFY_FAIL
+        assert got[3] == (0 if eth else B.BLST_AGGR_TYPE_MISMATCH)
+        assert got[5] == B.BLST_PK_IS_INFINITY and got[6] == B.BLST_POINT_NOT_IN_GROUP and got[7] == B.BLST_BAD_ENCODING
+    reg.close()
