@@ -40,7 +40,8 @@ def pmc_traffic(kernel_key: str):
     if not rec:
         return None
     return {"bytes_per_launch": int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024), "fetch_size_kib": rec["fetch_kib"],
-            "write_size_kib": rec["write_kib"], "source": rec.get("source"), "note": "separate rocprofv3 --pmc passes; FETCH_SIZE doubled (gfx950)"}
+            "write_size_kib": rec["write_kib"], "source": rec.get("source"),
+            "note": "separate rocprofv3 --pmc passes, summed over the kernel's launches of one step; FETCH_SIZE doubled (gfx950)"}
 
 
 def parse():
@@ -118,8 +119,8 @@ def run_merkle(args, L, torch, dist, rank, world):
     nl = ctypes.c_uint64(0)
     L.ecgpu_prof_read(dom, ctypes.byref(ms), ctypes.byref(nl))
     L.ecgpu_prof_enable(0)
-    kern_ms = ms.value / max(nl.value, 1)
-    # algorithmic bytes of the dominant kernel per launch: 121 B read per validator + one
+    kern_ms = ms.value / max(args.steps, 1)  # per state: the pass is issued as two half-range launches
+    # algorithmic bytes of the dominant kernel per state: 121 B read per validator + one
     # 32-byte node written per lane (2^D validators per lane, D from the schedule)
     lanes = n >> max(1, min(6, n.bit_length() - 1 - 18))
     alg_bytes = 121 * n + 32 * lanes
@@ -134,6 +135,7 @@ def run_merkle(args, L, torch, dist, rank, world):
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                   "traffic": pmc_traffic("k_merkle_pass<2, ValidatorLeaves>"),
                   "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches_timed": int(nl.value),
+                  "launch_note": "per state root: the validator pass goes out as two half-range launches; bytes and ms are their sum",
                   "valu_int": {"unit": "G hash64/s", "achieved": val_hashes / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0,
                                "peak": HASH64_PEAK_GHS,
                                "frac": (val_hashes / (kern_ms * 1e-3) / 1e9 / HASH64_PEAK_GHS) if kern_ms else 0.0,
@@ -148,7 +150,7 @@ R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 # Fp products of ONE K = 1 verification, counted on the lane programs themselves
 # (tests/hostsim hs_op_census, valid tuple): (fp_mul, fp_sqr) per stage.  A product is 351 (273 for
 # a square) quarter-rate integer multiplies (v_mad_u64_u32 / v_mul_lo_u32), see csrc/bls_fp.h.
-BLS_OPS = {"bls_pk_validate": (485, 1064), "bls_sig": (1583, 1133), "bls_h2c": (3896, 3414), "bls_pairing": (19643, 382)}
+BLS_OPS = {"bls_pk_validate": (485, 1064), "bls_sig": (1476, 756), "bls_h2c": (3838, 3163), "bls_pairing": (19643, 382)}
 BLS_BYTES_PER_SIG = 48 + 32 + 96 + 1  # K = 1 tuple in, status byte out
 
 

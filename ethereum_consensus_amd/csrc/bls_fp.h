@@ -392,9 +392,23 @@ ECG_HD Fp2 fp2_inv(const Fp2& a) {
     return Fp2{fp_mul(a.c0, d), fp_neg(fp_mul(a.c1, d))};
 }
 
-// Square root in Fp2 by the norm ("complex") method; true iff a is a square.  Any root.
-// 2 or 3 Fp exponentiations: sqrt(norm), then a^((p-3)/4) of the real candidate gives both its
-// root and the inverse needed for the imaginary part.
+// Square root in Fp2 by the norm ("complex") method, given s with s^2 = norm(a) = a0^2 + a1^2 and a1 != 0.
+// ONE Fp exponentiation: with d = (a0 + s)/2, t = d^((p-3)/4) and c = t d, either c^2 = d (then x0 = c, 1/x0 = t) or
+// c^2 = -d -- and then the OTHER candidate (a0 - s)/2 = a1^2 / (4 c^2) is the square, with root a1 / (2c) = -a1 t / 2
+// (c t = d^((p-1)/2) = -1) and imaginary part a1 / (2 x0) = c.  No second exponentiation, no data-dependent branch
+// around one: the lanes of a wave stay together.  Any root; false if r^2 != a.
+ECG_HD bool fp2_sqrt_with_norm_root(const Fp2& a, const Fp& s, Fp2& r) {
+    const Fp d = fp_mul(fp_add(a.c0, s), blsc::INV2);
+    const Fp t = fp_pow(d, blsc::EXP_PM3D4);
+    const Fp c = fp_mul(t, d);
+    const Fp ha1t = fp_mul(fp_mul(a.c1, blsc::INV2), t);  // a1 t / 2
+    const bool first = fp_eq(fp_sqr(c), d);
+    r.c0 = first ? c : fp_neg(ha1t);
+    r.c1 = first ? ha1t : c;
+    return fp2_eq(fp2_sqr(r), a);
+}
+
+// Square root in Fp2; true iff a is a square.  Any root.  Two Fp exponentiations (norm root, then the above).
 ECG_HD_NOINLINE bool fp2_sqrt(Fp2 a, Fp2& r) {
     if (fp_is_zero(a.c1)) {
         Fp s;
@@ -410,16 +424,7 @@ ECG_HD_NOINLINE bool fp2_sqrt(Fp2 a, Fp2& r) {
     Fp n = fp_add(fp_sqr(a.c0), fp_sqr(a.c1));
     Fp s;
     if (!fp_sqrt(n, s)) return false;
-    Fp d = fp_mul(fp_add(a.c0, s), blsc::INV2);
-    Fp x0, ix0;
-    if (!fp_sqrt_inv(d, x0, ix0)) {
-        d = fp_mul(fp_sub(a.c0, s), blsc::INV2);
-        if (!fp_sqrt_inv(d, x0, ix0)) return false;
-    }
-    // x1 = a1 / (2 x0)
-    Fp x1 = fp_mul(fp_mul(a.c1, blsc::INV2), ix0);
-    r = Fp2{x0, x1};
-    return fp2_eq(fp2_sqr(r), a);
+    return fp2_sqrt_with_norm_root(a, s, r);
 }
 
 // RFC 9380 sgn0 (m = 2) and the ZCash sign of an Fp2 (compare c1 first, then c0)

@@ -111,11 +111,32 @@ ECG_HD_NOINLINE void map_to_curve_g2(J2& r, const Fp2& u) {
         x1 = fp2_mulx(blsc::SSWU_MB_OVER_A, fp2_add(fp2_one(), fp2_inv(tv2)));
     }
     Fp2 gx1 = fp2_add(fp2_add(fp2_mulx(fp2_sqrx(x1), x1), fp2_mulx(blsc::SSWU_A, x1)), blsc::SSWU_B);
-    Fp2 x = x1, y;
-    if (!fp2_sqrt(gx1, y)) {
-        x = fp2_mulx(tv1, x1);
-        Fp2 gx2 = fp2_add(fp2_add(fp2_mulx(fp2_sqrx(x), x), fp2_mulx(blsc::SSWU_A, x)), blsc::SSWU_B);
-        (void)fp2_sqrt(gx2, y);  // exactly one of gx1, gx2 is a square
+    // Exactly one of gx1, gx2 = g(Z u^2 x1) = (Z u^2)^3 gx1 is a square.  Decide on the NORM of gx1 (one Fp
+    // exponentiation, which is also the norm root a square gx1 needs), derive the norm root of gx2 from it when gx1 is
+    // not a square -- norm(gx2) = m^3 n1 with m = norm(Z u^2); n1 and m are then both non-residues, s^2 = -n1,
+    // v = m^((p+1)/4) has v^2 = -m, so (m s v)^2 = m^3 n1 -- and take ONE Fp2 root of the chosen value.  Every lane
+    // of a wave runs the same 3 exponentiations (+1 for the lanes on gx2) instead of up to 6 on divergent paths.
+    const Fp2 x2 = fp2_mulx(tv1, x1);
+    const Fp2 gx2 = fp2_add(fp2_add(fp2_mulx(fp2_sqrx(x2), x2), fp2_mulx(blsc::SSWU_A, x2)), blsc::SSWU_B);
+    const Fp n1 = fp_add(fp_sqr(gx1.c0), fp_sqr(gx1.c1));
+    Fp sn;
+    const bool sq1 = fp_sqrt(n1, sn);  // sn = n1^((p+1)/4) either way
+    if (!sq1) {
+        const Fp m = fp_add(fp_sqr(tv1.c0), fp_sqr(tv1.c1));
+        Fp v;
+        (void)fp_sqrt(m, v);
+        sn = fp_mul(fp_mul(m, sn), v);
+    }
+    Fp2 x = sq1 ? x1 : x2, y;
+    const Fp2 g = sq1 ? gx1 : gx2;
+    bool ok = !fp_is_zero(g.c1) && fp2_sqrt_with_norm_root(g, sn, y);
+    if (!ok) {
+        // real g (a1 = 0) or an input outside the theorem's assumptions: the general routine decides
+        x = x1;
+        if (!fp2_sqrt(gx1, y)) {
+            x = x2;
+            (void)fp2_sqrt(gx2, y);
+        }
     }
     if (fp2_sgn0(u) != fp2_sgn0(y)) y = fp2_neg(y);
     // iso3: x' = xn/xd, y' = y yn/yd  ->  Jacobian with Z = xd yd

@@ -42,8 +42,8 @@ constexpr int PASS_BLOCK = 256;  // 4 waves; one lane = one output node
 // tiles at a time (each tile is read once: nothing to share across L2s).
 template <int D, class Leaf>
 __global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass(Leaf leaf, u64 n_in, u64 n_out, u8* out,
-                                                            const ZeroTable* zt, int level0) {
-    u64 gid = (u64)blockIdx.x * PASS_BLOCK + threadIdx.x;
+                                                            const ZeroTable* zt, int level0, u64 gid0) {
+    u64 gid = gid0 + (u64)blockIdx.x * PASS_BLOCK + threadIdx.x;
     if (gid >= n_out) return;
     lane_pass<D, Leaf>(leaf, gid, n_in, out, zt, level0);
 }
@@ -203,19 +203,23 @@ size_t merkle_ws_bytes(u64 n0) {
 }
 
 template <class Leaf>
+// output nodes [gid0, gid1) of the pass (the whole pass: 0, n_out)
 static int launch_pass(hipStream_t s, int D, const Leaf& leaf, u64 n_in, u64 n_out, u8* out, int level0,
-                       const char* tag) {
-    dim3 grid((unsigned)((n_out + PASS_BLOCK - 1) / PASS_BLOCK)), block(PASS_BLOCK);
+                       const char* tag, u64 gid0 = 0, u64 gid1 = ~0ull) {
+    if (gid1 > n_out) gid1 = n_out;
+    if (gid1 <= gid0) return ECGPU_SUCCESS;
+    n_out = gid1;
+    dim3 grid((unsigned)((gid1 - gid0 + PASS_BLOCK - 1) / PASS_BLOCK)), block(PASS_BLOCK);
     const ZeroTable* zt = device_zero_table();
     ProfScope ps(tag, s);
     switch (D) {
-        case 0: hipLaunchKernelGGL((k_merkle_pass<0, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
-        case 1: hipLaunchKernelGGL((k_merkle_pass<1, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
-        case 2: hipLaunchKernelGGL((k_merkle_pass<2, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
-        case 3: hipLaunchKernelGGL((k_merkle_pass<3, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
-        case 4: hipLaunchKernelGGL((k_merkle_pass<4, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
-        case 5: hipLaunchKernelGGL((k_merkle_pass<5, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
-        default: hipLaunchKernelGGL((k_merkle_pass<6, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0); break;
+        case 0: hipLaunchKernelGGL((k_merkle_pass<0, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;
+        case 1: hipLaunchKernelGGL((k_merkle_pass<1, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;
+        case 2: hipLaunchKernelGGL((k_merkle_pass<2, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;
+        case 3: hipLaunchKernelGGL((k_merkle_pass<3, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;
+        case 4: hipLaunchKernelGGL((k_merkle_pass<4, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;
+        case 5: hipLaunchKernelGGL((k_merkle_pass<5, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;
+        default: hipLaunchKernelGGL((k_merkle_pass<6, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;
     }
     ECG_HIP_CHECK(hipGetLastError());
     return ECGPU_SUCCESS;
@@ -239,7 +243,8 @@ int launch_tiles(hipStream_t s, const TileDesc* d_descs, u32 n_desc, u32 n_wg) {
 }
 
 int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes, u64 n0, u32 depth, bool mix,
-                     u64 mix_len, u8* d_out, u8* ws, u64* hash_count, TreeJob* deferred, const u8* job_base, bool background) {
+                     u64 mix_len, u8* d_out, u8* ws, u64* hash_count, TreeJob* deferred, const u8* job_base, bool background,
+                     hipEvent_t after_wide_passes) {
     if (depth > 64) {
         set_last_error("limit too large");
         return ECGPU_ERR_BAD_ARG;
@@ -257,12 +262,24 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
         u8* out = (cur == bufA) ? bufB : bufA;
         int rc;
         if (p.first) {
-            switch (kind) {
-                case LEAF_CHUNKS: rc = launch_pass(s, p.D, ChunkLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_chunks"); break;
-                case LEAF_VALIDATORS: rc = launch_pass(s, p.D, ValidatorLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_validators"); break;
-                case LEAF_BYTES48: rc = launch_pass(s, p.D, Bytes48Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_bytes48"); break;
-                case LEAF_PAIR64: rc = launch_pass(s, p.D, Pair64Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_pair64"); break;
-                default: rc = launch_pass(s, p.D, Eth1DataLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_eth1data"); break;
+            // with an `after_wide_passes` event the chip-filling leaf pass goes out in two halves and the event sits
+            // between them, so that whatever waits for it overlaps the second half and the tree's tail
+            const bool split = after_wide_passes && p.n_out >= (1u << 17);
+            const u64 cuts[3] = {0, split ? ((p.n_out / 2 + PASS_BLOCK - 1) / PASS_BLOCK) * PASS_BLOCK : p.n_out, p.n_out};
+            rc = ECGPU_SUCCESS;
+            for (int h = 0; h < 2 && !rc; h++) {
+                const u64 g0 = cuts[h], g1 = cuts[h + 1];
+                switch (kind) {
+                    case LEAF_CHUNKS: rc = launch_pass(s, p.D, ChunkLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_chunks", g0, g1); break;
+                    case LEAF_VALIDATORS: rc = launch_pass(s, p.D, ValidatorLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_validators", g0, g1); break;
+                    case LEAF_BYTES48: rc = launch_pass(s, p.D, Bytes48Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_bytes48", g0, g1); break;
+                    case LEAF_PAIR64: rc = launch_pass(s, p.D, Pair64Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_pair64", g0, g1); break;
+                    default: rc = launch_pass(s, p.D, Eth1DataLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_eth1data", g0, g1); break;
+                }
+                if (h == 0 && after_wide_passes && !rc) {
+                    ECG_HIP_CHECK(hipEventRecord(after_wide_passes, s));
+                    after_wide_passes = nullptr;
+                }
             }
         } else {
             rc = launch_pass(s, p.D, NodeLeaves{cur}, p.n_in, p.n_out, out, (int)p.level_in, "merkle_pass_nodes");
@@ -270,8 +287,9 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
         if (rc) return rc;
         cur = out;
     }
+    if (after_wide_passes) ECG_HIP_CHECK(hipEventRecord(after_wide_passes, s));
     if (sc.tile) {
-        // one workgroup per 1024 nodes; the descriptor rides in the unused tail of the workspace
+        // one workgroup per 1024 nodes
         u8* out = (cur == bufA) ? bufB : bufA;
         TileDesc td;
         td.in = sc.tile_first ? d_in : cur;

@@ -25,10 +25,11 @@ size_t merkle_ws_bytes(u64 n0);
 // `ws` must provide merkle_ws_bytes(n0).  Adds the number of hash64 performed to *hash_count.
 // With `deferred` set, the finishing job (<= 512 nodes -> root) is NOT launched: it is returned with offsets
 // relative to `job_base` so that the caller can batch it with others (launch_tree_jobs); `background`
-// selects the fewer-launches pass schedule (state_plan.h).
+// selects the fewer-launches pass schedule (state_plan.h); `after_wide_passes` is recorded on `s` once the wide
+// (chip-filling) passes are enqueued, i.e. where the tree's latency-bound tail begins.
 int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes, u64 n0, u32 depth,
                      bool mix, u64 mix_len, u8* d_out, u8* ws, u64* hash_count, TreeJob* deferred = nullptr,
-                     const u8* job_base = nullptr, bool background = false);
+                     const u8* job_base = nullptr, bool background = false, hipEvent_t after_wide_passes = nullptr);
 
 // Batched small trees: jobs live in device memory at d_jobs.
 int launch_tree_jobs(hipStream_t s, const TreeJob* d_jobs, u32 n_jobs, u8* d_buf);

@@ -49,19 +49,21 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     AuxStreams& ax = c->aux;
     rc = ax.init();
     if (rc) return rc;
-    ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
-    for (int i = 0; i < 2; i++) ECG_HIP_CHECK(hipStreamWaitEvent(ax.st[i], ax.fork, 0));
     size_t biggest = 0;
     for (size_t i = 1; i < plan.bigs.size(); i++)
         if (plan.bigs[i].bytes > plan.bigs[biggest].bytes) biggest = i;
     std::vector<u8*> wss(plan.bigs.size());
     for (size_t i = 0; i < plan.bigs.size(); i++) wss[i] = ar.take(merkle_ws_bytes(plan.bigs[i].n0));
     {
+        // The other fields are ~7 % of the hashes but their latency-bound workgroups would take wave slots from the
+        // chip-filling validator pass for its whole duration (measured 0.63 -> 0.79 ms); they start when that pass
+        // has been issued and overlap with the validator tree's own latency-bound tail instead.
         const BigField& b = plan.bigs[biggest];
         rc = merkleize_device(s, b.kind, d_ssz + b.src, b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk,
-                              wss[biggest], &hc);
+                              wss[biggest], &hc, nullptr, nullptr, false, ax.fork);
         if (rc) return rc;
     }
+    for (int i = 0; i < 2; i++) ECG_HIP_CHECK(hipStreamWaitEvent(ax.st[i], ax.fork, 0));
     std::vector<TreeJob> first_jobs;  // deferred finishing jobs of the other big fields + dependency level 0
     std::vector<TileDesc> tdescs;     // their tile stages, one launch for all of them
     u32 tile_wgs = 0;

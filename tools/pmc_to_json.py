@@ -1,0 +1,36 @@
+"""profiles/pmc_traffic.json from the two rocprofv3 --pmc passes of tools/gpu_profile_round.sh: per bench step, the sum of
+FETCH_SIZE / WRITE_SIZE (KiB) over the launches of each dominant kernel.  usage: pmc_to_json.py TAG N_STEPS_IN_PMC_RUN"""
+import csv
+import glob
+import json
+import sys
+
+KERNELS = {"k_pairing": "ecg::k_pairing(", "k_merkle_pass<2, ValidatorLeaves>": "k_merkle_pass<2, ecg::ValidatorLeaves>"}
+
+
+def total(root, counter, needle):
+    tot, n = 0.0, 0
+    for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] == counter and needle in row["Kernel_Name"]:
+                    tot += float(row["Counter_Value"])
+                    n += 1
+    return tot, n
+
+
+def main(tag, n_steps):
+    out = {}
+    for key, needle in KERNELS.items():
+        f, nf = total(f"gpurun_out/pmc_{tag}_FETCH_SIZE", "FETCH_SIZE", needle)
+        w, nw = total(f"gpurun_out/pmc_{tag}_WRITE_SIZE", "WRITE_SIZE", needle)
+        if nf and nw:
+            out[key] = {"fetch_kib": f / n_steps, "write_kib": w / n_steps, "launches_per_step": nf / n_steps,
+                        "source": f"profiles/{tag}_pmc_FETCH_SIZE.txt, profiles/{tag}_pmc_WRITE_SIZE.txt (rocprofv3 --pmc, one counter per "
+                                  f"pass, bench.py over {n_steps} steps incl. warm-up)"}
+    json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]))
