@@ -154,6 +154,10 @@ __global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u
     u64 lim = g.src_off + g.n_bytes;
     if (lim > src_total) lim = src_total;
     load_bytes_le<8>(d, src, g.src_off, lim);
+    if (g.last_and && g.n_bytes) {
+        const u32 b = g.n_bytes - 1;  // byte index inside the chunk
+        d[b >> 2] &= ~(0xffu << (8 * (b & 3))) | ((g.last_and & 0xffu) << (8 * (b & 3)));
+    }
     u32* q = reinterpret_cast<u32*>(dst + 32ull * g.dst_chunk);
 #pragma unroll
     for (int k = 0; k < 8; k++) q[k] = d[k];

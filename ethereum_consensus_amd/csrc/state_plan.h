@@ -130,6 +130,8 @@ struct GatherDesc {
     u64 src_off;
     u32 n_bytes;    // <= 32
     u32 dst_chunk;  // chunk index in the small-chunk buffer
+    u32 last_and;   // 0: copy as is; else AND mask for the last copied byte (Bitlist delimiter removal)
+    u32 pad_;
 };
 
 // A big field: reduced by the pass kernels straight from the encoding.
@@ -217,7 +219,7 @@ struct Builder {
     u32 next_chunk = 32;  // chunks 0..31 = the state container's field roots
     u64 hashes = 0;
     u32 alloc(u32 n) { u32 r = next_chunk; next_chunk += n; return r; }
-    void gather(u64 src, u32 nbytes, u32 dst_chunk) { gathers.push_back({src, nbytes, dst_chunk}); }
+    void gather(u64 src, u32 nbytes, u32 dst_chunk) { gathers.push_back({src, nbytes, dst_chunk, 0u, 0u}); }
     void job(int lvl, u32 in_chunk, u32 n, u32 depth, u32 out_chunk, bool mix = false, u64 mix_len = 0) {
         TreeJob j;
         j.in_off = 32ull * in_chunk;

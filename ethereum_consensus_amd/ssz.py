@@ -72,6 +72,22 @@ def hash_tree_root_beacon_state_deneb(ssz: bytes, preset: int = MAINNET) -> byte
     return _root(L.ecgpu_htr_beacon_state_deneb, _buf(ssz), len(ssz), preset)
 
 
+_compiled = {}
+
+
+def hash_tree_root(ssz_type, encoding: bytes) -> bytes:
+    """`T::hash_tree_root` for any SSZ type described with ssz_types (what #[derive(SimpleSerialize)] generates,
+    e.g. deneb BeaconBlock: deneb/beacon_block.rs:12-91) from the value's SSZ serialization."""
+    from . import ssz_types
+    L = _lib.load()
+    if ssz_type not in _compiled:
+        _compiled[ssz_type] = ssz_types.compile(ssz_type)
+    arr, farr, nf, root_idx = _compiled[ssz_type]
+    out = ctypes.create_string_buffer(32)
+    _lib.check(L.ecgpu_htr_ssz(arr, len(arr), farr, nf, root_idx, _buf(encoding), len(encoding), out), "ecgpu_htr_ssz")
+    return out.raw
+
+
 def is_valid_merkle_branch(leaf: bytes, branch, depth: int, index: int, root: bytes) -> bool:
     L = _lib.load()
     b = b"".join(branch[:depth])

@@ -97,6 +97,31 @@ uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);
 /* number of hash64 the last state root of this thread performed (work accounting for benches) */
 uint64_t ecgpu_last_hash64_count(void);
 
+/* Generic SSZ hash_tree_root driven by a type description: what `#[derive(SimpleSerialize)]` generates for every
+ * container of the reference (`ssz_rs::HashTreeRoot`, ssz/mod.rs:4-7), e.g. deneb `BeaconBlock` /
+ * `BeaconBlockBody` (deneb/beacon_block.rs:12-91; called via compute_signing_root, signing.rs:14-22, and at
+ * phase0/block_processing.rs:591).  `types[i]` describes one SSZ type; composite types name their element /
+ * field types by index.  The encoding is walked on the host (offsets only), every hash64 runs on the GPU. */
+enum {
+    ECGPU_SSZ_UINT = 0,       /* param = size in bytes (1, 2, 4, 8, 16, 32); `bool` is UINT 1 */
+    ECGPU_SSZ_BYTEVECTOR = 1, /* param = length in bytes */
+    ECGPU_SSZ_BYTELIST = 2,   /* param = limit in bytes */
+    ECGPU_SSZ_VECTOR = 3,     /* elem = element type, param = length */
+    ECGPU_SSZ_LIST = 4,       /* elem = element type, param = limit */
+    ECGPU_SSZ_BITVECTOR = 5,  /* param = length in bits */
+    ECGPU_SSZ_BITLIST = 6,    /* param = limit in bits */
+    ECGPU_SSZ_CONTAINER = 7   /* fields[first_field .. first_field + n_fields) = field type indices */
+};
+typedef struct {
+    uint32_t kind;
+    uint32_t elem;
+    uint64_t param;
+    uint32_t n_fields;
+    uint32_t first_field;
+} ecgpu_ssz_type;
+int ecgpu_htr_ssz(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs,
+                  uint32_t root_type, const uint8_t* ssz, uint64_t n_bytes, uint8_t root[32]);
+
 /* ---- BLS12-381 (min_pk: 48-byte G1 public keys, 96-byte G2 signatures) ---------------------- */
 /* crypto::verify_signature (crypto/bls.rs:64-77) */
 int ecgpu_verify(const uint8_t pk[48], const uint8_t* msg, size_t msg_len, const uint8_t sig[96]);

@@ -178,6 +178,18 @@ Bytes32 = ByteVector(32)
 Root = Bytes32
 
 
+def _serialize_sequence(elem: SSZType, v) -> bytes:
+    """SSZ sequence encoding: fixed-size elements back to back; variable-size ones behind a table of 4-byte offsets."""
+    parts = [elem.serialize(x) for x in v]
+    if elem.fixed_size is not None:
+        return b"".join(parts)
+    off, table = 4 * len(parts), []
+    for p in parts:
+        table.append(off.to_bytes(4, "little"))
+        off += len(p)
+    return b"".join(table) + b"".join(parts)
+
+
 class Vector(SSZType):
     def __init__(self, elem: SSZType, n: int):
         self.elem, self.n = elem, n
@@ -186,7 +198,7 @@ class Vector(SSZType):
 
     def serialize(self, v):
         assert len(v) == self.n
-        return b"".join(self.elem.serialize(x) for x in v)
+        return _serialize_sequence(self.elem, v)
 
     def htr(self, v):
         assert len(v) == self.n
@@ -203,8 +215,7 @@ class SSZList(SSZType):
         self.elem, self.limit = elem, limit
 
     def serialize(self, v):
-        assert self.elem.fixed_size is not None, "variable-size list elements not needed on this path"
-        return b"".join(self.elem.serialize(x) for x in v)
+        return _serialize_sequence(self.elem, v)
 
     def htr(self, v):
         assert len(v) <= self.limit
@@ -240,6 +251,16 @@ class Bitvector(SSZType):
 class Bitlist(SSZType):
     def __init__(self, limit: int):
         self.limit = limit
+
+    def serialize(self, v):
+        """bits little-endian within bytes, then one delimiter bit"""
+        assert len(v) <= self.limit
+        out = bytearray(len(v) // 8 + 1)
+        for i, b in enumerate(v):
+            if b:
+                out[i // 8] |= 1 << (i % 8)
+        out[len(v) // 8] |= 1 << (len(v) % 8)
+        return bytes(out)
 
     def htr(self, v):
         out = bytearray((len(v) + 7) // 8)
@@ -435,6 +456,61 @@ def BeaconStateDeneb(p: Preset) -> Container:
             ("historical_summaries", SSZList(HistoricalSummary, p.HISTORICAL_ROOTS_LIMIT)),
         ],
     )
+
+
+# ---- deneb block types (row a15), restated from the reference field for field ------------------------------------
+SignedBeaconBlockHeader = Container("SignedBeaconBlockHeader", [("message", BeaconBlockHeader), ("signature", BlsSignature)])  # phase0/beacon_block.rs:93-100
+ProposerSlashing = Container("ProposerSlashing", [("signed_header_1", SignedBeaconBlockHeader), ("signed_header_2", SignedBeaconBlockHeader)])  # phase0/operations.rs:97-100
+Deposit = Container("Deposit", [("proof", Vector(Root, 33)), ("data", DepositData)])  # phase0/operations.rs:110-122, DEPOSIT_CONTRACT_TREE_DEPTH + 1
+VoluntaryExit = Container("VoluntaryExit", [("epoch", uint64), ("validator_index", uint64)])  # :127-132
+SignedVoluntaryExit = Container("SignedVoluntaryExit", [("message", VoluntaryExit), ("signature", BlsSignature)])  # :137-140
+Withdrawal = Container("Withdrawal", [("index", uint64), ("validator_index", uint64), ("address", ExecutionAddress), ("amount", uint64)])  # capella/withdrawal.rs:9-17
+BlsToExecutionChange = Container("BlsToExecutionChange", [("validator_index", uint64), ("from_bls_public_key", BlsPublicKey),
+                                                          ("to_execution_address", ExecutionAddress)])  # capella/bls_to_execution_change.rs:9-15
+SignedBlsToExecutionChange = Container("SignedBlsToExecutionChange", [("message", BlsToExecutionChange), ("signature", BlsSignature)])  # :20-23
+
+
+class BlockPreset:
+    """phase0/presets/*.rs:7,32-36; altair:19; bellatrix:21-24; capella:18-19; deneb:20"""
+
+    def __init__(self, sync_committee_size, max_withdrawals, max_blob_commitments):
+        self.MAX_PROPOSER_SLASHINGS, self.MAX_VALIDATORS_PER_COMMITTEE, self.MAX_ATTESTER_SLASHINGS = 16, 2048, 2
+        self.MAX_ATTESTATIONS, self.MAX_DEPOSITS, self.MAX_VOLUNTARY_EXITS = 128, 16, 16
+        self.SYNC_COMMITTEE_SIZE = sync_committee_size
+        self.BYTES_PER_LOGS_BLOOM, self.MAX_EXTRA_DATA_BYTES = 256, 32
+        self.MAX_BYTES_PER_TRANSACTION, self.MAX_TRANSACTIONS_PER_PAYLOAD = 1 << 30, 1 << 20
+        self.MAX_WITHDRAWALS_PER_PAYLOAD, self.MAX_BLS_TO_EXECUTION_CHANGES = max_withdrawals, 16
+        self.MAX_BLOB_COMMITMENTS_PER_BLOCK = max_blob_commitments
+
+
+BLOCK_MAINNET, BLOCK_MINIMAL = BlockPreset(512, 16, 4096), BlockPreset(32, 4, 16)
+
+
+def BeaconBlockDeneb(p: BlockPreset) -> Container:
+    """deneb/beacon_block.rs:12-91 with phase0/operations.rs:35-61,105-108, altair/sync.rs:9-12, deneb/execution_payload.rs:13-46"""
+    indexed = Container("IndexedAttestation", [("attesting_indices", SSZList(uint64, p.MAX_VALIDATORS_PER_COMMITTEE)),
+                                               ("data", AttestationData), ("signature", BlsSignature)])
+    attestation = Container("Attestation", [("aggregation_bits", Bitlist(p.MAX_VALIDATORS_PER_COMMITTEE)), ("data", AttestationData),
+                                            ("signature", BlsSignature)])
+    attester_slashing = Container("AttesterSlashing", [("attestation_1", indexed), ("attestation_2", indexed)])
+    sync_aggregate = Container("SyncAggregate", [("sync_committee_bits", Bitvector(p.SYNC_COMMITTEE_SIZE)),
+                                                 ("sync_committee_signature", BlsSignature)])
+    payload = Container("ExecutionPayload", [
+        ("parent_hash", Bytes32), ("fee_recipient", ExecutionAddress), ("state_root", Bytes32), ("receipts_root", Bytes32),
+        ("logs_bloom", ByteVector(p.BYTES_PER_LOGS_BLOOM)), ("prev_randao", Bytes32), ("block_number", uint64), ("gas_limit", uint64),
+        ("gas_used", uint64), ("timestamp", uint64), ("extra_data", ByteList(p.MAX_EXTRA_DATA_BYTES)), ("base_fee_per_gas", uint256),
+        ("block_hash", Bytes32), ("transactions", SSZList(ByteList(p.MAX_BYTES_PER_TRANSACTION), p.MAX_TRANSACTIONS_PER_PAYLOAD)),
+        ("withdrawals", SSZList(Withdrawal, p.MAX_WITHDRAWALS_PER_PAYLOAD)), ("blob_gas_used", uint64), ("excess_blob_gas", uint64)])
+    body = Container("BeaconBlockBody", [
+        ("randao_reveal", BlsSignature), ("eth1_data", Eth1Data), ("graffiti", Bytes32),
+        ("proposer_slashings", SSZList(ProposerSlashing, p.MAX_PROPOSER_SLASHINGS)),
+        ("attester_slashings", SSZList(attester_slashing, p.MAX_ATTESTER_SLASHINGS)),
+        ("attestations", SSZList(attestation, p.MAX_ATTESTATIONS)), ("deposits", SSZList(Deposit, p.MAX_DEPOSITS)),
+        ("voluntary_exits", SSZList(SignedVoluntaryExit, p.MAX_VOLUNTARY_EXITS)), ("sync_aggregate", sync_aggregate),
+        ("execution_payload", payload), ("bls_to_execution_changes", SSZList(SignedBlsToExecutionChange, p.MAX_BLS_TO_EXECUTION_CHANGES)),
+        ("blob_kzg_commitments", SSZList(ByteVector(48), p.MAX_BLOB_COMMITMENTS_PER_BLOCK))])
+    return Container("BeaconBlock", [("slot", uint64), ("proposer_index", uint64), ("parent_root", Root), ("state_root", Root),
+                                     ("body", body)])
 
 
 def compute_signing_root(obj_type: SSZType, obj, domain: bytes) -> bytes:

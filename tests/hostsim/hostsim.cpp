@@ -9,6 +9,7 @@
 
 #include "merkle.h"
 #include "state_plan.h"
+#include "ssz_plan.h"
 
 using namespace ecg;
 
@@ -188,6 +189,10 @@ int hs_state_root_deneb(const u8* ssz, u64 n_bytes, int preset, u8* out, u64* ha
         u64 lim = g.src_off + g.n_bytes;
         if (lim > n_bytes) lim = n_bytes;
         load_bytes_le<8>(d, ssz, g.src_off, lim);
+        if (g.last_and && g.n_bytes) {
+            const u32 b = g.n_bytes - 1;
+            d[b >> 2] &= ~(0xffu << (8 * (b & 3))) | ((g.last_and & 0xffu) << (8 * (b & 3)));
+        }
         std::memcpy(small.data() + 32ull * g.dst_chunk, d, 32);
     }
     u64 hc = plan.small_hashes;
@@ -198,6 +203,48 @@ int hs_state_root_deneb(const u8* ssz, u64 n_bytes, int preset, u8* out, u64* ha
             hs_tree_job(small.data() + j.in_off, j.n, j.level, j.depth, (int)j.mix, j.mix_len, small.data() + j.out_off);
     std::memcpy(out, small.data() + 32ull * plan.root_chunk, 32);
     if (hashes) *hashes = hc;
+    return 0;
+}
+
+// ssz_generic.hip::ecgpu_htr_ssz on the lane simulator: same plan, same order
+int hs_htr_ssz(const ecgpu_ssz_type* types, u32 n_types, const u32* fields, u32 n_field_refs, u32 root_type, const u8* ssz, u64 n_bytes,
+               u8* out, u64* hashes) {
+    SszPlan plan;
+    static const u8 empty[4] = {0, 0, 0, 0};
+    if (!build_ssz_plan(types, n_types, fields, n_field_refs, root_type, ssz ? ssz : empty, n_bytes, plan)) return -3;
+    std::vector<u8> small(32ull * plan.n_chunks, 0);
+    for (const GatherDesc& g : plan.gathers) {
+        u32 d[8];
+        u64 lim = g.src_off + g.n_bytes;
+        if (lim > n_bytes) lim = n_bytes;
+        load_bytes_le<8>(d, ssz, g.src_off, lim);
+        if (g.last_and && g.n_bytes) {
+            const u32 b = g.n_bytes - 1;
+            d[b >> 2] &= ~(0xffu << (8 * (b & 3))) | ((g.last_and & 0xffu) << (8 * (b & 3)));
+        }
+        std::memcpy(small.data() + 32ull * g.dst_chunk, d, 32);
+    }
+    u32 max_level = (u32)plan.jobs.size();
+    for (auto& b : plan.bigs)
+        if (b.level + 1 > max_level) max_level = b.level + 1;
+    u64 hc = 0;
+    for (u32 l = 1; l < max_level; l++) {
+        for (auto& b : plan.bigs) {
+            if (b.level != l) continue;
+            std::vector<u8> src;
+            const u8* in = ssz + b.src;
+            if (b.kind == LEAF_NODES) {
+                src.assign(small.begin() + 32ull * b.src, small.begin() + 32ull * (b.src + b.n0));
+                in = src.data();
+            }
+            sim_merkleize(b.kind, in, b.bytes, b.n0, b.depth, b.mix, b.mix_len, small.data() + 32ull * b.out_chunk, &hc);
+        }
+        if (l < plan.jobs.size())
+            for (const TreeJob& j : plan.jobs[l])
+                hs_tree_job(small.data() + j.in_off, j.n, j.level, j.depth, (int)j.mix, j.mix_len, small.data() + j.out_off);
+    }
+    std::memcpy(out, small.data(), 32);
+    if (hashes) *hashes = plan.hashes;
     return 0;
 }
 

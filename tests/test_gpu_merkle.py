@@ -148,3 +148,38 @@ def test_malformed_state_is_rejected(gpu):
         gpu.hash_tree_root_beacon_state_deneb(enc + b"\0", 1)
     with pytest.raises(gpu.MerkleizationError):
         gpu.hash_tree_root_beacon_state_deneb(enc[:100], 1)
+
+
+# ---- generic SSZ hash_tree_root (ecgpu_htr_ssz): deneb BeaconBlock and the SSZ kinds ---------------
+def test_generic_ssz_kinds_and_beacon_block(gpu):
+    import random
+    from ethereum_consensus_amd import ssz_types as T
+    from tests._sszrand import random_value
+    from tests.test_hostsim_ssz import PAIRS
+    r = random.Random(41)
+    for pt, ot in PAIRS:
+        for fill in ("empty", "full", None, None):
+            v = random_value(ot, r, fill)
+            assert gpu.hash_tree_root(pt, ot.serialize(v)) == ot.htr(v)
+    ot, pt = ossz.Bitlist(2048), T.bitlist(2048)
+    for nbits in (0, 1, 7, 8, 9, 255, 256, 257, 2047, 2048):
+        v = [r.random() < 0.5 for _ in range(nbits)]
+        assert gpu.hash_tree_root(pt, ot.serialize(v)) == ot.htr(v)
+    for preset in ("mainnet", "minimal"):
+        pt = T.BeaconBlockDeneb(T.MAINNET if preset == "mainnet" else T.MINIMAL)
+        ot = ossz.BeaconBlockDeneb(ossz.BLOCK_MAINNET if preset == "mainnet" else ossz.BLOCK_MINIMAL)
+        for fill in ("empty", "full", None, None, None):
+            v = random_value(ot, r, fill)
+            assert gpu.hash_tree_root(pt, ot.serialize(v)) == ot.htr(v), (preset, fill)
+    # wide sequences: pass + tile kernels under the generic plan
+    for pt, ot, v in [(T.list_(T.uint64, 1 << 20), ossz.SSZList(ossz.uint64, 1 << 20), [r.randrange(1 << 64) for _ in range(70000)]),
+                      (T.list_(T.bytevector(48), 4096), ossz.SSZList(ossz.ByteVector(48), 4096), [r.randbytes(48) for _ in range(3000)]),
+                      (T.list_(T.bytelist(1 << 30), 1 << 20), ossz.SSZList(ossz.ByteList(1 << 30), 1 << 20),
+                       [r.randbytes(r.randrange(0, 200)) for _ in range(1500)] + [r.randbytes(70000)])]:
+        assert gpu.hash_tree_root(pt, ot.serialize(v)) == ot.htr(v)
+    # malformed encodings: rejected, never a crash
+    from ethereum_consensus_amd import _lib
+    with pytest.raises(_lib.EcgpuError):
+        gpu.hash_tree_root(T.bitlist(8), b"\x00")
+    with pytest.raises(_lib.EcgpuError):
+        gpu.hash_tree_root(T.BeaconBlockDeneb(T.MAINNET), bytes(50))

@@ -1,0 +1,124 @@
+"""The generic SSZ hash_tree_root plan (csrc/ssz_plan.h: offsets -> gathers / jobs / big trees) executed on the CPU
+lane simulator against oracle/ssz.py: deneb BeaconBlock and every SSZ kind at its edges."""
+import ctypes
+import random
+
+import pytest
+
+from ethereum_consensus_amd import ssz_types as T
+from oracle import ssz
+from tests import _hostsim as hs
+from tests._sszrand import random_value
+
+
+def sim_htr(ptype, enc: bytes):
+    L = hs.lib()
+    arr, farr, nf, root = T.compile(ptype)
+    out = ctypes.create_string_buffer(32)
+    h = ctypes.c_uint64(0)
+    buf = ctypes.create_string_buffer(bytes(enc), max(len(enc), 1))
+    L.hs_htr_ssz.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                             ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+    rc = L.hs_htr_ssz(arr, len(arr), farr, nf, root, buf, len(enc), out, ctypes.byref(h))
+    return rc, out.raw, h.value
+
+
+# (product type, oracle type) pairs for the kinds and their edges
+PAIRS = [
+    (T.uint64, ssz.uint64), (T.boolean, ssz.boolean), (T.uint256, ssz.uint256),
+    (T.bytevector(4), ssz.ByteVector(4)), (T.bytevector(32), ssz.Bytes32), (T.bytevector(48), ssz.ByteVector(48)),
+    (T.bytevector(96), ssz.ByteVector(96)), (T.bytevector(256), ssz.ByteVector(256)),
+    (T.bytelist(32), ssz.ByteList(32)), (T.bytelist(1 << 30), ssz.ByteList(1 << 30)),
+    (T.bitvector(4), ssz.Bitvector(4)), (T.bitvector(512), ssz.Bitvector(512)), (T.bitvector(513), ssz.Bitvector(513)),
+    (T.bitlist(2048), ssz.Bitlist(2048)), (T.bitlist(1), ssz.Bitlist(1)),
+    (T.vector(T.uint64, 5), ssz.Vector(ssz.uint64, 5)), (T.vector(T.Root, 33), ssz.Vector(ssz.Root, 33)),
+    (T.list_(T.uint64, 2048), ssz.SSZList(ssz.uint64, 2048)), (T.list_(T.uint8, 100), ssz.SSZList(ssz.uint8, 100)),
+    (T.list_(T.bytelist(1 << 30), 1 << 20), ssz.SSZList(ssz.ByteList(1 << 30), 1 << 20)),
+    (T.vector(T.bytelist(64), 3), ssz.Vector(ssz.ByteList(64), 3)),
+    (T.list_(T.Checkpoint, 16), ssz.SSZList(ssz.Checkpoint, 16)),
+]
+
+
+@pytest.mark.parametrize("i", range(len(PAIRS)))
+def test_every_kind_random_and_edges(i):
+    pt, ot = PAIRS[i]
+    r = random.Random(100 + i)
+    for fill in ("empty", "full", None, None, None, None):
+        v = random_value(ot, r, fill)
+        enc = ot.serialize(v)
+        rc, root, _ = sim_htr(pt, enc)
+        assert rc == 0
+        assert root == ot.htr(v), (fill, len(enc))
+
+
+@pytest.mark.parametrize("nbits", [0, 1, 7, 8, 9, 255, 256, 257, 2047, 2048])
+def test_bitlist_delimiter_positions(nbits):
+    r = random.Random(nbits)
+    ot, pt = ssz.Bitlist(2048), T.bitlist(2048)
+    for v in ([True] * nbits, [False] * nbits, [r.random() < 0.5 for _ in range(nbits)]):
+        rc, root, _ = sim_htr(pt, ot.serialize(v))
+        assert rc == 0 and root == ot.htr(v)
+
+
+def test_sequences_wider_than_one_finishing_job():
+    """> 512 chunks / child roots take the pass + tile kernels instead of a job (SszBigTree)"""
+    r = random.Random(4)
+    for pt, ot, n in [(T.list_(T.uint64, 1 << 20), ssz.SSZList(ssz.uint64, 1 << 20), 5000),
+                      (T.list_(T.bytevector(48), 4096), ssz.SSZList(ssz.ByteVector(48), 4096), 700),
+                      (T.list_(T.bytelist(1 << 30), 1 << 20), ssz.SSZList(ssz.ByteList(1 << 30), 1 << 20), 600),
+                      (T.bytelist(1 << 30), ssz.ByteList(1 << 30), 40000)]:
+        if isinstance(ot, ssz.ByteList):
+            v = r.randbytes(n)
+        elif isinstance(ot.elem, ssz.UInt):
+            v = [r.randrange(1 << 64) for _ in range(n)]
+        elif isinstance(ot.elem, ssz.ByteList):
+            v = [r.randbytes(r.randrange(0, 90)) for _ in range(n)]
+        else:
+            v = [r.randbytes(48) for _ in range(n)]
+        rc, root, _ = sim_htr(pt, ot.serialize(v))
+        assert rc == 0 and root == ot.htr(v)
+
+
+@pytest.mark.parametrize("preset", ["mainnet", "minimal"])
+def test_beacon_block_deneb(preset):
+    pt = T.BeaconBlockDeneb(T.MAINNET if preset == "mainnet" else T.MINIMAL)
+    ot = ssz.BeaconBlockDeneb(ssz.BLOCK_MAINNET if preset == "mainnet" else ssz.BLOCK_MINIMAL)
+    v0 = ot.default()
+    rc, root, hashes = sim_htr(pt, ot.serialize(v0))
+    assert rc == 0 and root == ot.htr(v0) and hashes > 50
+    r = random.Random(17)
+    for fill in ("full", None, None, None):
+        v = random_value(ot, r, fill)
+        enc = ot.serialize(v)
+        rc, root, _ = sim_htr(pt, enc)
+        assert rc == 0
+        assert root == ot.htr(v), (preset, fill, len(enc))
+    # the block's signing root (signing.rs:14-22) through the same entry
+    dom = r.randbytes(32)
+    sd = ssz.SigningData.serialize({"object_root": ot.htr(v), "domain": dom})
+    assert sim_htr(T.SigningData, sd)[1] == ssz.compute_signing_root(ot, v, dom)
+
+
+def test_reference_fixture_header_through_the_generic_entry():
+    """deneb/blob_sidecar.rs:78-84: the sepolia header whose root test_oracle_ssz pins"""
+    hdr = {"slot": 4996736, "proposer_index": 1508, "parent_root": bytes.fromhex("6b5d3b9ba1b0b0e1f2f5c5e4b5f7e4e0b2b0a4f0d0c7e1f3a5b7c9d1e3f5a7b9"),
+           "state_root": bytes(32), "body_root": bytes(range(32))}
+    enc = ssz.BeaconBlockHeader.serialize(hdr)
+    assert sim_htr(T.BeaconBlockHeader, enc)[1] == ssz.BeaconBlockHeader.htr(hdr)
+
+
+def test_malformed_encodings_are_rejected():
+    pt = T.BeaconBlockDeneb(T.MAINNET)
+    ot = ssz.BeaconBlockDeneb(ssz.BLOCK_MAINNET)
+    enc = bytearray(ot.serialize(random_value(ot, random.Random(3), None)))
+    assert sim_htr(pt, bytes(enc[:50]))[0] == -3                    # truncated
+    bad = bytearray(enc)
+    bad[80:84] = (len(enc) + 7).to_bytes(4, "little")              # body offset past the end
+    assert sim_htr(pt, bytes(bad))[0] == -3
+    assert sim_htr(T.bitlist(8), b"\x00")[0] == -3                 # no delimiter bit
+    assert sim_htr(T.bitlist(8), b"")[0] == -3
+    assert sim_htr(T.bitlist(4), b"\xff")[0] == -3                 # 7 bits > limit 4
+    assert sim_htr(T.list_(T.uint64, 2), bytes(24))[0] == -3        # 3 elements > limit 2
+    assert sim_htr(T.list_(T.uint64, 8), bytes(7))[0] == -3         # not a multiple of the element size
+    assert sim_htr(T.list_(T.bytelist(10), 4), (8).to_bytes(4, "little") + (4).to_bytes(4, "little"))[0] == -3  # offsets go backwards
+    assert sim_htr(T.uint64, bytes(7))[0] == -3
