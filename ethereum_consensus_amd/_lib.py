@@ -54,6 +54,11 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_htr_beacon_state_deneb_dev": (c_int, [u8p, c_u64, u8p, c_int, u8p, ctypes.c_void_p]),
         "ecgpu_beacon_state_deneb_fixed_size": (c_u64, [c_int]),
         "ecgpu_last_hash64_count": (c_u64, []),
+        "ecgpu_resident_state_create": (c_int, [c_int, u8p, c_u64, ctypes.POINTER(ctypes.c_void_p)]),
+        "ecgpu_resident_state_destroy": (None, [ctypes.c_void_p]),
+        "ecgpu_resident_state_patch": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, u8p, c_u32]),
+        "ecgpu_resident_state_root": (c_int, [ctypes.c_void_p, u8p]),
+        "ecgpu_resident_state_root_dev": (c_int, [ctypes.c_void_p, u8p, ctypes.c_void_p]),
         "ecgpu_htr_ssz": (c_int, [ctypes.c_void_p, c_u32, ctypes.c_void_p, c_u32, c_u32, u8p, c_u64, u8p]),
         "ecgpu_verify": (c_int, [u8p, u8p, c_size, u8p]),
         "ecgpu_fast_aggregate_verify": (c_int, [u8p, c_u32, u8p, c_size, u8p, c_int]),

@@ -138,11 +138,128 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     return ECGPU_SUCCESS;
 }
 
+// patch scatter: one workgroup per patch, byte copies (patches are small: a balance, a flag byte, a root)
+struct PatchDesc {
+    u64 dst_off, src_off, len;
+};
+__global__ void k_apply_patches(u8* state, const u8* data, const PatchDesc* p) {
+    const PatchDesc d = p[blockIdx.x];
+    for (u64 i = threadIdx.x; i < d.len; i += blockDim.x) state[d.dst_off + i] = data[d.src_off + i];
+}
+
 }  // namespace ecg
+
+struct ecgpu_resident_state {
+    int preset = 0;
+    u8* d_ssz = nullptr;   // encoding + 64 bytes of slack + the root
+    u64 n_bytes = 0;
+    std::vector<u8> h_fixed;  // host mirror of the fixed-size part (offsets and small fields): what the plan reads
+};
 
 using namespace ecg;
 
 extern "C" {
+
+int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!ssz || !out || preset < 0 || preset > 1 || n_bytes < layout_for(STATE_PRESETS[preset]).size) return ECGPU_ERR_BAD_ARG;
+    StatePlan plan;
+    if (!build_state_plan_deneb(ssz, n_bytes, preset, plan)) {
+        set_last_error(plan.error);
+        return ECGPU_ERR_BAD_ARG;
+    }
+    ecgpu_resident_state* st = new ecgpu_resident_state();
+    st->preset = preset;
+    st->n_bytes = n_bytes;
+    st->h_fixed.assign(ssz, ssz + layout_for(STATE_PRESETS[preset]).size);
+    ECG_HIP_CHECK(hipMalloc((void**)&st->d_ssz, n_bytes + 128));
+    ECG_HIP_CHECK(hipMemcpy(st->d_ssz, ssz, n_bytes, hipMemcpyHostToDevice));
+    *out = st;
+    return ECGPU_SUCCESS;
+}
+
+void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st) {
+    if (!st) return;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(st->d_ssz);
+    delete st;
+}
+
+int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offsets, const uint64_t* data_off, const uint8_t* data,
+                               uint32_t n) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!st || (n && (!offsets || !data_off || !data))) return ECGPU_ERR_BAD_ARG;
+    if (!n) return ECGPU_SUCCESS;
+    std::vector<PatchDesc> descs(n);
+    for (u32 i = 0; i < n; i++) {
+        if (data_off[i + 1] < data_off[i]) return ECGPU_ERR_BAD_ARG;
+        const u64 len = data_off[i + 1] - data_off[i];
+        if (offsets[i] > st->n_bytes || len > st->n_bytes - offsets[i]) {
+            set_last_error("patch outside the state encoding");
+            return ECGPU_ERR_BAD_ARG;
+        }
+        descs[i] = {offsets[i], data_off[i], len};
+    }
+    // the variable-size lists keep their lengths: a patch must not rewrite the offset words of the fixed part
+    const FixedLayout L = layout_for(STATE_PRESETS[st->preset]);
+    const u64 off_words[9] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off, L.prev_participation_off,
+                              L.cur_participation_off, L.inactivity_scores_off, L.payload_header_off, L.historical_summaries_off};
+    for (u32 i = 0; i < n; i++)
+        for (u64 w : off_words)
+            if (descs[i].dst_off < w + 4 && descs[i].dst_off + descs[i].len > w) {
+                bool same = true;
+                for (u64 b = (descs[i].dst_off > w ? descs[i].dst_off : w); b < w + 4 && b < descs[i].dst_off + descs[i].len; b++)
+                    same = same && data[descs[i].src_off + (b - descs[i].dst_off)] == st->h_fixed[b];
+                if (!same) {
+                    set_last_error("a patch may not change an SSZ offset: reload the state when a list changes length");
+                    return ECGPU_ERR_BAD_ARG;
+                }
+            }
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    const u64 total = data_off[n];
+    rc = ar.reserve(total + n * sizeof(PatchDesc) + 4096);
+    if (rc) return rc;
+    u8* d_data = ar.take(total ? total : 1);
+    PatchDesc* d_desc = (PatchDesc*)ar.take(n * sizeof(PatchDesc));
+    if (!d_data || !d_desc) return ECGPU_ERR_OOM;
+    if (total) ECG_HIP_CHECK(hipMemcpyAsync(d_data, data, total, hipMemcpyHostToDevice, s));
+    ECG_HIP_CHECK(hipMemcpyAsync(d_desc, descs.data(), n * sizeof(PatchDesc), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_apply_patches, dim3(n), dim3(64), 0, s, st->d_ssz, (const u8*)d_data, (const PatchDesc*)d_desc);
+    ECG_HIP_CHECK(hipGetLastError());
+    for (u32 i = 0; i < n; i++)  // host mirror of the fixed part
+        for (u64 b = 0; b < descs[i].len; b++)
+            if (descs[i].dst_off + b < st->h_fixed.size()) st->h_fixed[descs[i].dst_off + b] = data[descs[i].src_off + b];
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ECGPU_SUCCESS;
+}
+
+int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!st || !d_root) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(stream);
+    return state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root);
+}
+
+int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
+    if (!st || !root) return ECGPU_ERR_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    u8* d_root = st->d_ssz + ((st->n_bytes + 31) / 32) * 32 + 32;
+    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root);
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ECGPU_SUCCESS;
+}
 
 uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset) {
     if (preset < 0 || preset > 1) return 0;

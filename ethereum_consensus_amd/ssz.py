@@ -72,6 +72,51 @@ def hash_tree_root_beacon_state_deneb(ssz: bytes, preset: int = MAINNET) -> byte
     return _root(L.ecgpu_htr_beacon_state_deneb, _buf(ssz), len(ssz), preset)
 
 
+class ResidentBeaconStateDeneb:
+    """A deneb BeaconState kept in HBM: uploaded once, then patched in place with the bytes a block changed and
+    re-Merkleized on the device (the reference re-hashes the host-resident state every slot,
+    phase0/slot_processing.rs:67)."""
+
+    def __init__(self, encoding: bytes, preset: int = MAINNET):
+        self._L = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._L.ecgpu_resident_state_create(preset, _buf(encoding), len(encoding), ctypes.byref(h))
+        if rc == -3:
+            raise MerkleizationError((self._L.ecgpu_last_error() or b"bad state").decode())
+        _lib.check(rc, "ecgpu_resident_state_create")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._L.ecgpu_resident_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def patch(self, patches) -> None:
+        """patches: iterable of (offset into the SSZ encoding, replacement bytes)"""
+        patches = list(patches)
+        if not patches:
+            return
+        offs = (ctypes.c_uint64 * len(patches))(*[o for o, _ in patches])
+        doff = [0]
+        for _, b in patches:
+            doff.append(doff[-1] + len(b))
+        rc = self._L.ecgpu_resident_state_patch(self._h, offs, (ctypes.c_uint64 * len(doff))(*doff), _buf(b"".join(b for _, b in patches)),
+                                                len(patches))
+        if rc == -3:
+            raise MerkleizationError((self._L.ecgpu_last_error() or b"bad patch").decode())
+        _lib.check(rc, "ecgpu_resident_state_patch")
+
+    def hash_tree_root(self) -> bytes:
+        return _root(self._L.ecgpu_resident_state_root, self._h)
+
+
 _compiled = {}
 
 

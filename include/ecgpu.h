@@ -97,6 +97,24 @@ uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);
 /* number of hash64 the last state root of this thread performed (work accounting for benches) */
 uint64_t ecgpu_last_hash64_count(void);
 
+/* Device-resident state (BASELINE configs[4]: "state root after mutating ~2^12 balances + participation bytes per
+ * slot").  The reference keeps the state in host memory and re-Merkleizes all of it every slot
+ * (phase0/slot_processing.rs:67); shipping 148 MB of serialization over PCIe per slot would cost more than hashing
+ * it.  A resident state is uploaded once; afterwards only the bytes a block changed travel: `patch` overwrites byte
+ * ranges of the encoding in place (same total length: field values, balances, participation flags, roots ...),
+ * `root` re-Merkleizes on the device.  A change of length (a new validator) needs `create` again.  One resident
+ * state must not be used from two threads at once. */
+typedef struct ecgpu_resident_state ecgpu_resident_state_t;
+int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out);
+void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st);
+/* n patches: bytes data[data_off[i] .. data_off[i+1]) replace the encoding at offsets[i]; the patches of one call must
+ * not overlap (they are applied concurrently) */
+int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offsets, const uint64_t* data_off,
+                               const uint8_t* data, uint32_t n);
+int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]);
+/* asynchronous form: root written to device memory on `stream` */
+int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, ecgpu_stream_t stream);
+
 /* Generic SSZ hash_tree_root driven by a type description: what `#[derive(SimpleSerialize)]` generates for every
  * container of the reference (`ssz_rs::HashTreeRoot`, ssz/mod.rs:4-7), e.g. deneb `BeaconBlock` /
  * `BeaconBlockBody` (deneb/beacon_block.rs:12-91; called via compute_signing_root, signing.rs:14-22, and at

@@ -183,3 +183,40 @@ def test_generic_ssz_kinds_and_beacon_block(gpu):
         gpu.hash_tree_root(T.bitlist(8), b"\x00")
     with pytest.raises(_lib.EcgpuError):
         gpu.hash_tree_root(T.BeaconBlockDeneb(T.MAINNET), bytes(50))
+
+
+def test_resident_state_patches(gpu):
+    """ecgpu_resident_state_*: upload once, overwrite the bytes a block changed, re-Merkleize on the device.  After
+    every batch of patches the root equals the root of the patched encoding computed from scratch (whose parity with the
+    Python oracle the tests above establish), for patches in the big lists, the small fields and the fixed part."""
+    from ethereum_consensus_amd import synthetic
+    r = random.Random(12)
+    for preset, n in (("minimal", 3000), ("mainnet", 5000)):
+        f = synthetic.state_fields(n, preset, seed=21)
+        enc = bytearray(synthetic.serialize_state(f))
+        pid = synthetic.PRESETS[preset]["id"]
+        st = gpu.ResidentBeaconStateDeneb(bytes(enc), pid)
+        assert st.hash_tree_root() == gpu.hash_tree_root_beacon_state_deneb(bytes(enc), pid)
+        want0 = ossz.BeaconStateDeneb(ossz.MINIMAL if preset == "minimal" else ossz.MAINNET).htr(oracle_state_value(f))
+        assert st.hash_tree_root() == want0
+        from ethereum_consensus_amd import _lib
+        L = _lib.load()
+        fixed_size = int(L.ecgpu_beacon_state_deneb_fixed_size(pid))
+        for slot in range(3):
+            patches, used = [], set()
+            for _ in range(200):
+                ln = r.choice([1, 8, 8, 8, 32])
+                off = r.randrange(fixed_size, len(enc) - ln)  # somewhere in the variable part: validators, balances, flags ...
+                if any(b in used for b in range(off, off + ln)):
+                    continue  # the patches of one call must not overlap
+                used.update(range(off, off + ln))
+                patches.append((off, r.randbytes(ln)))
+            patches.append((40, (8_700_000 + slot).to_bytes(8, "little")))  # the `slot` field (fixed part, a gathered chunk)
+            patches.append((48 + 16 + 112 + 32 * 5, r.randbytes(32)))        # block_roots[5] (fixed part, big vector)
+            for off, b in patches:
+                enc[off:off + len(b)] = b
+            st.patch(patches)
+            assert st.hash_tree_root() == gpu.hash_tree_root_beacon_state_deneb(bytes(enc), pid), (preset, slot)
+        with pytest.raises(gpu.MerkleizationError):
+            st.patch([(len(enc) - 4, bytes(8))])          # runs past the end
+        st.close()
