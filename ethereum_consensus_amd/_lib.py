@@ -59,6 +59,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_resident_state_patch": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, u8p, c_u32]),
         "ecgpu_resident_state_root": (c_int, [ctypes.c_void_p, u8p]),
         "ecgpu_resident_state_root_dev": (c_int, [ctypes.c_void_p, u8p, ctypes.c_void_p]),
+        "ecgpu_compute_shuffled_indices": (c_int, [ctypes.c_void_p, c_u64, u8p, c_u32, ctypes.c_void_p]),
+        "ecgpu_compute_shuffled_indices_dev": (c_int, [ctypes.c_void_p, c_u64, u8p, c_u32, ctypes.c_void_p, ctypes.c_void_p]),
         "ecgpu_htr_ssz": (c_int, [ctypes.c_void_p, c_u32, ctypes.c_void_p, c_u32, c_u32, u8p, c_u64, u8p]),
         "ecgpu_verify": (c_int, [u8p, u8p, c_size, u8p]),
         "ecgpu_fast_aggregate_verify": (c_int, [u8p, c_u32, u8p, c_size, u8p, c_int]),

@@ -140,6 +140,15 @@ typedef struct {
 int ecgpu_htr_ssz(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs,
                   uint32_t root_type, const uint8_t* ssz, uint64_t n_bytes, uint8_t root[32]);
 
+/* Swap-or-not shuffling: `compute_shuffled_indices(indices, seed, context)`
+ * (phase0/helpers.rs:287-360; out[i] = indices[compute_shuffled_index(i, n, seed)], :249-282), the SHA-256 consumer
+ * behind every committee computation.  ValidatorIndex = usize -> uint64_t.  indices == NULL: the permutation itself.
+ * rounds = context.shuffle_round_count (90 on mainnet, 10 on minimal). */
+int ecgpu_compute_shuffled_indices(const uint64_t* indices, uint64_t n, const uint8_t seed[32], uint32_t rounds,
+                                   uint64_t* out);
+int ecgpu_compute_shuffled_indices_dev(const uint64_t* d_indices, uint64_t n, const uint8_t seed[32], uint32_t rounds,
+                                       uint64_t* d_out, ecgpu_stream_t stream);
+
 /* ---- BLS12-381 (min_pk: 48-byte G1 public keys, 96-byte G2 signatures) ---------------------- */
 /* crypto::verify_signature (crypto/bls.rs:64-77) */
 int ecgpu_verify(const uint8_t pk[48], const uint8_t* msg, size_t msg_len, const uint8_t sig[96]);

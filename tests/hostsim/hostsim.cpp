@@ -10,6 +10,7 @@
 #include "merkle.h"
 #include "state_plan.h"
 #include "ssz_plan.h"
+#include "shuffle.h"
 
 using namespace ecg;
 
@@ -204,6 +205,23 @@ int hs_state_root_deneb(const u8* ssz, u64 n_bytes, int preset, u8* out, u64* ha
     std::memcpy(out, small.data() + 32ull * plan.root_chunk, 32);
     if (hashes) *hashes = hc;
     return 0;
+}
+
+// shuffle.hip on the lane simulator: pivots, source table, one walk per index
+void hs_shuffle(const u64* in, u64 n, const u8* seed32, u32 rounds, u64* out) {
+    if (n == 0) return;
+    ShuffleSeed sd;
+    for (int i = 0; i < 8; i++)
+        sd.w[i] = ((u32)seed32[4 * i] << 24) | ((u32)seed32[4 * i + 1] << 16) | ((u32)seed32[4 * i + 2] << 8) | seed32[4 * i + 3];
+    const u64 nb = (n + 255) / 256;
+    std::vector<u64> piv(rounds ? rounds : 1);
+    std::vector<u32> table((size_t)rounds * nb * 8 + 8);
+    for (u32 r = 0; r < rounds; r++) piv[r] = shuffle_pivot(sd, r, n);
+    for (u64 i = 0; i < (u64)rounds * nb; i++) shuffle_hash_block(table.data() + i * 8, sd, (u32)(i / nb), true, (u32)(i % nb));
+    for (u64 i = 0; i < n; i++) {
+        const u64 j = shuffled_index(i, n, rounds, piv.data(), table.data(), nb);
+        out[i] = in ? in[j] : j;
+    }
 }
 
 // ssz_generic.hip::ecgpu_htr_ssz on the lane simulator: same plan, same order
