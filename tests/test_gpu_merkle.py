@@ -220,3 +220,33 @@ def test_resident_state_patches(gpu):
         with pytest.raises(gpu.MerkleizationError):
             st.patch([(len(enc) - 4, bytes(8))])          # runs past the end
         st.close()
+
+
+def test_concurrent_calls_from_several_host_threads(gpu):
+    """The reference functions are pure and re-entrant and its spec-test harness runs trials on several threads
+    (SURVEY.md 8b): every host thread gets its own stream + arena, so concurrent calls must not disturb each other."""
+    import threading
+    from ethereum_consensus_amd import bls, synthetic
+    from tests import _blscases as C
+    vals = [synthetic.validators(3000 + 17 * t).tobytes() for t in range(6)]
+    want = [cref.htr_validators(v)[0] for v in vals]
+    pk = bls.sk_to_pk_batch(C.CAN_SIGN_SK.to_bytes(32, "big"))
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(6):
+                assert gpu.hash_tree_root_validators(vals[t]) == want[t]
+                d = rnd(32 * (100 + t), t)
+                assert gpu.merkleize(d, 1 << 20, 7) == ossz.mix_in_length(ossz.merkleize_bytes(d, 1 << 20), 7)
+                if t % 2 == 0:
+                    bls.verify_signature(pk, C.CAN_SIGN_MSG, C.CAN_SIGN_SIG)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
