@@ -327,7 +327,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     if (!pts || !st || !sigpts || !hpts || !st_dec || !st_grp) return ECGPU_ERR_OOM;
     // Key-heavy batches (committees): the signature and message stages do not depend on the keys, so they run on an
     // auxiliary stream underneath the key validation + aggregation and join before the pairing check.
-    const bool fork = d_pk_off && !reg && n_pks >= 4ull * n;
+    // With a registry there is no key validation to hide behind: the signature stage stays on the caller's stream
+    // and only the (three times longer) message stage goes to the auxiliary one.
+    const bool fork = d_pk_off && (reg || n_pks >= 4ull * n) && n <= 16384;
     hipStream_t s2 = s;
     if (fork) {
         int rc = ax.init();
@@ -345,8 +347,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
     }
     {
-        ProfScope ps("bls_sig", s2);
-        hipLaunchKernelGGL(k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_sigs96, n, sigpts, st_dec, st_grp);
+        hipStream_t s_sig = reg ? s : s2;
+        ProfScope ps("bls_sig", s_sig);
+        hipLaunchKernelGGL(k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s_sig, d_sigs96, n, sigpts, st_dec, st_grp);
     }
     {
         ProfScope ps("bls_h2c", s2);
