@@ -32,7 +32,7 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
 }
 
 // T <- 2T, f <- f * line_{T,T}(P)
-ECG_HD_NOINLINE void miller_dbl_step(Fp12& f, MillerPair& m) {
+ECG_FP12_FN void miller_dbl_step(Fp12& f, MillerPair& m) {
     const J2& T = m.t;
     Fp2 A = fp2_sqrx(T.x);
     Fp2 B = fp2_sqrx(T.y);
@@ -54,7 +54,7 @@ ECG_HD_NOINLINE void miller_dbl_step(Fp12& f, MillerPair& m) {
 }
 
 // T <- T + Q, f <- f * line_{T,Q}(P)
-ECG_HD_NOINLINE void miller_add_step(Fp12& f, MillerPair& m) {
+ECG_FP12_FN void miller_add_step(Fp12& f, MillerPair& m) {
     const J2& T = m.t;
     Fp2 Z1Z1 = fp2_sqrx(T.z);
     Fp2 U2 = fp2_mulx(m.qx, Z1Z1);

@@ -9,6 +9,26 @@
 #pragma once
 #include "bls_fp.h"
 
+// Call structure of the lane kernels.  A routine that keeps values live across the out-of-line Fp products holds them
+// in callee-saved registers and must save / restore those at its own entry / exit: measured 229-282 dwords per
+// Fp6-product call, the bulk of k_pairing's private-segment traffic.  Inlining a level removes its saves (a kernel has
+// no caller to save for) at the price of code size:  ECG_INLINE_LEVEL 0: Fp6- and Fp12-level routines are calls (40.9 ms);
+// 1 (default): Fp6-level routines inline into the Fp12-level ones (39.3 ms, a third fewer saves); 2: Fp12-level routines and
+// the Miller steps inline as well (47 ms: one 2.8 MB function, the register allocator spills more than it saves).
+#ifndef ECG_INLINE_LEVEL
+#define ECG_INLINE_LEVEL 1
+#endif
+#if ECG_INLINE_LEVEL >= 1
+#define ECG_FP6_FN ECG_HD
+#else
+#define ECG_FP6_FN ECG_HD_NOINLINE
+#endif
+#if ECG_INLINE_LEVEL >= 2
+#define ECG_FP12_FN ECG_HD
+#else
+#define ECG_FP12_FN ECG_HD_NOINLINE
+#endif
+
 namespace ecg {
 
 // Fp2 products are inlined into the Fp6-level routines (only the Fp products underneath are calls), so the
@@ -58,12 +78,12 @@ ECG_HD void fp6_mul_core(Fp6& r, const Fp2& a0, const Fp2& a1, const Fp2& a2, co
     r.c2 = fp2_add(fp2_sub(fp2_sub(m02, t0), t2), t1);
 }
 // r may alias a or b (operands are loaded before the result is stored).
-ECG_HD_NOINLINE void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
+ECG_FP6_FN void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
     const Fp2 a0 = a.c0, a1 = a.c1, a2 = a.c2, b0 = b.c0, b1 = b.c1, b2 = b.c2;
     fp6_mul_core(r, a0, a1, a2, b0, b1, b2);
 }
 // a * (c0 + c1 v): 5 Fp2 products
-ECG_HD_NOINLINE void fp6_mul_by_01(Fp6& r, const Fp6& a, const Fp2& c0, const Fp2& c1) {
+ECG_FP6_FN void fp6_mul_by_01(Fp6& r, const Fp6& a, const Fp2& c0, const Fp2& c1) {
     Fp2 t0 = fp2_mulx(a.c0, c0);
     Fp2 t1 = fp2_mulx(a.c1, c1);
     Fp2 mid = fp2_sub(fp2_sub(fp2_mulx(fp2_add_lazy(a.c0, a.c1), fp2_add_lazy(c0, c1)), t0), t1);
@@ -74,7 +94,7 @@ ECG_HD_NOINLINE void fp6_mul_by_01(Fp6& r, const Fp6& a, const Fp2& c0, const Fp
     r.c2 = fp2_add(t1, s2a);
 }
 // a * (c1 v): 3 Fp2 products
-ECG_HD_NOINLINE void fp6_mul_by_1(Fp6& r, const Fp6& a, const Fp2& c1) {
+ECG_FP6_FN void fp6_mul_by_1(Fp6& r, const Fp6& a, const Fp2& c1) {
     Fp2 t0 = fp2_mul_xi(fp2_mulx(a.c2, c1));
     Fp2 t1 = fp2_mulx(a.c0, c1);
     Fp2 t2 = fp2_mulx(a.c1, c1);
@@ -83,17 +103,17 @@ ECG_HD_NOINLINE void fp6_mul_by_1(Fp6& r, const Fp6& a, const Fp2& c1) {
     r.c2 = t2;
 }
 // r = (a0 + a1)(b0 + b1): the middle product of the Fp12 Karatsuba, sums formed on the fly.  r must not alias.
-ECG_HD_NOINLINE void fp6_mul_sums(Fp6& r, const Fp6& a0, const Fp6& a1, const Fp6& b0, const Fp6& b1) {
+ECG_FP6_FN void fp6_mul_sums(Fp6& r, const Fp6& a0, const Fp6& a1, const Fp6& b0, const Fp6& b1) {
     fp6_mul_core(r, fp2_add_lazy(a0.c0, a1.c0), fp2_add_lazy(a0.c1, a1.c1), fp2_add_lazy(a0.c2, a1.c2), fp2_add_lazy(b0.c0, b1.c0),
                  fp2_add_lazy(b0.c1, b1.c1), fp2_add_lazy(b0.c2, b1.c2));
 }
 // r = (a0 + a1)(a0 + v a1): the first product of the complex squaring.  r must not alias.
-ECG_HD_NOINLINE void fp6_mul_sqr_sums(Fp6& r, const Fp6& a0, const Fp6& a1) {
+ECG_FP6_FN void fp6_mul_sqr_sums(Fp6& r, const Fp6& a0, const Fp6& a1) {
     fp6_mul_core(r, fp2_add_lazy(a0.c0, a1.c0), fp2_add_lazy(a0.c1, a1.c1), fp2_add_lazy(a0.c2, a1.c2),
                  fp2_add_lazy(a0.c0, fp2_mul_xi(a1.c2)), fp2_add_lazy(a0.c1, a1.c0), fp2_add_lazy(a0.c2, a1.c1));
 }
 // r = (f0 + f1) * (l0 + (l1 + l2) v): the middle product of the sparse line multiplication.  r must not alias.
-ECG_HD_NOINLINE void fp6_mul_by_01_sums(Fp6& r, const Fp6& f0, const Fp6& f1, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+ECG_FP6_FN void fp6_mul_by_01_sums(Fp6& r, const Fp6& f0, const Fp6& f1, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
     // a_k, c1 < 4p; a0 + a1 < 8p and l0 + c1 < 6p as fp2_mul operands
     const Fp2 a0 = fp2_add_lazy(f0.c0, f1.c0), a1 = fp2_add_lazy(f0.c1, f1.c1), a2 = fp2_add_lazy(f0.c2, f1.c2), c1 = fp2_add_lazy(l1, l2);
     Fp2 t0 = fp2_mulx(a0, l0);
@@ -107,7 +127,7 @@ ECG_HD_NOINLINE void fp6_mul_by_01_sums(Fp6& r, const Fp6& f0, const Fp6& f1, co
 }
 // Karatsuba recombination in one pass: r1 = m - t0 - t1, r0 = t0 + v t1.  r0 / r1 may alias m, t0, t1
 // component-wise (every component is read before it is written).
-ECG_HD_NOINLINE void fp12_karatsuba_combine(Fp6& r0, Fp6& r1, const Fp6& m, const Fp6& t0, const Fp6& t1) {
+ECG_FP6_FN void fp12_karatsuba_combine(Fp6& r0, Fp6& r1, const Fp6& m, const Fp6& t0, const Fp6& t1) {
     const Fp2 x0 = t0.c0, x1 = t0.c1, x2 = t0.c2, y0 = t1.c0, y1 = t1.c1, y2 = t1.c2;
     const Fp2 m0 = m.c0, m1 = m.c1, m2 = m.c2;
     r1.c0 = fp2_sub(fp2_sub(m0, x0), y0);
@@ -118,7 +138,7 @@ ECG_HD_NOINLINE void fp12_karatsuba_combine(Fp6& r0, Fp6& r1, const Fp6& m, cons
     r0.c2 = fp2_add(x2, y1);
 }
 // complex-squaring recombination: r.c0 = s - ab - v ab, r.c1 = 2 ab
-ECG_HD_NOINLINE void fp12_sqr_combine(Fp12& r, const Fp6& s, const Fp6& ab) {
+ECG_FP6_FN void fp12_sqr_combine(Fp12& r, const Fp6& s, const Fp6& ab) {
     const Fp2 x0 = ab.c0, x1 = ab.c1, x2 = ab.c2;
     const Fp2 s0 = s.c0, s1 = s.c1, s2 = s.c2;
     r.c0.c0 = fp2_sub(fp2_sub(s0, x0), fp2_mul_xi(x2));
@@ -156,7 +176,7 @@ ECG_HD void fp12_conj(Fp12& r, const Fp12& a) {
     fp6_neg(r.c1, a.c1);
 }
 // 3 Fp6 products.  r may alias a or b.
-ECG_HD_NOINLINE void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
+ECG_FP12_FN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
     Fp6 t0, t1, m;
     fp6_mul(t0, a.c0, b.c0);
     fp6_mul(t1, a.c1, b.c1);
@@ -164,14 +184,14 @@ ECG_HD_NOINLINE void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
     fp12_karatsuba_combine(r.c0, r.c1, m, t0, t1);
 }
 // complex squaring, 2 Fp6 products: c0 = (a0 + a1)(a0 + v a1) - a0a1 - v a0a1, c1 = 2 a0a1
-ECG_HD_NOINLINE void fp12_sqr(Fp12& r, const Fp12& a) {
+ECG_FP12_FN void fp12_sqr(Fp12& r, const Fp12& a) {
     Fp6 ab, s;
     fp6_mul(ab, a.c0, a.c1);
     fp6_mul_sqr_sums(s, a.c0, a.c1);
     fp12_sqr_combine(r, s, ab);
 }
 // f * ((l0 + l1 v) + (l2 v) w): the Miller-loop line shape on the M-twist, 13 Fp2 products.
-ECG_HD_NOINLINE void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+ECG_FP12_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
     Fp6 aa, bb, m;
     fp6_mul_by_01(aa, f.c0, l0, l1);
     fp6_mul_by_1(bb, f.c1, l2);
@@ -208,7 +228,7 @@ ECG_HD void fp4_sqr(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
     c0 = fp2_add(fp2_mul_xi(t1), t0);
     c1 = fp2_sub(fp2_sub(fp2_sqrx(fp2_add(a, b)), t0), t1);
 }
-ECG_HD_NOINLINE void fp12_cyclotomic_sqr(Fp12& r, const Fp12& f) {
+ECG_FP12_FN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& f) {
     Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
     Fp2 t0, t1, t2, t3;
     fp4_sqr(t0, t1, z0, z1);

@@ -11,7 +11,7 @@ echo "pytest exit $?" >> gpurun_out/${TAG}_pytest_gpu.log
 tail -4 gpurun_out/${TAG}_pytest_gpu.log
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 1500 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG} -o ${TAG} -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG} -o ${TAG} -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aggregates > gpurun_out/${TAG}_prof.log 2>&1
 DB=$(find gpurun_out/prof_${TAG} -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" gpurun_out/${TAG}_bench_kernel_stats.txt && head -16 gpurun_out/${TAG}_bench_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
