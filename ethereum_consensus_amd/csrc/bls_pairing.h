@@ -32,7 +32,7 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
 }
 
 // T <- 2T, f <- f * line_{T,T}(P)
-ECG_FP12_FN void miller_dbl_step(Fp12& f, MillerPair& m) {
+ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, MillerPair& m) {
     const J2& T = m.t;
     Fp2 A = fp2_sqrx(T.x);
     Fp2 B = fp2_sqrx(T.y);

@@ -13,7 +13,9 @@
 // in callee-saved registers and must save / restore those at its own entry / exit: measured 229-282 dwords per
 // Fp6-product call, the bulk of k_pairing's private-segment traffic.  Inlining a level removes its saves (a kernel has
 // no caller to save for) at the price of code size:  ECG_INLINE_LEVEL 0: Fp6- and Fp12-level routines are calls (40.9 ms);
-// 1 (default): Fp6-level routines inline into the Fp12-level ones (39.3 ms, a third fewer saves); 2: Fp12-level routines and
+// 1 (default): Fp6-level routines inline into the Fp12-level ones (39.3 ms, a third fewer saves) and the doubling iteration
+// of the Miller loop (accumulator squaring, doubling step, line multiplication) inlines into miller_loop (36.5 ms);
+// inlining the cyclotomic squaring into its loop as well changes nothing; 2: all Fp12-level routines and
 // the Miller steps inline as well (47 ms: one 2.8 MB function, the register allocator spills more than it saves).
 #ifndef ECG_INLINE_LEVEL
 #define ECG_INLINE_LEVEL 1
@@ -27,6 +29,18 @@
 #define ECG_FP12_FN ECG_HD
 #else
 #define ECG_FP12_FN ECG_HD_NOINLINE
+#endif
+// the doubling iteration of the Miller loop (accumulator squaring, doubling step, line multiplication): one instance each
+#if ECG_INLINE_LEVEL >= 1 || defined(ECG_INLINE_MILLER_DBL)
+#define ECG_MILLER_DBL_FN ECG_HD
+#else
+#define ECG_MILLER_DBL_FN ECG_HD_NOINLINE
+#endif
+// the cyclotomic squaring inside the 63-step exponentiation loops of the final exponentiation
+#if ECG_INLINE_LEVEL >= 2 || defined(ECG_INLINE_CYC_SQR)
+#define ECG_CYC_SQR_FN ECG_HD
+#else
+#define ECG_CYC_SQR_FN ECG_HD_NOINLINE
 #endif
 
 namespace ecg {
@@ -184,14 +198,14 @@ ECG_FP12_FN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
     fp12_karatsuba_combine(r.c0, r.c1, m, t0, t1);
 }
 // complex squaring, 2 Fp6 products: c0 = (a0 + a1)(a0 + v a1) - a0a1 - v a0a1, c1 = 2 a0a1
-ECG_FP12_FN void fp12_sqr(Fp12& r, const Fp12& a) {
+ECG_MILLER_DBL_FN void fp12_sqr(Fp12& r, const Fp12& a) {
     Fp6 ab, s;
     fp6_mul(ab, a.c0, a.c1);
     fp6_mul_sqr_sums(s, a.c0, a.c1);
     fp12_sqr_combine(r, s, ab);
 }
 // f * ((l0 + l1 v) + (l2 v) w): the Miller-loop line shape on the M-twist, 13 Fp2 products.
-ECG_FP12_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+ECG_MILLER_DBL_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
     Fp6 aa, bb, m;
     fp6_mul_by_01(aa, f.c0, l0, l1);
     fp6_mul_by_1(bb, f.c1, l2);
@@ -228,7 +242,7 @@ ECG_HD void fp4_sqr(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
     c0 = fp2_add(fp2_mul_xi(t1), t0);
     c1 = fp2_sub(fp2_sub(fp2_sqrx(fp2_add(a, b)), t0), t1);
 }
-ECG_FP12_FN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& f) {
+ECG_CYC_SQR_FN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& f) {
     Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
     Fp2 t0, t1, t2, t3;
     fp4_sqr(t0, t1, z0, z1);
