@@ -56,3 +56,38 @@ def test_product_does_not_import_the_oracle():
             text = open(os.path.join(dirpath, f), errors="ignore").read()
             for needle in ("import oracle", "from oracle", "liboracle", "libhostsim", "oracle/_build", "oracle.cref"):
                 assert needle not in text, (f, needle)
+
+
+def _build_c_caller():
+    from ethereum_consensus_amd import _lib
+    _lib.load()  # builds the library if needed
+    src = os.path.join(ROOT, "tests", "cabi", "abi_smoke.c")
+    exe = os.path.join(ROOT, "tests", "cabi", "abi_smoke")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    import subprocess
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + libdir, "-lecgpu",
+                    "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_plain_c_caller_without_a_gpu():
+    """include/ecgpu.h compiles as C99 and a C program linked against libecgpu.so gets ECGPU_ERR_NO_DEVICE everywhere."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = _build_c_caller()
+    r = subprocess.run([exe, "nogpu"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_on_the_gpu():
+    import subprocess
+    from oracle import bls12_381 as B, ssz as ossz
+    from tests import _blscases as C
+    exe = _build_c_caller()
+    root = ossz.BeaconBlockHeader.htr(ossz.BeaconBlockHeader.default()).hex()
+    pk = B.sk_to_pk(C.CAN_SIGN_SK).hex()
+    r = subprocess.run([exe, "gpu", root, pk, C.CAN_SIGN_SIG.hex(), C.CAN_SIGN_MSG.decode()], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
