@@ -18,12 +18,14 @@ constexpr int FP_N = 13;
 
 // op census for the roofline arithmetic in DESIGN.md / bench.py: host lane simulator only
 #if !defined(__HIPCC__) && defined(ECG_COUNT_OPS)
-extern unsigned long long g_ecg_fp_mul_count, g_ecg_fp_sqr_count;
+extern unsigned long long g_ecg_fp_mul_count, g_ecg_fp_sqr_count, g_ecg_fp_mad_count;
 #define ECG_COUNT_MUL() (++g_ecg_fp_mul_count)
 #define ECG_COUNT_SQR() (++g_ecg_fp_sqr_count)
+#define ECG_COUNT_MAD(n) (g_ecg_fp_mad_count += (n))  // multiply instructions of the sums of products
 #else
 #define ECG_COUNT_MUL() ((void)0)
 #define ECG_COUNT_SQR() ((void)0)
+#define ECG_COUNT_MAD(n) ((void)0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -167,6 +169,161 @@ ECG_HD Fp fp_mul_body(const Fp& a, const Fp& b) {
     return r;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
+// nothing but memory and scalar instructions may be scheduled across (operand loads should still be issued early)
+#define ECG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x3f4)
+// T[k] += a[k] * b for 7 / 6 consecutive columns, written as the instructions themselves.  Two reasons: from
+// `(u64)a * b` LLVM keeps every operand limb that has more than one use as a zero-extended 64-bit register PAIR (the
+// extension is CSE'd and then allocated), which doubles the operand registers of a sum of products and spills it to the
+// private segment; and one statement per multiply-add gets an s_nop between every two of them (the hazard recogniser's
+// conservative rule for back-to-back inline asm), which costs a full issue slot each at one wave per SIMD.  The carry-out
+// of v_mad_u64_u32 goes to vcc and is never used (columns have 4 bits of headroom).
+ECG_D void ecg_mad7(u64* T, const u32* a, u32 b) {
+    asm("v_mad_u64_u32 %0, vcc, %7, %14, %0\n\tv_mad_u64_u32 %1, vcc, %8, %14, %1\n\tv_mad_u64_u32 %2, vcc, %9, %14, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %10, %14, %3\n\tv_mad_u64_u32 %4, vcc, %11, %14, %4\n\tv_mad_u64_u32 %5, vcc, %12, %14, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %13, %14, %6"
+        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(b)
+        : "vcc");
+}
+ECG_D void ecg_mad6(u64* T, const u32* a, u32 b) {
+    asm("v_mad_u64_u32 %0, vcc, %6, %12, %0\n\tv_mad_u64_u32 %1, vcc, %7, %12, %1\n\tv_mad_u64_u32 %2, vcc, %8, %12, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %9, %12, %3\n\tv_mad_u64_u32 %4, vcc, %10, %12, %4\n\tv_mad_u64_u32 %5, vcc, %11, %12, %5"
+        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b)
+        : "vcc");
+}
+// the same with the limbs of p (compile-time constants, kept in scalar registers: one per instruction is allowed)
+ECG_D void ecg_mad7_p(u64* T, u32 m) {
+    asm("v_mad_u64_u32 %0, vcc, %14, %7, %0\n\tv_mad_u64_u32 %1, vcc, %14, %8, %1\n\tv_mad_u64_u32 %2, vcc, %14, %9, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %14, %10, %3\n\tv_mad_u64_u32 %4, vcc, %14, %11, %4\n\tv_mad_u64_u32 %5, vcc, %14, %12, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %14, %13, %6"
+        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6])
+        : "s"(blsc::P[0]), "s"(blsc::P[1]), "s"(blsc::P[2]), "s"(blsc::P[3]), "s"(blsc::P[4]), "s"(blsc::P[5]), "s"(blsc::P[6]), "v"(m)
+        : "vcc");
+}
+ECG_D void ecg_mad6_p(u64* T, u32 m) {
+    asm("v_mad_u64_u32 %0, vcc, %12, %6, %0\n\tv_mad_u64_u32 %1, vcc, %12, %7, %1\n\tv_mad_u64_u32 %2, vcc, %12, %8, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %12, %9, %3\n\tv_mad_u64_u32 %4, vcc, %12, %10, %4\n\tv_mad_u64_u32 %5, vcc, %12, %11, %5"
+        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5])
+        : "s"(blsc::P[7]), "s"(blsc::P[8]), "s"(blsc::P[9]), "s"(blsc::P[10]), "s"(blsc::P[11]), "s"(blsc::P[12]), "v"(m)
+        : "vcc");
+}
+// T[0..12] += a[0..12] * b
+ECG_D void ecg_mad_row(u64* T, const u32* a, u32 b) {
+    ecg_mad7(T, a, b);
+    ecg_mad6(T + 7, a + 7, b);
+}
+ECG_D void ecg_mad_row_p(u64* T, u32 m) {
+    ecg_mad7_p(T, m);
+    ecg_mad6_p(T + 7, m);
+}
+#else
+#define ECG_SCHED_FENCE() ((void)0)
+// host lane simulator (CPU test-suite): the same column arithmetic, with every accumulation checked for 64-bit overflow
+extern unsigned long long g_ecg_column_overflows;
+ECG_HD void ecg_mad_row(u64* T, const u32* a, u32 b) {
+    for (int j = 0; j < 13; j++)
+        if (__builtin_add_overflow(T[j], (u64)a[j] * b, &T[j])) g_ecg_column_overflows++;
+}
+ECG_HD void ecg_mad_row_p(u64* T, u32 m) {
+    for (int j = 0; j < 13; j++)
+        if (__builtin_add_overflow(T[j], (u64)m * blsc::P[j], &T[j])) g_ecg_column_overflows++;
+}
+#endif
+// k * p in normalized limbs, evaluated at compile time: the offsets of the lazy subtractions below.
+struct FpConst {
+    u32 l[13];
+};
+constexpr FpConst fp_p_times(u32 k) {
+    FpConst r{};
+    u64 c = 0;
+    for (int i = 0; i < 13; i++) {
+        c += (u64)blsc::P[i] * k;
+        r.l[i] = i + 1 < 13 ? (u32)(c & 0x3fffffffu) : (u32)c;
+        if (i + 1 < 13) c >>= 30;
+    }
+    return r;
+}
+// K p - a in (0, K p] for a < K p: the lazy negation used to fold signs into sums of products.  Limbs renormalized.
+template <int K>
+ECG_HD Fp fp_neg_lazy(const Fp& a) {
+    constexpr FpConst kp = fp_p_times(K);
+    Fp s;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        int32_t t = (int32_t)kp.l[i] - (int32_t)a.l[i] + c;
+        s.l[i] = i + 1 < FP_N ? ((u32)t & FP_MASK) : (u32)t;
+        c = t >> 30;
+    }
+    return s;
+}
+// a - b + K p in (0, bound(a) + K p) for b < K p
+template <int K>
+ECG_HD Fp fp_sub_lazy_k(const Fp& a, const Fp& b) {
+    constexpr FpConst kp = fp_p_times(K);
+    Fp s;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        int32_t t = (int32_t)a.l[i] - (int32_t)b.l[i] + (int32_t)kp.l[i] + c;
+        s.l[i] = i + 1 < FP_N ? ((u32)t & FP_MASK) : (u32)t;
+        c = t >> 30;
+    }
+    return s;
+}
+
+// Sum of N products with ONE Montgomery reduction: (a_0 b_0 + ... + a_{N-1} b_{N-1}) / R mod p, result < 2p whenever
+// the integer sum is < R p = 632 p^2 (operands are lazy sums / lazy negations; every caller states its bound).
+// This is how the tower spends multiplier time instead of linear operations: on gfx950 a 104-instruction modular
+// subtraction costs a sixth of a whole product, so Karatsuba (3 reductions + 5 linear operations per Fp2 product)
+// loses to schoolbook with the signs folded into operands (4 half-products + 2 reductions, no linear operation on a
+// result).  169 N + 169 multiply-adds + 13 quotient digits; the 64-bit columns absorb 15 products of 30-bit limbs, so
+// they are renormalized every floor(15 / (N + 1)) rows.
+template <int N>
+ECG_HD Fp fp_sumprod(const Fp (&a)[N], const Fp (&b)[N]) {
+    constexpr int ROWS = 15 / (N + 1);
+    static_assert(ROWS >= 1, "too many products per row for the 64-bit columns");
+    ECG_COUNT_MAD(169 * N + 182);
+    ECG_SCHED_FENCE();  // one sum at a time: interleaving independent sums multiplies the live column accumulators
+    u64 T[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) T[i] = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const u32 bi = b[k].l[i];
+            ecg_mad_row(T + i, a[k].l, bi);
+        }
+        const u32 m = ((u32)T[i] * blsc::N0) & FP_MASK;
+        ecg_mad_row_p(T + i, m);
+        T[i + 1] += T[i] >> 30;  // T[i] == 0 mod 2^30 now
+        if ((i + 1) % ROWS == 0 && i + 1 < FP_N) {
+#pragma unroll
+            for (int c = i + 1; c <= i + 12; c++) {
+                T[c + 1] += T[c] >> 30;
+                T[c] &= FP_MASK;
+            }
+        }
+    }
+    Fp r;
+#pragma unroll
+    for (int c = 13; c < 25; c++) {
+        T[c + 1] += T[c] >> 30;
+        r.l[c - 13] = (u32)T[c] & FP_MASK;
+    }
+    r.l[12] = (u32)T[25];
+    ECG_SCHED_FENCE();
+    return r;
+}
+ECG_HD Fp fp_sumprod2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1) {
+    const Fp a[2] = {a0, a1};
+    const Fp b[2] = {b0, b1};
+    return fp_sumprod<2>(a, b);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
 // The out-of-line call takes its operands as two 13-element vectors: clang's AMDGPU ABI gives a
 // function 16 argument registers for aggregates, so the second `Fp` struct of fp_mul(Fp, Fp) travelled
 // through the stack (13 dwords of scratch store + load per product); vectors are passed in VGPRs.
@@ -184,6 +341,9 @@ static __device__ __attribute__((noinline)) fp_vec13 fp_mul_call(fp_vec13 a, fp_
     for (int i = 0; i < FP_N; i++) o[i] = r.l[i];
     return o;
 }
+#if defined(ECG_FP_MUL_INLINE)
+ECG_HD Fp fp_mul(const Fp& a, const Fp& b) { return fp_mul_body(a, b); }  // experiment: no call at all
+#else
 ECG_HD Fp fp_mul(const Fp& a, const Fp& b) {
     fp_vec13 x, y;
 #pragma unroll
@@ -197,6 +357,7 @@ ECG_HD Fp fp_mul(const Fp& a, const Fp& b) {
     for (int i = 0; i < FP_N; i++) r.l[i] = o[i];
     return r;
 }
+#endif
 #else
 ECG_HD_NOINLINE Fp fp_mul(Fp a, Fp b) {
     ECG_COUNT_MUL();
@@ -373,24 +534,44 @@ ECG_HD Fp2 fp2_mul_fp(const Fp2& a, const Fp& k) { return Fp2{fp_mul(a.c0, k), f
 // a + b as a product operand (components < bound(a) + bound(b), see fp_add_lazy)
 ECG_HD Fp2 fp2_add_lazy(const Fp2& a, const Fp2& b) { return Fp2{fp_add_lazy(a.c0, b.c0), fp_add_lazy(a.c1, b.c1)}; }
 
-// Karatsuba: 3 Fp products.  Operand components may be lazy sums < 8p: the inner sums are then < 16p and
-// 16p x 16p = 256 p^2 < 632 p^2; every product comes back < 2p.
+// Two sums of two products, the minus sign of i^2 folded into a lazily negated operand: 4 half-products and 2
+// reductions, no linear operation on a result (Karatsuba's 3 products cost 5 of them: measured 9300 vs 6700 cycles,
+// profiles/r01zf_fpbench.txt).  Operand components may be lazy sums < 8p: each sum is below 2 * 8p * 8p = 128 p^2.
 ECG_HD Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
-    Fp t0 = fp_mul(a.c0, b.c0);
-    Fp t1 = fp_mul(a.c1, b.c1);
-    Fp t2 = fp_mul(fp_add_lazy(a.c0, a.c1), fp_add_lazy(b.c0, b.c1));
-    return Fp2{fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
+    const Fp nb1 = fp_neg_lazy<8>(b.c1);
+    return Fp2{fp_sumprod2(a.c0, b.c0, a.c1, nb1), fp_sumprod2(a.c0, b.c1, a.c1, b.c0)};
 }
-// (a0 + a1)(a0 - a1) + 2 a0 a1 i: 2 Fp products.  Operand components < 2p (a0 - a1 + 2p < 4p, a0 + a1 < 4p).
+// (a0 + a1)(a0 - a1) + (2 a0 a1) i: 2 Fp products.  Operand components < 4p (a0 - a1 + 4p < 8p, sums < 8p).
 ECG_HD Fp2 fp2_sqr(const Fp2& a) {
-    Fp t0 = fp_mul(fp_add_lazy(a.c0, a.c1), fp_sub_lazy(a.c0, a.c1));
-    Fp t1 = fp_mul(a.c0, a.c1);
-    return Fp2{t0, fp_dbl(t1)};
+    const Fp s[1] = {fp_add_lazy(a.c0, a.c1)}, d[1] = {fp_sub_lazy_k<4>(a.c0, a.c1)};
+    const Fp x[1] = {a.c0}, y[1] = {fp_add_lazy(a.c1, a.c1)};
+    return Fp2{fp_sumprod<1>(s, d), fp_sumprod<1>(x, y)};
 }
 ECG_HD Fp2 fp2_inv(const Fp2& a) {
     Fp d = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
     return Fp2{fp_mul(a.c0, d), fp_neg(fp_mul(a.c1, d))};
 }
+
+// Sum of M Fp2 products with two reductions in all: sum_k x_k y_k, where ny[k] = K p - y_k.c1 is handed in (a lazy
+// negation is shared by every sum the same y_k appears in).  Bound: the 2M half-products of each component must sum
+// below 632 p^2.
+template <int M>
+ECG_HD Fp2 fp2_sumprod(const Fp2 (&x)[M], const Fp2 (&y)[M], const Fp (&ny)[M]) {
+    Fp a[2 * M], br[2 * M], bi[2 * M];
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        a[2 * k] = x[k].c0;
+        a[2 * k + 1] = x[k].c1;
+        br[2 * k] = y[k].c0;  // re: xr yr - xi yi
+        br[2 * k + 1] = ny[k];
+        bi[2 * k] = y[k].c1;  // im: xr yi + xi yr
+        bi[2 * k + 1] = y[k].c0;
+    }
+    return Fp2{fp_sumprod<2 * M>(a, br), fp_sumprod<2 * M>(a, bi)};
+}
+// xi a = (a0 - a1) + (a0 + a1) i as a product operand: components < 2 K p for components of a < K p
+template <int K>
+ECG_HD Fp2 fp2_mul_xi_lazy(const Fp2& a) { return Fp2{fp_sub_lazy_k<K>(a.c0, a.c1), fp_add_lazy(a.c0, a.c1)}; }
 
 // Square root in Fp2 by the norm ("complex") method, given s with s^2 = norm(a) = a0^2 + a1^2 and a1 != 0.
 // ONE Fp exponentiation: with d = (a0 + s)/2, t = d^((p-3)/4) and c = t d, either c^2 = d (then x0 = c, 1/x0 = t) or

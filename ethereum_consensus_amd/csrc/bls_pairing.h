@@ -78,28 +78,41 @@ ECG_FP12_FN void miller_add_step(Fp12& f, MillerPair& m) {
 }
 
 // f = prod_k f_{|x|,Q_k}(P_k), conjugated (x < 0)
+// The accumulator is a local VALUE whose address never leaves this function (the five addition steps work on a copy):
+// it lives in VGPRs/AGPRs across the whole doubling iteration instead of making three round trips through the
+// private segment per bit.
 ECG_HD_NOINLINE void miller_loop(Fp12& f, MillerPair* pairs, int n) {
     fp12_set_one(f);
     bool any = false;
     for (int k = 0; k < n; k++) any = any || pairs[k].active;
     if (!any) return;
+    Fp12 acc;
+    fp12_set_one(acc);
     for (int b = 62; b >= 0; b--) {
-        if (b != 62) fp12_sqr(f, f);
+        if (b != 62) fp12_sqr(acc, acc);
         for (int k = 0; k < n; k++)
-            if (pairs[k].active) miller_dbl_step(f, pairs[k]);
+            if (pairs[k].active) miller_dbl_step(acc, pairs[k]);
         if ((blsc::X_ABS >> b) & 1)
             for (int k = 0; k < n; k++)
-                if (pairs[k].active) miller_add_step(f, pairs[k]);
+                if (pairs[k].active) {
+                    Fp12 t = acc;
+                    miller_add_step(t, pairs[k]);
+                    acc = t;
+                }
     }
-    fp12_conj(f, f);
+    fp12_conj(f, acc);
 }
 
 // a^x for a in the cyclotomic subgroup (x < 0: conjugate)
 ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
-    Fp12 acc = a;
+    Fp12 acc = a;  // a register-resident value: the squaring is inlined, the five products work on a copy
     for (int b = 62; b >= 0; b--) {
-        fp12_cyclotomic_sqr(acc, acc);
-        if ((blsc::X_ABS >> b) & 1) fp12_mul(acc, acc, a);
+        fp12_cyclotomic_sqr_inl(acc, acc);
+        if ((blsc::X_ABS >> b) & 1) {
+            Fp12 t = acc;
+            fp12_mul(t, t, a);
+            acc = t;
+        }
     }
     fp12_conj(r, acc);
 }

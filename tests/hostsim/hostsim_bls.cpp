@@ -15,7 +15,7 @@
 using namespace ecg;
 
 namespace ecg {
-unsigned long long g_ecg_fp_mul_count = 0, g_ecg_fp_sqr_count = 0;
+unsigned long long g_ecg_fp_mul_count = 0, g_ecg_fp_sqr_count = 0, g_ecg_fp_mad_count = 0, g_ecg_column_overflows = 0;
 }
 
 static Fp in_fp(const u8* b) { return fp_from_raw(raw_from_be48(b, false)); }
@@ -26,6 +26,20 @@ static void out_fp2(const Fp2& a, u8* b) {
     out_fp(a.c1, b + 48);
 }
 
+// Sum of n (1..8) products over RAW limb vectors (13 u32 each, no range reduction: the test chooses lazy operands up to
+// the documented bounds and worst-case limb patterns): out = 13 limbs of sum a_k b_k / R mod p (almost reduced).
+// Returns the number of 64-bit column overflows the host arithmetic detected since the last call (must be 0).
+template <int N>
+static void sumprod_raw(const u32* a, const u32* b, u32* out) {
+    Fp x[N], y[N];
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < 13; i++) {
+            x[k].l[i] = a[13 * k + i];
+            y[k].l[i] = b[13 * k + i];
+        }
+    const Fp r = fp_sumprod<N>(x, y);
+    for (int i = 0; i < 13; i++) out[i] = r.l[i];
+}
 extern "C" {
 
 // op: 0 mul 1 add 2 sub 3 neg 4 inv 5 sqrt(returns 1 if square) 6 sqr 7 lex_largest 8 dbl 9 is_zero 10 eq
@@ -227,15 +241,17 @@ void hs_pairing(int n, const u8* p_xy, const int* p_inf, const u8* q_xy, const i
     out_fp12(e, out);
 }
 
-// Fp product census of the stages of one K = 1 verification (valid inputs): out[2*s] = fp_mul calls,
-// out[2*s+1] = fp_sqr calls for s = pk_validate, sig (decode + group check), hash_to_g2, pairing.
+// Multiplier census of the stages of one K = 1 verification (valid inputs): out[3*s] = fp_mul calls, out[3*s+1] = fp_sqr
+// calls, out[3*s+2] = multiply instructions inside sums of products, for s = pk_validate, sig (decode + group check),
+// hash_to_g2, pairing.
 void hs_op_census(const u8* pk48, const u8* msg, u64 msg_len, const u8* sig96, u64* out) {
     auto snap = [&](int s) {
-        out[2 * s] = g_ecg_fp_mul_count;
-        out[2 * s + 1] = g_ecg_fp_sqr_count;
-        g_ecg_fp_mul_count = g_ecg_fp_sqr_count = 0;
+        out[3 * s] = g_ecg_fp_mul_count;
+        out[3 * s + 1] = g_ecg_fp_sqr_count;
+        out[3 * s + 2] = g_ecg_fp_mad_count;
+        g_ecg_fp_mul_count = g_ecg_fp_sqr_count = g_ecg_fp_mad_count = 0;
     };
-    g_ecg_fp_mul_count = g_ecg_fp_sqr_count = 0;
+    g_ecg_fp_mul_count = g_ecg_fp_sqr_count = g_ecg_fp_mad_count = 0;
     A1 p;
     stage_pk_validate(p, pk48);
     snap(0);
@@ -275,10 +291,28 @@ int hs_vm2_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
     return fp12_is_one(e) ? 1 : 0;
 }
 
-void hs_census_reset() { g_ecg_fp_mul_count = g_ecg_fp_sqr_count = 0; }
+u64 hs_sumprod_raw(int n, const u32* a, const u32* b, u32* out) {
+    g_ecg_column_overflows = 0;
+    switch (n) {
+        case 1: sumprod_raw<1>(a, b, out); break;
+        case 2: sumprod_raw<2>(a, b, out); break;
+        case 3: sumprod_raw<3>(a, b, out); break;
+        case 4: sumprod_raw<4>(a, b, out); break;
+        case 5: sumprod_raw<5>(a, b, out); break;
+        case 6: sumprod_raw<6>(a, b, out); break;
+        case 7: sumprod_raw<7>(a, b, out); break;
+        case 8: sumprod_raw<8>(a, b, out); break;
+        default: return ~0ull;
+    }
+    return g_ecg_column_overflows;
+}
+u64 hs_column_overflows() { return g_ecg_column_overflows; }
+
+void hs_census_reset() { g_ecg_fp_mul_count = g_ecg_fp_sqr_count = g_ecg_fp_mad_count = 0; }
 void hs_census_read(u64* out) {
     out[0] = g_ecg_fp_mul_count;
     out[1] = g_ecg_fp_sqr_count;
+    out[2] = g_ecg_fp_mad_count;
 }
 
 int hs_fast_aggregate_verify(const u8* pks48, u32 k, const u8* msg, u64 msg_len, const u8* sig96, int eth) {

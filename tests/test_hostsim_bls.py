@@ -78,6 +78,54 @@ def test_fp_arithmetic_and_lazy_range():
         assert int.from_bytes(out.raw, "big") == x
 
 
+def _limbs(v):
+    return [(v >> (30 * i)) & 0x3FFFFFFF if i < 12 else v >> 360 for i in range(13)]
+
+
+def _sumprod(avals, bvals):
+    n = len(avals)
+    arr = (ctypes.c_uint32 * (13 * n))
+    a = arr(*[w for v in avals for w in _limbs(v)])
+    b = arr(*[w for v in bvals for w in _limbs(v)])
+    out = (ctypes.c_uint32 * 13)()
+    L = lib()
+    L.hs_sumprod_raw.restype = ctypes.c_uint64
+    ov = L.hs_sumprod_raw(n, a, b, out)
+    return ov, sum(int(out[i]) << (30 * i) for i in range(13))
+
+
+def test_sum_of_products_lazy_bounds_and_column_headroom():
+    """fp_sumprod<N>: one Montgomery reduction for N products of lazy operands.  Result < 2p and == sum a b / R whenever
+    the sum is below R p (632 p^2); the 64-bit columns never overflow, even for saturated 30-bit limbs."""
+    r = random.Random(77)
+    RINV = pow(1 << 390, -1, P)
+    for n in range(1, 9):
+        # operands at the top of the lazy range: n products of (k p - small) values with n k^2 < 632
+        k = 1
+        while n * (k + 1) ** 2 < 632 and k < 16:
+            k += 1
+        for _ in range(40):
+            av = [k * P - 1 - r.randrange(1 << r.choice([1, 64, 380])) for _ in range(n)]
+            bv = [k * P - 1 - r.randrange(1 << r.choice([1, 64, 380])) for _ in range(n)]
+            ov, res = _sumprod(av, bv)
+            assert ov == 0
+            assert res < 2 * P
+            assert res % P == sum(x * y for x, y in zip(av, bv)) * RINV % P
+        # random reduced operands
+        for _ in range(40):
+            av = [r.randrange(2 * P) for _ in range(n)]
+            bv = [r.randrange(2 * P) for _ in range(n)]
+            ov, res = _sumprod(av, bv)
+            assert ov == 0 and res < 2 * P
+            assert res % P == sum(x * y for x, y in zip(av, bv)) * RINV % P
+        # worst-case limb pattern: every low limb saturated, top limb at the 16p ceiling (the value bound is violated
+        # on purpose: only the column headroom is under test)
+        sat = sum(0x3FFFFFFF << (30 * i) for i in range(12)) + ((16 * P) >> 360 << 360)
+        ov, _res = _sumprod([sat] * n, [sat] * n)
+        assert ov == 0
+    assert lib().hs_column_overflows() == 0
+
+
 def test_fp2_arithmetic():
     r = random.Random(2)
     v2 = [(0, 0), (1, 0), (0, 1), (P - 1, 0), (0, P - 1), (5, 0), (0, 7)] + [(r.randrange(P), r.randrange(P)) for _ in range(60)]

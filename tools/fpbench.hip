@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "bls_fp.h"
+#include "bls_pairing.h"
 #include "sha256.h"
 using namespace ecg;
 
@@ -77,6 +77,175 @@ __global__ void __launch_bounds__(64) k_bench(const Fp* in, Fp* out) {
         }
     }
     out[t] = fp_add(x, y);
+}
+
+
+// the round-1 forms, kept here for comparison: Karatsuba over reduced Fp products (out-of-line calls)
+static __device__ __forceinline__ Fp2 fp2_mul_karatsuba(const Fp2& a, const Fp2& b) {
+    Fp t0 = fp_mul(a.c0, b.c0);
+    Fp t1 = fp_mul(a.c1, b.c1);
+    Fp t2 = fp_mul(fp_add_lazy(a.c0, a.c1), fp_add_lazy(b.c0, b.c1));
+    return Fp2{fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
+}
+static __device__ __forceinline__ void fp6_mul_karatsuba(Fp6& r, const Fp2& a0, const Fp2& a1, const Fp2& a2, const Fp2& b0, const Fp2& b1,
+                                                         const Fp2& b2) {
+    Fp2 t0 = fp2_mul_karatsuba(a0, b0);
+    Fp2 t1 = fp2_mul_karatsuba(a1, b1);
+    Fp2 t2 = fp2_mul_karatsuba(a2, b2);
+    Fp2 m12 = fp2_mul_karatsuba(fp2_add_lazy(a1, a2), fp2_add_lazy(b1, b2));
+    Fp2 m01 = fp2_mul_karatsuba(fp2_add_lazy(a0, a1), fp2_add_lazy(b0, b1));
+    Fp2 m02 = fp2_mul_karatsuba(fp2_add_lazy(a0, a2), fp2_add_lazy(b0, b2));
+    r.c0 = fp2_add(t0, fp2_mul_xi(fp2_sub(fp2_sub(m12, t1), t2)));
+    r.c1 = fp2_add(fp2_sub(fp2_sub(m01, t0), t1), fp2_mul_xi(t2));
+    r.c2 = fp2_add(fp2_sub(fp2_sub(m02, t0), t2), t1);
+}
+// Fp6 product chain: OP 0 = Karatsuba over out-of-line Fp products (round-1 form), 1 = schoolbook with lazy reduction
+template <int OP>
+__global__ void __launch_bounds__(64) k_bench6(const Fp* in, Fp* out) {
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    Fp6 x, y;
+    Fp* xs = (Fp*)&x;
+    Fp* ys = (Fp*)&y;
+    for (int k = 0; k < 6; k++) {
+        xs[k] = in[(t + k) & 63];
+        ys[k] = in[(t + 11 * k + 5) & 63];
+    }
+    for (int i = 0; i < ITERS / 4; i++) {
+        if (OP == 0) fp6_mul_karatsuba(x, x.c0, x.c1, x.c2, y.c0, y.c1, y.c2);
+        if (OP == 1) fp6_mul_lazy<2, 2>(x, x.c0, x.c1, x.c2, y.c0, y.c1, y.c2);
+        if (OP == 2) {  // Fp2 product by two sums of two products
+            x.c0 = fp2_mul(x.c0, y.c0);
+        }
+        if (OP == 3) {
+            x.c0 = fp2_mul_karatsuba(x.c0, y.c0);
+        }
+        if (OP == 4) {  // one product through the sum-of-products body (instruction-level multiply-adds)
+            const Fp a[1] = {x.c0.c0}, b[1] = {y.c0.c0};
+            x.c0.c0 = fp_sumprod<1>(a, b);
+        }
+    }
+    Fp acc = xs[0];
+    for (int k = 1; k < 6; k++) acc = fp_add(acc, xs[k]);
+    out[t] = acc;
+}
+template <int OP>
+void run6(const char* name, double mults_per_iter, const Fp* d_in, Fp* d_out) {
+    for (int wps : {1, 2}) {
+        const int blocks = 256 * 4 * wps;
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipLaunchKernelGGL(k_bench6<OP>, dim3(blocks), dim3(64), 0, 0, d_in, d_out);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k_bench6<OP>, dim3(blocks), dim3(64), 0, 0, d_in, d_out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        const double us_per_op = ms * 1e3 / (ITERS / 4) / wps;
+        printf("%-34s waves/SIMD %d  %8.3f ms  %7.3f us SIMD-time per wave-iteration  (%.0f cycles @2.4GHz)  %6.2f T mult/s\n", name, wps, ms,
+               us_per_op, us_per_op * 2400, mults_per_iter * (ITERS / 4) * blocks * 64.0 / (ms * 1e-3) / 1e12);
+    }
+}
+
+// G2 doubling chain: OP 0 = through the out-of-line jac_dbl<Fp2> (references to private memory, as the kernels call it),
+// 1 = the same formulas inlined into the loop
+template <int OP>
+__global__ void __launch_bounds__(64) k_bench_dbl(const Fp* in, Fp* out) {
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    J2 p;
+    Fp* ps = (Fp*)&p;
+    for (int k = 0; k < 6; k++) ps[k] = in[(t + 3 * k) & 63];
+    for (int i = 0; i < ITERS / 8; i++) {
+        if (OP == 0) jac_dbl(p, p);
+        if (OP == 1) {
+            Fp2 A = fp2_sqr(p.x), B = fp2_sqr(p.y), C = fp2_sqr(B);
+            Fp2 D = fp2_dbl(fp2_sub(fp2_sub(fp2_sqr(fp2_add(p.x, B)), A), C));
+            Fp2 E = fp2_add(fp2_dbl(A), A), Fq = fp2_sqr(E);
+            Fp2 Z3 = fp2_dbl(fp2_mul(p.y, p.z)), X3 = fp2_sub(Fq, fp2_dbl(D));
+            Fp2 C8 = fp2_dbl(fp2_dbl(fp2_dbl(C)));
+            p.y = fp2_sub(fp2_mul(E, fp2_sub(D, X3)), C8);
+            p.x = X3;
+            p.z = Z3;
+        }
+    }
+    Fp acc = ps[0];
+    for (int k = 1; k < 6; k++) acc = fp_add(acc, ps[k]);
+    out[t] = acc;
+}
+template <int OP>
+void run_dbl(const char* name, const Fp* d_in, Fp* d_out) {
+    for (int wps : {1, 2}) {
+        const int blocks = 256 * 4 * wps;
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipLaunchKernelGGL(k_bench_dbl<OP>, dim3(blocks), dim3(64), 0, 0, d_in, d_out);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k_bench_dbl<OP>, dim3(blocks), dim3(64), 0, 0, d_in, d_out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        const double us_per_op = ms * 1e3 / (ITERS / 8) / wps;
+        printf("%-34s waves/SIMD %d  %8.3f ms  %7.3f us SIMD-time per wave-iteration  (%.0f cycles @2.4GHz)\n", name, wps, ms, us_per_op,
+               us_per_op * 2400);
+    }
+}
+
+// Fp12-level operations of the pairing on a register-resident accumulator (everything inlined into the loop)
+template <int OP>
+__global__ void __launch_bounds__(64) k_bench12(const Fp* in, Fp* out) {
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    Fp12 f, g;
+    Fp* fs = (Fp*)&f;
+    Fp* gs = (Fp*)&g;
+    for (int k = 0; k < 12; k++) {
+        fs[k] = in[(t + k) & 63];
+        gs[k] = in[(t + 5 * k + 1) & 63];
+    }
+    MillerPair m;
+    m.px = in[t & 63];
+    m.py = in[(t + 1) & 63];
+    m.qx = g.c0.c0;
+    m.qy = g.c0.c1;
+    m.t.x = g.c0.c2;
+    m.t.y = g.c1.c0;
+    m.t.z = g.c1.c1;
+    m.active = 1;
+    for (int i = 0; i < ITERS / 16; i++) {
+        if (OP == 0) fp12_sqr(f, f);
+        if (OP == 1) fp12_mul(f, f, g);
+        if (OP == 2) fp12_mul_by_line(f, g.c0.c0, g.c0.c1, g.c0.c2);
+        if (OP == 3) fp12_cyclotomic_sqr(f, f);
+        if (OP == 4) miller_dbl_step(f, m);
+    }
+    Fp acc = fs[0];
+    for (int k = 1; k < 12; k++) acc = fp_add(acc, fs[k]);
+    acc = fp_add(acc, m.t.x.c0);
+    out[t] = acc;
+}
+template <int OP>
+void run12(const char* name, double mults, const Fp* d_in, Fp* d_out) {
+    for (int wps : {1}) {
+        const int blocks = 256 * 4 * wps;
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipLaunchKernelGGL(k_bench12<OP>, dim3(blocks), dim3(64), 0, 0, d_in, d_out);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k_bench12<OP>, dim3(blocks), dim3(64), 0, 0, d_in, d_out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        const double us_per_op = ms * 1e3 / (ITERS / 16) / wps;
+        printf("%-34s waves/SIMD %d  %8.3f ms  %7.3f us SIMD-time per wave-iteration  (%.0f cycles @2.4GHz)  %6.2f T mult/s\n", name, wps, ms,
+               us_per_op, us_per_op * 2400, mults * (ITERS / 16) * blocks * 64.0 / (ms * 1e-3) / 1e12);
+    }
 }
 
 // hash64 chain in registers: the unit of the Merkle roofline
@@ -156,5 +325,17 @@ int main() {
     run<6>("fp2_sqr (dual call)", 702, 0, d_in, d_out);
     run<7>("fp2_mul (3 calls)", 1053, 0, d_in, d_out);
     run<8>("fp2_mul (LDS-arg call)", 1053, 0, d_in, d_out);
+    run12<0>("fp12_sqr (registers)", 2 * (36 * 169 + 6 * 195), d_in, d_out);
+    run12<1>("fp12_mul (registers / call)", 3 * (36 * 169 + 6 * 195), d_in, d_out);
+    run12<2>("fp12_mul_by_line (registers)", 72 * 169 + 12 * 195, d_in, d_out);
+    run12<3>("fp12_cyclotomic_sqr (call)", 3 * (10 * 169 + 4 * 195), d_in, d_out);
+    run12<4>("miller_dbl_step incl. line mul", 0, d_in, d_out);
+    run_dbl<0>("G2 doubling (out-of-line jac_dbl)", d_in, d_out);
+    run_dbl<1>("G2 doubling (inline formulas)", d_in, d_out);
+    run6<4>("fp_mul as fp_sumprod<1> (inline)", 364, d_in, d_out);
+    run6<3>("fp2_mul Karatsuba (3 calls)", 1053 + 39, d_in, d_out);
+    run6<2>("fp2_mul 2 sums of 2 products", 1040 + 26, d_in, d_out);
+    run6<0>("fp6_mul Karatsuba (18 calls)", 18 * 364, d_in, d_out);
+    run6<1>("fp6_mul schoolbook lazy (6 sums)", 36 * 169 + 6 * 195, d_in, d_out);
     return 0;
 }
