@@ -147,10 +147,13 @@ def run_merkle(args, L, torch, dist, rank, world):
 
 
 R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-# Fp products of ONE K = 1 verification, counted on the lane programs themselves
-# (tests/hostsim hs_op_census, valid tuple): (fp_mul, fp_sqr) per stage.  A product is 351 (273 for
-# a square) quarter-rate integer multiplies (v_mad_u64_u32 / v_mul_lo_u32), see csrc/bls_fp.h.
-BLS_OPS = {"bls_pk_validate": (485, 1064), "bls_sig": (1476, 756), "bls_h2c": (3838, 3163), "bls_pairing": (19643, 382)}
+# Integer multiplies of ONE K = 1 verification, counted on the lane programs themselves (tests/hostsim hs_op_census, valid
+# tuple): (fp_mul calls, fp_sqr calls, multiplies inside sums of products) per stage.  An Fp product is 351 (273 for a
+# square) multiply instructions (v_mad_u64_u32 / v_mul_lo_u32), a sum of N products with one reduction 169 N + 182, see
+# csrc/bls_fp.h.
+BLS_OPS = {"bls_pk_validate": (485, 1064, 0), "bls_sig": (218, 756, 439088), "bls_h2c": (875, 3037, 1021020),
+           "bls_pairing": (651, 382, 7239674)}
+BLS_MULTS_PER_SIG = sum(m * 351 + s * 273 + x for m, s, x in BLS_OPS.values())
 BLS_BYTES_PER_SIG = 48 + 32 + 96 + 1  # K = 1 tuple in, status byte out
 
 
@@ -266,7 +269,7 @@ def run_bls(args, L, torch, dist, rank, world):
     kern_ms = stages[dom]
     alg_bytes = BLS_BYTES_PER_SIG * n
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    mul_ops = {k: (m * 351 + s * 273) * n for k, (m, s) in BLS_OPS.items()}
+    mul_ops = {k: (m * 351 + s * 273 + x) * n for k, (m, s, x) in BLS_OPS.items()}
     return dict(
         dt=dt, units_per_step=n, metric="bls_signatures_verified_per_sec", unit="sigs/s", dtype="u32",
         config={"workload": f"fast_aggregate_verify of {n} synthetic (pk, msg, sig) tuples, K = 1, 32-byte messages, "
@@ -279,7 +282,8 @@ def run_bls(args, L, torch, dist, rank, world):
                   "avg_launch_ms": kern_ms, "stage_ms": stages,
                   "valu_int": {"unit": "T multiplies/s (v_mad_u64_u32 + v_mul_lo_u32)", "peak": MUL_PIPE_PEAK_TOPS,
                                "achieved": {k: (mul_ops[k] / (stages[k] * 1e-3) / 1e12 if stages[k] > 0 else 0.0) for k in stages},
-                               "note": "the path is integer-multiplier bound, not HBM bound: 10.6 M multiplies vs 177 B per signature"}},
+                               "note": f"the path is integer-multiplier bound, not HBM bound: {BLS_MULTS_PER_SIG / 1e6:.1f} M multiplies vs 177 B per "
+                                       "signature"}},
         check={"statuses_match_construction": ok, "expected_failures": int(want.astype(bool).sum())},
     )
 

@@ -221,6 +221,14 @@ __global__ void __launch_bounds__(64) k_bench12(const Fp* in, Fp* out) {
         if (OP == 2) fp12_mul_by_line(f, g.c0.c0, g.c0.c1, g.c0.c2);
         if (OP == 3) fp12_cyclotomic_sqr(f, f);
         if (OP == 4) miller_dbl_step(f, m);
+        if (OP == 5) {  // fp12_mul with everything inlined, operands in registers
+            Fp6 t0, t1, mm;
+            fp6_mul(t0, f.c0, g.c0);
+            fp6_mul(t1, f.c1, g.c1);
+            fp6_mul_sums(mm, f.c0, f.c1, g.c0, g.c1);
+            fp12_karatsuba_combine(f.c0, f.c1, mm, t0, t1);
+        }
+        if (OP == 6) fp12_cyclotomic_sqr_inl(f, f);
     }
     Fp acc = fs[0];
     for (int k = 1; k < 12; k++) acc = fp_add(acc, fs[k]);
@@ -327,6 +335,8 @@ int main() {
     run<8>("fp2_mul (LDS-arg call)", 1053, 0, d_in, d_out);
     run12<0>("fp12_sqr (registers)", 2 * (36 * 169 + 6 * 195), d_in, d_out);
     run12<1>("fp12_mul (registers / call)", 3 * (36 * 169 + 6 * 195), d_in, d_out);
+    run12<5>("fp12_mul (registers, inlined)", 3 * (36 * 169 + 6 * 195), d_in, d_out);
+    run12<6>("fp12_cyclotomic_sqr (inlined)", 3 * (10 * 169 + 4 * 195), d_in, d_out);
     run12<2>("fp12_mul_by_line (registers)", 72 * 169 + 12 * 195, d_in, d_out);
     run12<3>("fp12_cyclotomic_sqr (call)", 3 * (10 * 169 + 4 * 195), d_in, d_out);
     run12<4>("miller_dbl_step incl. line mul", 0, d_in, d_out);
