@@ -47,6 +47,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_merkleize_dev": (c_int, [u8p, c_u64, c_u64, c_int, c_u64, u8p, ctypes.c_void_p]),
         "ecgpu_htr_validators": (c_int, [u8p, c_u64, c_u64, u8p]),
         "ecgpu_htr_validators_dev": (c_int, [u8p, c_u64, c_u64, u8p, ctypes.c_void_p]),
+        "ecgpu_validators_subtree_root": (c_int, [u8p, c_u64, c_u64, u8p]),
+        "ecgpu_validators_subtree_root_dev": (c_int, [u8p, c_u64, c_u64, u8p, ctypes.c_void_p]),
+        "ecgpu_merkleize_subtree_roots": (c_int, [u8p, c_u32, c_u64, c_u64, c_int, c_u64, u8p]),
+        "ecgpu_merkleize_subtree_roots_dev": (c_int, [u8p, c_u32, c_u64, c_u64, c_int, c_u64, u8p, ctypes.c_void_p]),
         "ecgpu_htr_beacon_block_header": (c_int, [u8p, u8p]),
         "ecgpu_signing_root": (c_int, [u8p, u8p, u8p]),
         "ecgpu_is_valid_merkle_branch": (c_int, [u8p, u8p, c_u32, c_u64, u8p]),

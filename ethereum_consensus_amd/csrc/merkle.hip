@@ -416,8 +416,7 @@ int ecgpu_htr_validators(const uint8_t* ssz121, uint64_t n, uint64_t limit, uint
     return merkleize_host(LEAF_VALIDATORS, ssz121, n * 121, n, ceil_log2_u64(limit), true, n, root);
 }
 
-int ecgpu_htr_validators_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t limit, uint8_t* d_root,
-                             ecgpu_stream_t stream) {
+static int validators_tree_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t limit, bool mix, uint8_t* d_root, ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
     if (n > limit) return ECGPU_ERR_BAD_ARG;
@@ -429,9 +428,76 @@ int ecgpu_htr_validators_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t limit
     if (rc) return rc;
     u8* ws = ar.take(merkle_ws_bytes(n));
     u64 hc = 0;
-    rc = merkleize_device(s, LEAF_VALIDATORS, d_ssz121, n * 121, n, ceil_log2_u64(limit), true, n, d_root, ws, &hc);
+    rc = merkleize_device(s, LEAF_VALIDATORS, d_ssz121, n * 121, n, ceil_log2_u64(limit), mix, n, d_root, ws, &hc);
     c->last_hash64 = hc;
     return rc;
+}
+
+int ecgpu_htr_validators_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t limit, uint8_t* d_root,
+                             ecgpu_stream_t stream) {
+    return validators_tree_dev(d_ssz121, n, limit, true, d_root, stream);
+}
+
+// One shard's share of a sharded validator list: the root of the aligned subtree of `width` leaves, no length mix-in.
+int ecgpu_validators_subtree_root(const uint8_t* ssz121, uint64_t n, uint64_t width, uint8_t root[32]) {
+    if ((!ssz121 && n) || !root || n > width || (width & (width - 1)) || !width) return ECGPU_ERR_BAD_ARG;
+    return merkleize_host(LEAF_VALIDATORS, ssz121, n * 121, n, ceil_log2_u64(width), false, 0, root);
+}
+
+int ecgpu_validators_subtree_root_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t width, uint8_t* d_root,
+                                      ecgpu_stream_t stream) {
+    if ((width & (width - 1)) || !width) return ECGPU_ERR_BAD_ARG;
+    return validators_tree_dev(d_ssz121, n, width, false, d_root, stream);
+}
+
+// Top of a sharded list: n_sub sub-roots of aligned `width`-leaf subtrees -> root of the `limit`-leaf tree.  One finishing
+// job: the nodes enter at level log2(width), so odd tails pair with the zero hashes of THAT level upwards.
+static int subtree_roots_job(hipStream_t s, const u8* d_nodes, u32 n_sub, u64 width, u64 limit, bool mix, u64 len, u8* d_root) {
+    if (!width || (width & (width - 1)) || n_sub > TREEJOB_MAX_NODES || limit % width || (u64)n_sub > limit / width) {
+        set_last_error("sub-roots: width must be a power of two dividing the limit, at most 512 sub-roots");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    TreeJob job;
+    job.in_off = 0;
+    job.out_off = (u64)((uintptr_t)d_root - (uintptr_t)d_nodes);
+    job.n = n_sub;
+    job.level = ceil_log2_u64(width);
+    job.depth = ceil_log2_u64(limit);
+    job.mix = mix ? 1 : 0;
+    job.mix_len = len;
+    ProfScope ps("merkle_tree_job", s);
+    hipLaunchKernelGGL(k_tree_job1, dim3(1), dim3(JOB_BLOCK), 0, s, job, const_cast<u8*>(d_nodes), device_zero_table());
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
+int ecgpu_merkleize_subtree_roots(const uint8_t* sub_roots, uint32_t n_sub, uint64_t width, uint64_t limit, int mix_in_len,
+                                  uint64_t len, uint8_t root[32]) {
+    if ((!sub_roots && n_sub) || !root) return ECGPU_ERR_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    rc = ar.reserve(32ull * n_sub + 1024);
+    if (rc) return rc;
+    u8* d_in = ar.take(32ull * n_sub + 32);
+    u8* d_root = ar.take(32);
+    if (n_sub) ECG_HIP_CHECK(hipMemcpyAsync(d_in, sub_roots, 32ull * n_sub, hipMemcpyHostToDevice, s));
+    rc = subtree_roots_job(s, d_in, n_sub, width, limit, mix_in_len != 0, len, d_root);
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ECGPU_SUCCESS;
+}
+
+int ecgpu_merkleize_subtree_roots_dev(const uint8_t* d_sub_roots, uint32_t n_sub, uint64_t width, uint64_t limit,
+                                      int mix_in_len, uint64_t len, uint8_t* d_root, ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    ThreadCtx* c = tctx();
+    return subtree_roots_job(c->stream_or_own(stream), d_sub_roots, n_sub, width, limit, mix_in_len != 0, len, d_root);
 }
 
 int ecgpu_htr_beacon_block_header(const uint8_t ssz112[112], uint8_t root[32]) {

@@ -39,3 +39,36 @@ def all_gather_ragged(dist, local, n_total: int, world: int):
         lo, hi = shard_range(n_total, r, world)
         parts.append(g[r * width:r * width + (hi - lo)])
     return torch.cat(parts)
+
+
+def subtree_width(n_total: int, world: int) -> int:
+    """Leaves per rank when one big list is sharded: the smallest power of two W with W * world >=
+    n_total, so that every rank owns one aligned subtree (ranks past the end own an all-zero subtree)."""
+    per = max(1, -(-n_total // world))
+    return 1 << (per - 1).bit_length()
+
+
+def subtree_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """[lo, hi) of the leaves rank `rank` owns under subtree_width."""
+    w = subtree_width(n_total, world)
+    return min(rank * w, n_total), min((rank + 1) * w, n_total)
+
+
+def sharded_list_root(dist, n_total: int, limit: int, sub_root, top, mix_in_length=None) -> bytes:
+    """Root of one list whose leaves are sharded by subtree_range.  `sub_root(width) -> 32 bytes` is this rank's aligned
+    subtree (no length mix-in); `top(sub_roots, width, limit, mix_in_length)` climbs the top log2(world) levels and the
+    zero-hash ladder to the list limit and mixes the length in -- redundantly on every rank, after the path's only
+    exchange: an all-gather of the 32-byte sub-roots."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    w = subtree_width(n_total, world)
+    if limit % w:
+        raise ValueError("list limit is not a multiple of the shard width")
+    mine = sub_root(w)
+    if world > 1:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.frombuffer(bytearray(mine), dtype=torch.uint8).to(dev)
+        roots = bytes(all_gather_bytes(dist, t, world).cpu().numpy())
+    else:
+        roots = mine
+    return top(roots, w, limit, mix_in_length)

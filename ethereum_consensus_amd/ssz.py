@@ -54,6 +54,39 @@ def hash_tree_root_validators(ssz121: bytes, limit: int = VALIDATOR_REGISTRY_LIM
     return _root(L.ecgpu_htr_validators, _buf(ssz121), len(ssz121) // 121, limit)
 
 
+def validators_subtree_root(ssz121: bytes, width: int) -> bytes:
+    """One shard's share of a sharded `List<Validator, N>`: root of the aligned subtree of `width`
+    validators (a power of two), no length mix-in."""
+    if len(ssz121) % 121:
+        raise MerkleizationError("validator encoding is not a multiple of 121 bytes")
+    L = _lib.load()
+    return _root(L.ecgpu_validators_subtree_root, _buf(ssz121), len(ssz121) // 121, width)
+
+
+def merkleize_subtree_roots(sub_roots: bytes, width: int, limit: int, mix_in_length: int | None = None) -> bytes:
+    """Top of a sharded list: sub-roots of aligned `width`-leaf subtrees -> root of the `limit`-leaf tree [+ length]."""
+    L = _lib.load()
+    return _root(L.ecgpu_merkleize_subtree_roots, _buf(sub_roots), len(sub_roots) // 32, width, limit,
+                 0 if mix_in_length is None else 1, mix_in_length or 0)
+
+
+def hash_tree_root_validators_sharded(dist, ssz121_local: bytes, n_total: int, limit: int = VALIDATOR_REGISTRY_LIMIT) -> bytes:
+    """hash_tree_root(List<Validator, limit>) of a registry sharded over the ranks of `dist` (torch.distributed, one
+    process per GPU): rank r holds validators [r W, (r + 1) W) with W = shard.subtree_width(n_total, world).  One
+    all-gather of 32-byte sub-roots, then every rank finishes the top of the tree."""
+    from . import shard
+    return shard.sharded_list_root(dist, n_total, limit, lambda w: validators_subtree_root(ssz121_local, w),
+                                   merkleize_subtree_roots, mix_in_length=n_total)
+
+
+def merkleize_sharded(dist, data_local: bytes, n_chunks_total: int, limit_chunks: int, mix_in_length: int | None = None) -> bytes:
+    """`merkleize(pack(data), limit_chunks)` [+ mix_in_length] of a packed basic list (balances, participation,
+    inactivity scores) whose chunks are sharded like `hash_tree_root_validators_sharded` shards validators."""
+    from . import shard
+    return shard.sharded_list_root(dist, n_chunks_total, limit_chunks, lambda w: merkleize(data_local, w),
+                                   merkleize_subtree_roots, mix_in_length=mix_in_length)
+
+
 def hash_tree_root_beacon_block_header(ssz112: bytes) -> bytes:
     if len(ssz112) != 112:
         raise MerkleizationError("BeaconBlockHeader encoding must be 112 bytes")

@@ -70,6 +70,19 @@ int ecgpu_merkleize_dev(const uint8_t* d_data, uint64_t n_bytes, uint64_t limit_
 int ecgpu_htr_validators(const uint8_t* ssz121, uint64_t n, uint64_t limit, uint8_t root[32]);
 int ecgpu_htr_validators_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t limit, uint8_t* d_root,
                              ecgpu_stream_t stream);
+/* Multi-GPU sharding of one big list: rank g owns the aligned subtree of `width` (a power of two)
+ * leaves starting at g * width.  ecgpu_validators_subtree_root is that subtree's root for validator records --
+ * `merkleize(validator roots, width)` without the length mix-in; packed basic lists (balances, participation) use
+ * ecgpu_merkleize[_dev] with limit_chunks = width and mix_in_len = 0.  The ranks all-gather their 32-byte sub-roots and
+ * each finishes with ecgpu_merkleize_subtree_roots: n_sub (<= 512) nodes entering at level log2(width) -- odd tails pair
+ * with the zero hashes of that level upwards --, climbed to the `limit`-leaf root, then mix_in_length(len). */
+int ecgpu_validators_subtree_root(const uint8_t* ssz121, uint64_t n, uint64_t width, uint8_t root[32]);
+int ecgpu_validators_subtree_root_dev(const uint8_t* d_ssz121, uint64_t n, uint64_t width, uint8_t* d_root,
+                                      ecgpu_stream_t stream);
+int ecgpu_merkleize_subtree_roots(const uint8_t* sub_roots, uint32_t n_sub, uint64_t width, uint64_t limit, int mix_in_len,
+                                  uint64_t len, uint8_t root[32]);
+int ecgpu_merkleize_subtree_roots_dev(const uint8_t* d_sub_roots, uint32_t n_sub, uint64_t width, uint64_t limit,
+                                      int mix_in_len, uint64_t len, uint8_t* d_root, ecgpu_stream_t stream);
 
 /* hash_tree_root(BeaconBlockHeader) from its 112-byte SSZ encoding (phase0/beacon_block.rs:83-91;
  * called at phase0/slot_processing.rs:75, block_processing.rs:579). */

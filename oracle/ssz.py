@@ -69,6 +69,23 @@ def merkleize_bytes(data: bytes, limit_chunks: int | None = None) -> bytes:
     return merkleize_chunks(chunks, limit_chunks)
 
 
+def merkleize_subtree_roots(sub_roots: Sequence[bytes], width: int, limit: int) -> bytes:
+    """Top of a tree whose first levels were reduced elsewhere (sharded lists): `sub_roots` are the roots
+    of consecutive aligned `width`-leaf subtrees; climb from level log2(width) to the `limit`-leaf root, odd tails
+    pairing with the zero hash of their own level."""
+    level, depth = _depth_for(width), _depth_for(limit)
+    assert width == 1 << level and len(sub_roots) * width <= max(limit, 1)
+    if not sub_roots:
+        return ZERO_HASHES[depth]
+    layer = list(sub_roots)
+    for d in range(level, depth):
+        if len(layer) & 1:
+            layer.append(ZERO_HASHES[d])
+        layer = [hash64(layer[i], layer[i + 1]) for i in range(0, len(layer), 2)]
+    assert len(layer) == 1
+    return layer[0]
+
+
 def mix_in_length(root: bytes, length: int) -> bytes:
     return hash64(root, length.to_bytes(32, "little"))
 

@@ -250,3 +250,37 @@ def test_concurrent_calls_from_several_host_threads(gpu):
     for x in th:
         x.join()
     assert not errors, errors
+
+
+def test_sharded_big_lists_equal_the_unsharded_roots(gpu):
+    """validators / packed lists cut into aligned subtrees (one per rank), sub-roots combined by the
+    top-of-tree call -- here the "ranks" run one after the other on the one GPU; the collective itself is covered by
+    tests/test_dist_gloo.py."""
+    from ethereum_consensus_amd import shard
+    import random
+    r = random.Random(9)
+    for n in (0, 1, 5, 1000, 4096, 70001):
+        vals = bytes(r.getrandbits(8) for _ in range(121 * min(n, 64))) * (n // 64 + 1)
+        vals = vals[:121 * n]
+        full = gpu.hash_tree_root_validators(vals)
+        bal = bytes(r.getrandbits(8) for _ in range(256)) * (n * 8 // 256 + 1)
+        bal = bal[:8 * n]
+        n_chunks = (8 * n + 31) // 32
+        limit_chunks = (1 << 40) * 8 // 32
+        full_bal = gpu.merkleize(bal, limit_chunks, n)
+        for world in (1, 2, 4, 8):
+            w = shard.subtree_width(n, world)
+            subs = b""
+            for rank in range(world):
+                lo, hi = shard.subtree_range(n, rank, world)
+                subs += gpu.validators_subtree_root(vals[121 * lo:121 * hi], w)
+            assert gpu.merkleize_subtree_roots(subs, w, 1 << 40, n) == full
+            wc = shard.subtree_width(n_chunks, world)
+            subs = b""
+            for rank in range(world):
+                lo, hi = shard.subtree_range(n_chunks, rank, world)
+                subs += gpu.merkleize(bal[32 * lo:32 * hi], wc)
+            assert gpu.merkleize_subtree_roots(subs, wc, limit_chunks, n) == full_bal
+    # single-process form of the host helper (world 1: no collective)
+    assert gpu.hash_tree_root_validators_sharded(None, vals, n) == full
+    assert gpu.merkleize_sharded(None, bal, n_chunks, limit_chunks, n) == full_bal

@@ -119,3 +119,20 @@ def test_default_state_roots_both_presets():
         # validators: empty list -> Z_40 mixed with 0
         i = [n for n, _ in t.fields].index("validators")
         assert t.field_roots(s)[i] == hashlib.sha256(ssz.ZERO_HASHES[40] + bytes(32)).digest()
+
+
+def test_subtree_roots_compose_to_the_full_root():
+    """Sharded lists: aligned subtrees reduced separately, then the top of the tree."""
+    import hashlib
+    from oracle import ssz as O
+    for n in (0, 1, 3, 8, 9, 100, 257):
+        chunks = [hashlib.sha256(b"c" + i.to_bytes(4, "little")).digest() for i in range(n)]
+        for limit in (512, 1 << 20, 1 << 40):
+            want = O.merkleize_chunks(chunks, limit)
+            for width in (1, 2, 64, 512):
+                n_sub = max(1, -(-n // width))
+                subs = [O.merkleize_chunks(chunks[k * width:(k + 1) * width], width) for k in range(n_sub)]
+                assert O.merkleize_subtree_roots(subs, width, limit) == want
+                # trailing all-zero subtrees (ranks past the end of the list) change nothing
+                if (n_sub + 1) * width <= limit:
+                    assert O.merkleize_subtree_roots(subs + [O.merkleize_chunks([], width)], width, limit) == want
