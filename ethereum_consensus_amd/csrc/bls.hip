@@ -17,6 +17,7 @@
 // (DESIGN.md has the numbers).  No CPU fallback: without a gfx950 device every entry point fails.
 #include "bls_verify.h"
 #include "bls_vm_host.h"
+#include "bls_kernels.h"
 #include "runtime.h"
 
 #include <cstdlib>
@@ -25,13 +26,6 @@
 namespace ecg {
 
 int init_bls_tables(hipStream_t) { return init_vm2_tables(); }
-
-constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches over every CU
-#ifndef ECG_BLS_WAVES
-#define ECG_BLS_WAVES 1  // waves per SIMD the register allocator must leave room for: 1 = the whole 512-entry VGPR+AGPR file.
-                         // These lane kernels are bound by private-segment traffic, so registers beat occupancy
-                         // (65 ms vs 76 ms per 65 536 tuples at 1 vs 2 waves/SIMD, profiles/r01k_bls_probe_*.txt)
-#endif
 
 // ---- stage kernels ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pk_validate(const u8* pks48, u32 n, A1* pts, u8* st) {
@@ -132,79 +126,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_h2c(const u8* msgs
     hpts[i] = h;
 }
 
-// fast_aggregate_verify tuple i: status algebra + pairing equation.
-// k_of: number of keys of tuple i = pk_off ? pk_off[i+1]-pk_off[i] : 1.
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts,
-                                                        const A2* sigpts, const u8* st_dec, const u8* st_grp, const u8* sigs96,
-                                                        u32 n, int eth_variant, u8* status_out, int only_marked) {
-    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    if (only_marked && status_out[i] != VM_NEEDS_LANE_PATH) return;
-    const u32 k = pk_off ? pk_off[i + 1] - pk_off[i] : 1;
-    const bool sig_inf_bytes = sig_is_infinity_bytes(sigs96 + 96 * (size_t)i);
-    const bool agg_inf = agg[i].inf != 0;
-    u8 pre = combine_fav_status(k, eth_variant != 0, sig_inf_bytes, st_pk[i], st_dec[i], st_grp[i], agg_inf, 0xff);
-    if (pre != 0xff) {
-        status_out[i] = pre;
-        return;
-    }
-    A1 a = agg[i];
-    A2 h = hpts[i];
-    A2 s = sigpts[i];
-    status_out[i] = stage_pairing(a, h, s);
-}
-
-// ---- aggregate_verify: one Miller loop per lane, product + final exponentiation on one lane ------
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs) {
-    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
-    if (i > n) return;
-    MillerPair pr;
-    if (i < n) {
-        A1 p = pts[i];
-        A2 q = hpts[i];
-        miller_pair_init(pr, p, q);
-    } else {
-        A1 ng;
-        ng.x = blsc::G1_X;
-        ng.y = blsc::G1_NEG_Y;
-        ng.inf = 0;
-        A2 s = *sigpt;
-        miller_pair_init(pr, ng, s);
-    }
-    Fp12 f;
-    miller_loop(f, &pr, 1);
-    fs[i] = f;
-}
-
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_aggv_final(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp,
-                                                           const Fp12* fs, u8* status_out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (u32 i = 0; i < n_pks; i++)
-        if (st_pk[i]) {
-            *status_out = st_pk[i];
-            return;
-        }
-    if (st_dec[0]) {
-        *status_out = st_dec[0];
-        return;
-    }
-    if (n_pks == 0 || n_pks != n_msgs) {
-        *status_out = ECGPU_VERIFY_FAIL;
-        return;
-    }
-    if (st_grp[0]) {
-        *status_out = st_grp[0];
-        return;
-    }
-    Fp12 f = fs[0];
-    for (u32 i = 1; i <= n_pks; i++) {
-        Fp12 g = fs[i];
-        fp12_mul(f, f, g);
-    }
-    Fp12 e;
-    final_exponentiation(e, f);
-    *status_out = fp12_is_one(e) ? ECGPU_SUCCESS : ECGPU_VERIFY_FAIL;
-}
+// k_pairing, k_miller_pairs, k_aggv_final: bls_pairing_kernels.hip (a translation unit of its own: the tower code under
+// them is most of the compile time, and the two units build side by side)
 
 // ---- aggregate outputs -----------------------------------------------------------------------
 // status of crypto::aggregate (bls.rs:79-93): every signature is decoded first, then group-checked
@@ -328,8 +251,11 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     // Key-heavy batches (committees): the signature and message stages do not depend on the keys, so they run on an
     // auxiliary stream underneath the key validation + aggregation and join before the pairing check.
     // With a registry there is no key validation to hide behind: the signature stage stays on the caller's stream
-    // and only the (three times longer) message stage goes to the auxiliary one.
-    const bool fork = d_pk_off && (reg || n_pks >= 4ull * n) && n <= 16384;
+    // and only the (three times longer) message stage goes to the auxiliary one.  Big K = 1 batches gain nothing from it:
+    // two one-wave-per-SIMD kernels side by side take as long as one after the other (65 536 tuples: 13.6 ms together,
+    // 3.2 + 9.9 apart, profiles/r01s4_*).
+    const bool key_heavy = d_pk_off && !reg && n_pks >= 4ull * n;
+    const bool fork = d_pk_off && (reg || key_heavy) && n <= 16384;
     hipStream_t s2 = s;
     if (fork) {
         int rc = ax.init();
@@ -347,7 +273,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
     }
     {
-        hipStream_t s_sig = reg ? s : s2;
+        hipStream_t s_sig = key_heavy ? s2 : s;
         ProfScope ps("bls_sig", s_sig);
         hipLaunchKernelGGL(k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s_sig, d_sigs96, n, sigpts, st_dec, st_grp);
     }

@@ -1,0 +1,20 @@
+// Launch geometry of the BLS lane kernels and the kernels that live in a translation unit of their own.
+#pragma once
+#include "bls_verify.h"
+
+namespace ecg {
+
+constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches over every CU
+#ifndef ECG_BLS_WAVES
+#define ECG_BLS_WAVES 1  // waves per SIMD the register allocator must leave room for: 1 = the whole 512-entry VGPR+AGPR file.
+                         // These lane kernels hold hundreds of live field-element limbs, so registers beat occupancy
+                         // (re-measured after every restructuring)
+#endif
+
+// bls_pairing_kernels.hip
+__global__ void k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
+                          const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out, int only_marked);
+__global__ void k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);
+__global__ void k_aggv_final(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, const Fp12* fs, u8* status_out);
+
+}  // namespace ecg
