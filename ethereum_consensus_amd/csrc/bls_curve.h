@@ -85,7 +85,7 @@ ECG_HD void jac_neg(Jac<F>& r, const Jac<F>& p) {
 
 // dbl-2009-l (a = 0).  inf -> inf; y == 0 -> inf.  r may alias p.
 template <class F>
-ECG_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+ECG_HD void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
     F A = f_sqr(p.x);
     F B = f_sqr(p.y);
     F C = f_sqr(B);
@@ -100,10 +100,18 @@ ECG_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
     r.x = X3;
     r.z = Z3;
 }
+// the out-of-line forms: every point they are handed is a local of the caller (private segment, see ecg_priv_load)
+template <class F>
+ECG_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+    const Jac<F> x = ecg_priv_load(p);
+    Jac<F> z;
+    jac_dbl_inl(z, x);
+    ecg_priv_store(r, z);
+}
 
 // madd-2007-bl: Jacobian + affine (affine not infinity).  r may alias p.
 template <class F>
-ECG_HD_NOINLINE void jac_add_aff(Jac<F>& r, const Jac<F>& p, const F& qx, const F& qy) {
+ECG_HD void jac_add_aff_inl(Jac<F>& r, const Jac<F>& p, const F& qx, const F& qy) {
     if (jac_is_inf(p)) {
         r.x = qx;
         r.y = qy;
@@ -135,10 +143,18 @@ ECG_HD_NOINLINE void jac_add_aff(Jac<F>& r, const Jac<F>& p, const F& qx, const 
     r.y = Y3;
     r.z = Z3;
 }
+template <class F>
+ECG_HD_NOINLINE void jac_add_aff(Jac<F>& r, const Jac<F>& p, const F& qx, const F& qy) {
+    const Jac<F> x = ecg_priv_load(p);
+    const F ax = ecg_priv_load(qx), ay = ecg_priv_load(qy);
+    Jac<F> z;
+    jac_add_aff_inl(z, x, ax, ay);
+    ecg_priv_store(r, z);
+}
 
 // add-2007-bl: Jacobian + Jacobian, all special cases.  r may alias p or q.
 template <class F>
-ECG_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+ECG_HD void jac_add_inl(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     if (jac_is_inf(p)) {
         r = q;
         return;
@@ -174,6 +190,13 @@ ECG_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     r.y = Y3;
     r.z = Z3;
 }
+template <class F>
+ECG_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+    const Jac<F> x = ecg_priv_load(p), y = ecg_priv_load(q);
+    Jac<F> z;
+    jac_add_inl(z, x, y);
+    ecg_priv_store(r, z);
+}
 
 template <class F>
 ECG_HD bool jac_eq(const Jac<F>& p, const Jac<F>& q) {
@@ -202,24 +225,26 @@ ECG_HD void jac_to_aff(Aff<F>& r, const Jac<F>& p) {
 // [|x|] P, |x| = 0xd201000000010000 (MSB-first double-and-add: 63 doublings, 5 additions)
 template <class F>
 ECG_HD_NOINLINE void jac_mul_xabs(Jac<F>& r, const Jac<F>& p) {
-    Jac<F> acc = p;
+    const Jac<F> base = ecg_priv_load(p);
+    Jac<F> acc = base;
     for (int b = 62; b >= 0; b--) {
         jac_dbl(acc, acc);
-        if ((blsc::X_ABS >> b) & 1) jac_add(acc, acc, p);
+        if ((blsc::X_ABS >> b) & 1) jac_add(acc, acc, base);
     }
-    r = acc;
+    ecg_priv_store(r, acc);
 }
 
 // [k] P for a scalar of `nwords` 32-bit LE words (test-vector generation: sk -> pk, signing)
 template <class F>
 ECG_HD_NOINLINE void jac_mul_scalar(Jac<F>& r, const Jac<F>& p, const u32* k, int nwords) {
+    const Jac<F> base = ecg_priv_load(p);
     Jac<F> acc;
     jac_set_inf(acc);
     for (int b = nwords * 32 - 1; b >= 0; b--) {
         jac_dbl(acc, acc);
-        if ((k[b >> 5] >> (b & 31)) & 1) jac_add(acc, acc, p);
+        if ((k[b >> 5] >> (b & 31)) & 1) jac_add(acc, acc, base);
     }
-    r = acc;
+    ecg_priv_store(r, acc);
 }
 
 // ---- endomorphisms and subgroup checks --------------------------------------------------------
@@ -259,7 +284,7 @@ ECG_HD bool bytes_all_zero(const u8* b, int from, int to) {
     return o == 0;
 }
 
-ECG_HD_NOINLINE int g1_decompress(A1& r, const u8* b) {
+ECG_HD int g1_decompress_inl(A1& r, const u8* b) {
     r.inf = 0;
     r.x = fp_zero();
     r.y = fp_zero();
@@ -283,6 +308,12 @@ ECG_HD_NOINLINE int g1_decompress(A1& r, const u8* b) {
     r.y = y;
     return ECGPU_SUCCESS;
 }
+ECG_HD_NOINLINE int g1_decompress(A1& r, const u8* b) {  // r: a local of the caller (private segment); b: global memory
+    A1 z;
+    const int rc = g1_decompress_inl(z, b);
+    ecg_priv_store(r, z);
+    return rc;
+}
 
 ECG_HD void g1_compress(u8* out, const A1& p) {
     if (p.inf) {
@@ -295,7 +326,7 @@ ECG_HD void g1_compress(u8* out, const A1& p) {
     if (fp_lex_largest(p.y)) out[0] |= 0x20;
 }
 
-ECG_HD_NOINLINE int g2_decompress(A2& r, const u8* b) {
+ECG_HD int g2_decompress_inl(A2& r, const u8* b) {
     r.inf = 0;
     r.x = fp2_zero();
     r.y = fp2_zero();
@@ -319,6 +350,12 @@ ECG_HD_NOINLINE int g2_decompress(A2& r, const u8* b) {
     r.x = x;
     r.y = y;
     return ECGPU_SUCCESS;
+}
+ECG_HD_NOINLINE int g2_decompress(A2& r, const u8* b) {  // r: a local of the caller (private segment); b: global memory
+    A2 z;
+    const int rc = g2_decompress_inl(z, b);
+    ecg_priv_store(r, z);
+    return rc;
 }
 
 ECG_HD void g2_compress(u8* out, const A2& p) {

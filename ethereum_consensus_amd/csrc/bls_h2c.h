@@ -101,7 +101,9 @@ ECG_HD Fp2 fp2_horner(const Fp2* c, int deg, const Fp2& x) {
 
 // simplified SWU onto E2' (RFC 9380 6.6.2, straight-line form) then the 3-isogeny to E2, result in
 // Jacobian coordinates (no inversion for the isogeny denominators).
-ECG_HD_NOINLINE void map_to_curve_g2(J2& r, const Fp2& u) {
+ECG_HD_NOINLINE void map_to_curve_g2(J2& r_out, const Fp2& u_in) {
+    const Fp2 u = ecg_priv_load(u_in);  // operands are locals of the caller (private segment)
+    J2 r;
     Fp2 tv1 = fp2_mulx(blsc::SSWU_Z, fp2_sqrx(u));
     Fp2 tv2 = fp2_add(fp2_sqrx(tv1), tv1);
     Fp2 x1;
@@ -146,6 +148,7 @@ ECG_HD_NOINLINE void map_to_curve_g2(J2& r, const Fp2& u) {
     Fp2 yd = fp2_horner(blsc::ISO_YDEN, 3, x);
     if (fp2_is_zero(xd) || fp2_is_zero(yd)) {
         jac_set_inf(r);  // exceptional point of the isogeny
+        ecg_priv_store(r_out, r);
         return;
     }
     Fp2 z = fp2_mulx(xd, yd);
@@ -153,10 +156,12 @@ ECG_HD_NOINLINE void map_to_curve_g2(J2& r, const Fp2& u) {
     r.x = fp2_mulx(fp2_mulx(xn, xd), yd2);                                       // xn xd yd^2
     r.y = fp2_mulx(fp2_mulx(fp2_mulx(y, yn), fp2_mulx(fp2_sqrx(xd), xd)), yd2);  // y yn xd^3 yd^2
     r.z = z;
+    ecg_priv_store(r_out, r);
 }
 
 // h_eff multiplication by Budroni-Pintore: [x^2 - x - 1] P + [x - 1] psi(P) + psi^2(2P)
-ECG_HD_NOINLINE void g2_clear_cofactor(J2& r, const J2& p) {
+ECG_HD_NOINLINE void g2_clear_cofactor(J2& r, const J2& p_in) {
+    const J2 p = ecg_priv_load(p_in);
     J2 t1, t2, t3, n;
     jac_mul_xabs(t1, p);
     jac_neg(t1, t1);  // [x] P
@@ -173,7 +178,8 @@ ECG_HD_NOINLINE void g2_clear_cofactor(J2& r, const J2& p) {
     jac_neg(n, t1);
     jac_add(t3, t3, n);
     jac_neg(n, p);
-    jac_add(r, t3, n);
+    jac_add(t3, t3, n);
+    ecg_priv_store(r, t3);
 }
 
 ECG_HD_NOINLINE void hash_to_g2(A2& r, const u8* msg, size_t msg_len) {
@@ -186,7 +192,9 @@ ECG_HD_NOINLINE void hash_to_g2(A2& r, const u8* msg, size_t msg_len) {
     map_to_curve_g2(q1, u1);
     jac_add(q0, q0, q1);
     g2_clear_cofactor(q0, q0);
-    jac_to_aff(r, q0);
+    A2 a;
+    jac_to_aff(a, q0);
+    ecg_priv_store(r, a);
 }
 
 }  // namespace ecg

@@ -54,7 +54,7 @@ ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, MillerPair& m) {
 }
 
 // T <- T + Q, f <- f * line_{T,Q}(P)
-ECG_FP12_FN void miller_add_step(Fp12& f, MillerPair& m) {
+ECG_HD void miller_add_step_inl(Fp12& f, MillerPair& m) {
     const J2& T = m.t;
     Fp2 Z1Z1 = fp2_sqrx(T.z);
     Fp2 U2 = fp2_mulx(m.qx, Z1Z1);
@@ -76,53 +76,69 @@ ECG_FP12_FN void miller_add_step(Fp12& f, MillerPair& m) {
     m.t.z = Z3;
     fp12_mul_by_line(f, l0, l1, l2);
 }
+// out of line (5 of the 68 iterations): accumulator and pair are locals of miller_loop
+ECG_FP12_FN void miller_add_step(Fp12& f, MillerPair& m) {
+    Fp12 x = ecg_priv_load(f);
+    MillerPair y = ecg_priv_load(m);
+    miller_add_step_inl(x, y);
+    ecg_priv_store(f, x);
+    ecg_priv_store(m, y);
+}
 
 // f = prod_k f_{|x|,Q_k}(P_k), conjugated (x < 0)
 // The accumulator is a local VALUE whose address never leaves this function (the five addition steps work on a copy):
 // it lives in VGPRs/AGPRs across the whole doubling iteration instead of making three round trips through the
 // private segment per bit.
 ECG_HD_NOINLINE void miller_loop(Fp12& f, MillerPair* pairs, int n) {
-    fp12_set_one(f);
     bool any = false;
-    for (int k = 0; k < n; k++) any = any || pairs[k].active;
-    if (!any) return;
+    MillerPair lp[2];  // n <= 2 (verify: 2 pairs; aggregate_verify: 1 per lane); private copies, see ecg_priv_load
+    for (int k = 0; k < n && k < 2; k++) {
+        lp[k] = ecg_priv_load(pairs[k]);
+        any = any || lp[k].active;
+    }
     Fp12 acc;
     fp12_set_one(acc);
-    for (int b = 62; b >= 0; b--) {
-        if (b != 62) fp12_sqr(acc, acc);
-        for (int k = 0; k < n; k++)
-            if (pairs[k].active) miller_dbl_step(acc, pairs[k]);
-        if ((blsc::X_ABS >> b) & 1)
+    if (any) {
+        for (int b = 62; b >= 0; b--) {
+            if (b != 62) fp12_sqr(acc, acc);
             for (int k = 0; k < n; k++)
-                if (pairs[k].active) {
-                    Fp12 t = acc;
-                    miller_add_step(t, pairs[k]);
-                    acc = t;
-                }
+                if (lp[k].active) miller_dbl_step(acc, lp[k]);
+            if ((blsc::X_ABS >> b) & 1)
+                for (int k = 0; k < n; k++)
+                    if (lp[k].active) {
+                        Fp12 t = acc;
+                        miller_add_step(t, lp[k]);
+                        acc = t;
+                    }
+        }
+        fp12_conj(acc, acc);
     }
-    fp12_conj(f, acc);
+    ecg_priv_store(f, acc);
 }
 
 // a^x for a in the cyclotomic subgroup (x < 0: conjugate)
 ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
-    Fp12 acc = a;  // a register-resident value: the squaring is inlined, the five products work on a copy
+    const Fp12 base = ecg_priv_load(a);
+    Fp12 acc = base;  // a register-resident value: the squaring is inlined, the five products work on a copy
     for (int b = 62; b >= 0; b--) {
         fp12_cyclotomic_sqr_inl(acc, acc);
         if ((blsc::X_ABS >> b) & 1) {
-            Fp12 t = acc;
-            fp12_mul(t, t, a);
+            Fp12 t = acc, u = base;
+            fp12_mul(t, t, u);
             acc = t;
         }
     }
-    fp12_conj(r, acc);
+    fp12_conj(acc, acc);
+    ecg_priv_store(r, acc);
 }
 
 // f^(3 (p^12 - 1)/r); the factor 3 is coprime to r so "== 1" is unaffected
 ECG_HD_NOINLINE void final_exponentiation(Fp12& r, const Fp12& f) {
     Fp12 t, u, a, b, c;
+    const Fp12 f0 = ecg_priv_load(f);
     // easy part: (p^6 - 1)(p^2 + 1)
-    fp12_conj(t, f);
-    fp12_inv(u, f);
+    fp12_conj(t, f0);
+    fp12_inv(u, f0);
     fp12_mul(t, t, u);
     fp12_frob(u, t);
     fp12_frob(u, u);
@@ -146,7 +162,8 @@ ECG_HD_NOINLINE void final_exponentiation(Fp12& r, const Fp12& f) {
     fp12_mul(c, c, u);  // b^(x^2 + p^2 - 1)
     fp12_cyclotomic_sqr(u, t);
     fp12_mul(u, u, t);  // t^3
-    fp12_mul(r, c, u);
+    fp12_mul(c, c, u);
+    ecg_priv_store(r, c);
 }
 
 // e(p0, q0) * e(p1, q1) == 1 ?

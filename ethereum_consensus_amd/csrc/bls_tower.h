@@ -151,7 +151,7 @@ ECG_FP6_FN void fp12_sqr_combine(Fp12& r, const Fp6& s, const Fp6& ab) {
     r.c1.c2 = fp2_dbl(x2);
 }
 
-ECG_HD_NOINLINE void fp6_inv(Fp6& r, const Fp6& a) {
+ECG_HD void fp6_inv_inl(Fp6& r, const Fp6& a) {
     Fp2 c0 = fp2_sub(fp2_sqrx(a.c0), fp2_mul_xi(fp2_mulx(a.c1, a.c2)));
     Fp2 c1 = fp2_sub(fp2_mul_xi(fp2_sqrx(a.c2)), fp2_mulx(a.c0, a.c1));
     Fp2 c2 = fp2_sub(fp2_sqrx(a.c1), fp2_mulx(a.c0, a.c2));
@@ -160,6 +160,12 @@ ECG_HD_NOINLINE void fp6_inv(Fp6& r, const Fp6& a) {
     r.c0 = fp2_mulx(c0, ti);
     r.c1 = fp2_mulx(c1, ti);
     r.c2 = fp2_mulx(c2, ti);
+}
+ECG_HD_NOINLINE void fp6_inv(Fp6& r, const Fp6& a) {
+    const Fp6 x = ecg_priv_load(a);
+    Fp6 z;
+    fp6_inv_inl(z, x);
+    ecg_priv_store(r, z);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -178,12 +184,19 @@ ECG_HD void fp12_conj(Fp12& r, const Fp12& a) {
     fp6_neg(r.c1, a.c1);
 }
 // 3 Fp6 products.  r may alias a or b.
-ECG_FP12_FN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
+ECG_HD void fp12_mul_inl(Fp12& r, const Fp12& a, const Fp12& b) {
     Fp6 t0, t1, m;
     fp6_mul(t0, a.c0, b.c0);
     fp6_mul(t1, a.c1, b.c1);
     fp6_mul_sums(m, a.c0, a.c1, b.c0, b.c1);
     fp12_karatsuba_combine(r.c0, r.c1, m, t0, t1);
+}
+// out of line: operands and result are locals of the caller (private segment, see ecg_priv_load)
+ECG_FP12_FN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
+    const Fp12 x = ecg_priv_load(a), y = ecg_priv_load(b);
+    Fp12 z;
+    fp12_mul_inl(z, x, y);
+    ecg_priv_store(r, z);
 }
 // complex squaring, 2 Fp6 products: c0 = (a0 + a1)(a0 + v a1) - a0a1 - v a0a1, c1 = 2 a0a1
 ECG_MILLER_DBL_FN void fp12_sqr(Fp12& r, const Fp12& a) {
@@ -235,7 +248,7 @@ ECG_MILLER_DBL_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, c
         f.c1.c2 = fp2_sumprod<3>(x, y210, ny210);
     }
 }
-ECG_HD_NOINLINE void fp12_inv(Fp12& r, const Fp12& a) {
+ECG_HD void fp12_inv_inl(Fp12& r, const Fp12& a) {
     Fp6 t0, t1;
     fp6_mul(t0, a.c0, a.c0);
     fp6_mul(t1, a.c1, a.c1);
@@ -246,15 +259,27 @@ ECG_HD_NOINLINE void fp12_inv(Fp12& r, const Fp12& a) {
     fp6_mul(t0, a.c1, t1);
     fp6_neg(r.c1, t0);
 }
+ECG_HD_NOINLINE void fp12_inv(Fp12& r, const Fp12& a) {
+    const Fp12 x = ecg_priv_load(a);
+    Fp12 z;
+    fp12_inv_inl(z, x);
+    ecg_priv_store(r, z);
+}
 // Frobenius a -> a^p: with a = sum_k a_k w^k (c0 = (a0, a2, a4), c1 = (a1, a3, a5)),
 // a_k -> conj(a_k) * xi^(k (p-1)/6).
-ECG_HD_NOINLINE void fp12_frob(Fp12& r, const Fp12& a) {
+ECG_HD void fp12_frob_inl(Fp12& r, const Fp12& a) {
     r.c0.c0 = fp2_conj(a.c0.c0);
     r.c1.c0 = fp2_mulx(fp2_conj(a.c1.c0), blsc::FROB_GAMMA[1]);
     r.c0.c1 = fp2_mulx(fp2_conj(a.c0.c1), blsc::FROB_GAMMA[2]);
     r.c1.c1 = fp2_mulx(fp2_conj(a.c1.c1), blsc::FROB_GAMMA[3]);
     r.c0.c2 = fp2_mulx(fp2_conj(a.c0.c2), blsc::FROB_GAMMA[4]);
     r.c1.c2 = fp2_mulx(fp2_conj(a.c1.c2), blsc::FROB_GAMMA[5]);
+}
+ECG_HD_NOINLINE void fp12_frob(Fp12& r, const Fp12& a) {
+    const Fp12 x = ecg_priv_load(a);
+    Fp12 z;
+    fp12_frob_inl(z, x);
+    ecg_priv_store(r, z);
 }
 
 // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the
@@ -305,6 +330,11 @@ ECG_HD void fp12_cyclotomic_sqr_inl(Fp12& r, const Fp12& f) {
     r.c1.c1 = z1;
     r.c1.c2 = z5;
 }
-ECG_HD_NOINLINE void fp12_cyclotomic_sqr(Fp12& r, const Fp12& f) { fp12_cyclotomic_sqr_inl(r, f); }
+ECG_HD_NOINLINE void fp12_cyclotomic_sqr(Fp12& r, const Fp12& f) {
+    const Fp12 x = ecg_priv_load(f);
+    Fp12 z;
+    fp12_cyclotomic_sqr_inl(z, x);
+    ecg_priv_store(r, z);
+}
 
 }  // namespace ecg

@@ -49,3 +49,38 @@ ECG_HD u32 ecg_maj(u32 a, u32 b, u32 c) {
     return (a & b) | (c & (a | b));
 #endif
 }
+
+// Out-of-line lane routines take their operands by reference, i.e. through GENERIC pointers: the compiler must use flat
+// loads / stores, and because flat accesses may return out of order between the LDS and the memory path every use waits for
+// ALL outstanding accesses (s_waitcnt 0) -- at one wave per SIMD that is a full 1-2 us private-segment round trip per
+// access group (measured: 90 k of the 244 k cycles of an out-of-line Fp12 product).  Every such object in this code base is
+// a kernel- or function-local, i.e. lives in the private segment; these helpers say so: the copy goes through
+// address-space-5 pointers (scratch_load / scratch_store with their own counters, issued early, waited for one by one).
+// ONLY for references to locals -- never for global or LDS memory.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+ECG_D T ecg_priv_load(const T& x) {
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "dword-granular objects only");
+    typedef __attribute__((address_space(5))) const u32* src_t;
+    T r;
+    src_t p = (src_t)(const u32*)(const void*)&x;
+    u32* q = (u32*)&r;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) q[i] = p[i];
+    return r;
+}
+template <class T>
+ECG_D void ecg_priv_store(T& x, const T& v) {
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "dword-granular objects only");
+    typedef __attribute__((address_space(5))) u32* dst_t;
+    dst_t p = (dst_t)(u32*)(void*)&x;
+    const u32* q = (const u32*)&v;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) p[i] = q[i];
+}
+#else
+template <class T>
+ECG_HD T ecg_priv_load(const T& x) { return x; }
+template <class T>
+ECG_HD void ecg_priv_store(T& x, const T& v) { x = v; }
+#endif
