@@ -1,0 +1,69 @@
+// Box self-check: does instruction fetch keep up with straight-line code that is much larger than the instruction cache?
+//
+// The BLS lane kernels are megabytes of straight-line multiply-adds at one wave per SIMD.  On most boxes of the pool a
+// loop of 1 MB of code runs as fast per instruction as a loop of 8 KB; on a minority it runs several times slower (and
+// so do k_pairing, k_sig, k_h2c -- profiles/r01zg_bls_probe_slow_box.txt -- while small-code kernels are unaffected).
+// bench.py reports the two timings next to its numbers so that a reader can tell a slow kernel from a slow box.
+#include "runtime.h"
+
+namespace ecg {
+
+// MADS independent-accumulator multiply-adds per loop trip, emitted as instructions (nothing for the optimizer to fold)
+template <int MADS>
+__global__ void __launch_bounds__(64) k_ifetch_probe(u32* out, u32 trips) {
+    u64 acc0 = threadIdx.x, acc1 = blockIdx.x, acc2 = 3, acc3 = 5;
+    const u32 a = threadIdx.x * 2654435761u + 1, b = blockIdx.x * 40503u + 7;
+    for (u32 t = 0; t < trips; t++) {
+#pragma unroll
+        for (int k = 0; k < MADS / 4; k++) {
+            asm volatile(
+                "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\t"
+                "v_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_mad_u64_u32 %3, vcc, %4, %5, %3"
+                : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+                : "v"(a), "v"(b)
+                : "vcc");
+        }
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = (u32)(acc0 ^ acc1 ^ acc2 ^ acc3);
+}
+
+template <int MADS>
+static int time_probe(hipStream_t s, u32* d_out, u32 trips, double* ms) {
+    hipEvent_t e0, e1;
+    ECG_HIP_CHECK(hipEventCreate(&e0));
+    ECG_HIP_CHECK(hipEventCreate(&e1));
+    const dim3 grid(1024), block(64);  // one wave per SIMD, like the lane kernels
+    hipLaunchKernelGGL(k_ifetch_probe<MADS>, grid, block, 0, s, d_out, trips);  // warm-up: code load, caches
+    ECG_HIP_CHECK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_ifetch_probe<MADS>, grid, block, 0, s, d_out, trips);
+    ECG_HIP_CHECK(hipEventRecord(e1, s));
+    ECG_HIP_CHECK(hipEventSynchronize(e1));
+    float f = 0;
+    ECG_HIP_CHECK(hipEventElapsedTime(&f, e0, e1));
+    *ms = f;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ECGPU_SUCCESS;
+}
+
+}  // namespace ecg
+
+using namespace ecg;
+
+extern "C" int ecgpu_selfcheck_ifetch(double* ms_small_loop, double* ms_large_loop) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!ms_small_loop || !ms_large_loop) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    rc = ar.reserve(1024 * 64 * 4 + 256);
+    if (rc) return rc;
+    u32* d_out = (u32*)ar.take(1024 * 64 * 4);
+    if (!d_out) return ECGPU_ERR_OOM;
+    // the same 2^21 multiply-adds per lane: 2048 trips through 8 KB of code, 16 trips through 1 MB
+    rc = time_probe<1024>(s, d_out, 2048, ms_small_loop);
+    if (rc) return rc;
+    return time_probe<131072>(s, d_out, 16, ms_large_loop);
+}

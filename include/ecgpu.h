@@ -229,6 +229,9 @@ int ecgpu_sign_batch_dev(const uint8_t* d_sks32, uint32_t sk_stride, const uint8
 int ecgpu_prof_enable(int on);
 int ecgpu_prof_filter(const char* kernel_tag); /* NULL/"" = time every tagged kernel */
 int ecgpu_prof_read(const char* kernel_tag, double* total_ms, uint64_t* launches);
+/* Box self-check: the same 2^21 multiply-adds per lane as a loop over 8 KB of code and as a loop over 1 MB of code
+ * (one wave per SIMD, like the BLS lane kernels).  The two take the same time on a healthy box. */
+int ecgpu_selfcheck_ifetch(double* ms_small_loop, double* ms_large_loop);
 
 #ifdef __cplusplus
 }
