@@ -4,6 +4,7 @@
 // encoding (read once); the ~60 small chunks are gathered into one staging buffer and reduced
 // by three batched k_tree_jobs launches (leaf containers -> nested containers -> the 28-field
 // state container).
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -12,12 +13,25 @@
 
 namespace ecg {
 
+// d_vroots != nullptr (resident state): the 32-byte hash_tree_root of every validator record is cached there and kept
+// current by the caller, so the registry enters the tree as a list of 2^20 ready chunks (1.0 M hash64) instead of 121-byte
+// records (9.4 M).
 static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, const u8* h_fixed,
-                             int preset, u8* d_root) {
+                             int preset, u8* d_root, const u8* d_vroots = nullptr) {
     StatePlan plan;
     if (!build_state_plan_deneb(h_fixed, n_bytes, preset, plan)) {
         set_last_error(plan.error);
         return ECGPU_ERR_BAD_ARG;
+    }
+    std::vector<const u8*> fptr(plan.bigs.size());
+    for (size_t i = 0; i < plan.bigs.size(); i++) {
+        BigField& b = plan.bigs[i];
+        fptr[i] = d_ssz + b.src;
+        if (d_vroots && b.kind == LEAF_VALIDATORS) {
+            b.kind = LEAF_CHUNKS;
+            b.bytes = 32ull * b.n0;
+            fptr[i] = d_vroots;
+        }
     }
     // ---- device buffers --------------------------------------------------------------------------
     Arena& ar = c->arena(s);
@@ -59,7 +73,7 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         // chip-filling validator pass for its whole duration (measured 0.63 -> 0.79 ms); they start when that pass
         // has been issued and overlap with the validator tree's own latency-bound tail instead.
         const BigField& b = plan.bigs[biggest];
-        rc = merkleize_device(s, b.kind, d_ssz + b.src, b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk,
+        rc = merkleize_device(s, b.kind, fptr[biggest], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk,
                               wss[biggest], &hc, nullptr, nullptr, false, ax.fork);
         if (rc) return rc;
     }
@@ -75,7 +89,7 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         if (sc.passes.empty()) {
             // <= 2^19 leaves: leaf functor + 10 levels in the shared tile launch, then the batched finishing job
             if (sc.tile) {
-                tdescs.push_back({d_ssz + b.src, b.bytes, b.n0, wss[i], (u32)b.kind, 0u, b.depth, tile_wgs});
+                tdescs.push_back({fptr[i], b.bytes, b.n0, wss[i], (u32)b.kind, 0u, b.depth, tile_wgs});
                 tile_wgs += (u32)((b.n0 + TILE_NODES - 1) / TILE_NODES);
             }
             dj.in_off = (u64)(wss[i] - ar.base);
@@ -87,7 +101,7 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
             dj.mix = b.mix ? 1 : 0;
             hc += sc.hashes;
         } else {
-            rc = merkleize_device(ax.st[1], b.kind, d_ssz + b.src, b.bytes, b.n0, b.depth, b.mix, b.mix_len,
+            rc = merkleize_device(ax.st[1], b.kind, fptr[i], b.bytes, b.n0, b.depth, b.mix, b.mix_len,
                                   d_small + 32ull * b.out_chunk, wss[i], &hc, &dj, ar.base, true);
             if (rc) return rc;
         }
@@ -138,6 +152,15 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     return ECGPU_SUCCESS;
 }
 
+// hash_tree_root of validator records into the resident state's cache: lane = record; idx == nullptr: records [0, n)
+__global__ void __launch_bounds__(256) k_validator_roots(ValidatorLeaves leaves, const u32* idx, u32 n, u8* vroots) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const u64 v = idx ? idx[t] : t;
+    const Node r = leaves(v);
+    node_store(r, vroots + 32 * v);
+}
+
 // patch scatter: one workgroup per patch, byte copies (patches are small: a balance, a flag byte, a root)
 struct PatchDesc {
     u64 dst_off, src_off, len;
@@ -154,6 +177,12 @@ struct ecgpu_resident_state {
     u8* d_ssz = nullptr;   // encoding + 64 bytes of slack + the root
     u64 n_bytes = 0;
     std::vector<u8> h_fixed;  // host mirror of the fixed-size part (offsets and small fields): what the plan reads
+    // SURVEY.md 8f rank 2, first level: the root of every validator record, kept current by the patches.  93 % of a state
+    // root's hash64 are these 8 per validator, and a slot touches a handful of records.
+    u8* d_vroots = nullptr;
+    u64 vals_off = 0, n_vals = 0;       // byte offset / count of the validator records in the encoding
+    std::vector<u32> dirty;             // records whose cached root is stale (deduplicated at the next root)
+    bool all_dirty = true;
 };
 
 using namespace ecg;
@@ -175,6 +204,12 @@ int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes
     st->h_fixed.assign(ssz, ssz + layout_for(STATE_PRESETS[preset]).size);
     ECG_HIP_CHECK(hipMalloc((void**)&st->d_ssz, n_bytes + 128));
     ECG_HIP_CHECK(hipMemcpy(st->d_ssz, ssz, n_bytes, hipMemcpyHostToDevice));
+    for (const BigField& b : plan.bigs)
+        if (b.kind == LEAF_VALIDATORS) {
+            st->vals_off = b.src;
+            st->n_vals = b.n0;
+        }
+    if (st->n_vals) ECG_HIP_CHECK(hipMalloc((void**)&st->d_vroots, 32 * st->n_vals));
     *out = st;
     return ECGPU_SUCCESS;
 }
@@ -183,6 +218,7 @@ void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st) {
     if (!st) return;
     (void)hipDeviceSynchronize();
     (void)hipFree(st->d_ssz);
+    (void)hipFree(st->d_vroots);
     delete st;
 }
 
@@ -231,10 +267,56 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     ECG_HIP_CHECK(hipMemcpyAsync(d_desc, descs.data(), n * sizeof(PatchDesc), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_apply_patches, dim3(n), dim3(64), 0, s, st->d_ssz, (const u8*)d_data, (const PatchDesc*)d_desc);
     ECG_HIP_CHECK(hipGetLastError());
+    for (u32 i = 0; i < n && !st->all_dirty; i++) {  // validator records these bytes belong to
+        const u64 lo = descs[i].dst_off, hi = descs[i].dst_off + descs[i].len;
+        const u64 v0 = st->vals_off, v1 = st->vals_off + 121 * st->n_vals;
+        if (!descs[i].len || hi <= v0 || lo >= v1) continue;
+        const u64 first = ((lo > v0 ? lo : v0) - v0) / 121, last = ((hi < v1 ? hi : v1) - 1 - v0) / 121;
+        if (st->dirty.size() + (last - first + 1) > st->n_vals / 8) {
+            st->all_dirty = true;  // cheaper to rebuild the cache in one full-width launch
+            st->dirty.clear();
+            break;
+        }
+        for (u64 v = first; v <= last; v++) st->dirty.push_back((u32)v);
+    }
     for (u32 i = 0; i < n; i++)  // host mirror of the fixed part
         for (u64 b = 0; b < descs[i].len; b++)
             if (descs[i].dst_off + b < st->h_fixed.size()) st->h_fixed[descs[i].dst_off + b] = data[descs[i].src_off + b];
     ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ECGPU_SUCCESS;
+}
+
+// bring the cached validator roots up to date on stream s (before the arena is reset by the root computation)
+static int refresh_validator_roots(ecgpu_resident_state* st, hipStream_t s, ThreadCtx* c) {
+    if (!st->n_vals) return ECGPU_SUCCESS;
+    const ValidatorLeaves leaves{st->d_ssz + st->vals_off, 121 * st->n_vals};
+    if (st->all_dirty) {
+        hipLaunchKernelGGL(k_validator_roots, dim3((u32)((st->n_vals + 255) / 256)), dim3(256), 0, s, leaves, (const u32*)nullptr,
+                           (u32)st->n_vals, st->d_vroots);
+        ECG_HIP_CHECK(hipGetLastError());
+        st->all_dirty = false;
+        st->dirty.clear();
+        return ECGPU_SUCCESS;
+    }
+    if (st->dirty.empty()) return ECGPU_SUCCESS;
+    std::sort(st->dirty.begin(), st->dirty.end());
+    st->dirty.erase(std::unique(st->dirty.begin(), st->dirty.end()), st->dirty.end());
+    // the index list travels through an allocation of its own: the arena belongs to the root computation that follows
+    static thread_local u32* d_idx = nullptr;
+    static thread_local size_t d_idx_cap = 0;
+    if (st->dirty.size() > d_idx_cap) {
+        if (d_idx) {
+            ECG_HIP_CHECK(hipStreamSynchronize(s));
+            ECG_HIP_CHECK(hipFree(d_idx));
+        }
+        d_idx_cap = st->dirty.size() * 2 + 1024;
+        ECG_HIP_CHECK(hipMalloc((void**)&d_idx, d_idx_cap * sizeof(u32)));
+    }
+    ECG_HIP_CHECK(hipMemcpyAsync(d_idx, st->dirty.data(), st->dirty.size() * sizeof(u32), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_validator_roots, dim3((u32)((st->dirty.size() + 255) / 256)), dim3(256), 0, s, leaves, (const u32*)d_idx,
+                       (u32)st->dirty.size(), st->d_vroots);
+    ECG_HIP_CHECK(hipGetLastError());
+    st->dirty.clear();
     return ECGPU_SUCCESS;
 }
 
@@ -244,7 +326,9 @@ int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, e
     if (!st || !d_root) return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
-    return state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root);
+    rc = refresh_validator_roots(st, s, c);
+    if (rc) return rc;
+    return state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots);
 }
 
 int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
@@ -254,7 +338,9 @@ int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
     u8* d_root = st->d_ssz + ((st->n_bytes + 31) / 32) * 32 + 32;
-    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root);
+    rc = refresh_validator_roots(st, s, c);
+    if (rc) return rc;
+    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots);
     if (rc) return rc;
     ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
     ECG_HIP_CHECK(hipStreamSynchronize(s));

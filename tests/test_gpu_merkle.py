@@ -217,6 +217,21 @@ def test_resident_state_patches(gpu):
                 enc[off:off + len(b)] = b
             st.patch(patches)
             assert st.hash_tree_root() == gpu.hash_tree_root_beacon_state_deneb(bytes(enc), pid), (preset, slot)
+        # the cached validator roots: one patch across many records (the cache is rebuilt), then a few single-byte ones
+        # (only those records are re-hashed), then a patch that straddles two records
+        vals_off = fixed_size + len(f["historical_roots"].tobytes()) + 72 * len(f["eth1_data_votes"])  # 3rd variable field
+        assert bytes(enc[vals_off:vals_off + 121]) == f["validators"].tobytes()[:121]
+        big = r.randbytes(121 * (n // 2) + 17)
+        enc[vals_off + 121 * 5 + 3:vals_off + 121 * 5 + 3 + len(big)] = big
+        st.patch([(vals_off + 121 * 5 + 3, big)])
+        assert st.hash_tree_root() == gpu.hash_tree_root_beacon_state_deneb(bytes(enc), pid)
+        few = [(vals_off + 121 * v + r.randrange(121), r.randbytes(1)) for v in (0, 1, n // 3, n - 1)]
+        few.append((vals_off + 121 * 77 - 4, r.randbytes(8)))  # last 4 bytes of record 76, first 4 of record 77
+        for off, b in few:
+            enc[off:off + len(b)] = b
+        st.patch(few)
+        assert st.hash_tree_root() == gpu.hash_tree_root_beacon_state_deneb(bytes(enc), pid)
+        assert st.hash_tree_root() == gpu.hash_tree_root_beacon_state_deneb(bytes(enc), pid)  # nothing dirty: cache as is
         with pytest.raises(gpu.MerkleizationError):
             st.patch([(len(enc) - 4, bytes(8))])          # runs past the end
         st.close()
