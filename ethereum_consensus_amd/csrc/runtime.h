@@ -55,7 +55,9 @@ struct AuxStreams {
 
 struct ThreadCtx {
     hipStream_t own_stream = nullptr;
-    AuxStreams aux;
+    AuxStreams aux;      // state roots: the fields underneath the validator registry
+    AuxStreams aux_bls;  // BLS batches: signature / message stages (their own set, so that a state root and a verification
+                         // enqueued by one host thread on two streams do not serialize on shared auxiliary streams)
     std::map<hipStream_t, Arena> arenas;
     PinnedBuf staging;      // host-pinned staging for small H2D/D2H payloads
     u64 last_hash64 = 0;
