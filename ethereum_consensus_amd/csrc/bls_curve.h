@@ -42,6 +42,28 @@ ECG_HD void f_set_zero(Fp2& a) { a = fp2_zero(); }
 ECG_HD void f_set_one(Fp2& a) { a = fp2_one(); }
 ECG_HD Fp2 f_inv(const Fp2& a) { return fp2_inv(a); }
 
+// lazy product operands and sums of two products, generic over the two fields (bounds: bls_fp.h).  f_sp2<KB0, KB1> is
+// a0 b0 + a1 b1 with ONE reduction per coefficient; KB0 / KB1 bound the components of b0 / b1 in units of p (Fp2 only:
+// the imaginary parts are negated lazily).
+ECG_HD Fp f_add_lazy(const Fp& a, const Fp& b) { return fp_add_lazy(a, b); }
+ECG_HD Fp2 f_add_lazy(const Fp2& a, const Fp2& b) { return fp2_add_lazy(a, b); }
+template <int K>
+ECG_HD Fp f_sub_lazy(const Fp& a, const Fp& b) { return fp_sub_lazy_k<K>(a, b); }
+template <int K>
+ECG_HD Fp2 f_sub_lazy(const Fp2& a, const Fp2& b) { return Fp2{fp_sub_lazy_k<K>(a.c0, b.c0), fp_sub_lazy_k<K>(a.c1, b.c1)}; }
+template <int K>
+ECG_HD Fp f_neg_lazy(const Fp& a) { return fp_neg_lazy<K>(a); }
+template <int K>
+ECG_HD Fp2 f_neg_lazy(const Fp2& a) { return Fp2{fp_neg_lazy<K>(a.c0), fp_neg_lazy<K>(a.c1)}; }
+template <int KB0, int KB1>
+ECG_HD Fp f_sp2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1) { return fp_sumprod2(a0, b0, a1, b1); }
+template <int KB0, int KB1>
+ECG_HD Fp2 f_sp2(const Fp2& a0, const Fp2& b0, const Fp2& a1, const Fp2& b1) {
+    const Fp2 x[2] = {a0, a1}, y[2] = {b0, b1};
+    const Fp ny[2] = {fp_neg_lazy<KB0>(b0.c1), fp_neg_lazy<KB1>(b1.c1)};
+    return fp2_sumprod<2>(x, y, ny);
+}
+
 template <class F>
 struct Jac {
     F x, y, z;
@@ -83,21 +105,26 @@ ECG_HD void jac_neg(Jac<F>& r, const Jac<F>& p) {
     r.z = p.z;
 }
 
-// dbl-2009-l (a = 0).  inf -> inf; y == 0 -> inf.  r may alias p.
+// Doubling (a = 0), the dbl-2009-l quantities regrouped so that no modular addition touches a product:
+//   A = X^2, B = Y^2, D = 4 X B, E = 3A (lazy),
+//   X3 = E^2 - 2D = E E + (8p - 4X)(2B),   Y3 = E (D - X3) - 8 B^2 = E (D - X3 + 2p) + (8p - 4B)(2B),   Z3 = (2Y) Z
+// 2 squarings, 2 products, 2 sums of two products over 10 lazy operands (the textbook form: 5 squarings, 2 products and
+// 14 modular additions / doublings).  Bounds (units of p^2, per coefficient; Fp2 doubles them): E E 36 + (8)(4) 32 = 68;
+// E (D - X3) 24 + 32 = 56.  inf -> inf (Z3 = 0); y == 0 -> inf.  r may alias p.
 template <class F>
 ECG_HD void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
-    F A = f_sqr(p.x);
-    F B = f_sqr(p.y);
-    F C = f_sqr(B);
-    F D = f_sub(f_sub(f_sqr(f_add(p.x, B)), A), C);
-    D = f_dbl(D);
-    F E = f_add(f_dbl(A), A);
-    F Fq = f_sqr(E);
-    F Z3 = f_dbl(f_mul(p.y, p.z));
-    F X3 = f_sub(Fq, f_dbl(D));
-    F C8 = f_dbl(f_dbl(f_dbl(C)));
-    r.y = f_sub(f_mul(E, f_sub(D, X3)), C8);
+    const F A = f_sqr(p.x);
+    const F B = f_sqr(p.y);
+    const F X2 = f_add_lazy(p.x, p.x), X4 = f_add_lazy(X2, X2);  // < 8p
+    const F D = f_mul(X4, B);
+    const F E = f_add_lazy(f_add_lazy(A, A), A);                 // < 6p
+    const F B2 = f_add_lazy(B, B), B4 = f_add_lazy(B2, B2);      // < 4p, < 8p
+    const F n4X = f_neg_lazy<8>(X4), n4B = f_neg_lazy<8>(B4);    // 8p - 4X, 8p - 4B
+    const F X3 = f_sp2<6, 4>(E, E, n4X, B2);
+    const F Y3 = f_sp2<4, 4>(E, f_sub_lazy<2>(D, X3), n4B, B2);
+    const F Z3 = f_mul(f_add_lazy(p.y, p.y), p.z);
     r.x = X3;
+    r.y = Y3;
     r.z = Z3;
 }
 // the out-of-line forms: every point they are handed is a local of the caller (private segment, see ecg_priv_load)

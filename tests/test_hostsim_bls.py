@@ -349,3 +349,15 @@ def test_lane_group_vm_pairing_programs(entry):
     got = f12_un(out.raw)
     # the programs compute f^(3 (p^12 - 1)/r) like csrc/bls_pairing.h (the factor 3 keeps == 1 intact)
     assert got == B.f12_mul(B.f12_sqr(want), want) or got == want
+
+
+def test_no_column_overflow_anywhere_in_the_suite():
+    """Every accumulation of the host lane simulator is checked for 64-bit overflow (csrc/bls_fp.h); after everything above
+    -- tower, pairing, group laws, hash-to-curve, verification -- the counter must still be zero."""
+    L = lib()
+    L.hs_column_overflows.restype = ctypes.c_uint64
+    # run one more full verification so that the counter covers a complete path even when this test runs alone
+    from tests import _blscases as C
+    pk = B.sk_to_pk(C.CAN_SIGN_SK)
+    assert L.hs_fast_aggregate_verify(bytes(pk), 1, bytes(C.CAN_SIGN_MSG), len(C.CAN_SIGN_MSG), bytes(C.CAN_SIGN_SIG), 0) == 0
+    assert L.hs_column_overflows() == 0
