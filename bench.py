@@ -151,7 +151,7 @@ R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 # tuple): (fp_mul calls, fp_sqr calls, multiplies inside sums of products) per stage.  An Fp product is 351 (273 for a
 # square) multiply instructions (v_mad_u64_u32 / v_mul_lo_u32), a sum of N products with one reduction 169 N + 182, see
 # csrc/bls_fp.h.
-BLS_OPS = {"bls_pk_validate": (485, 1064, 0), "bls_sig": (218, 756, 439088), "bls_h2c": (875, 3037, 1021020),
+BLS_OPS = {"bls_pk_validate": (485, 686, 131040), "bls_sig": (218, 756, 522626), "bls_h2c": (875, 3037, 1189422),
            "bls_pairing": (651, 382, 7239674)}
 BLS_MULTS_PER_SIG = sum(m * 351 + s * 273 + x for m, s, x in BLS_OPS.values())
 BLS_BYTES_PER_SIG = 48 + 32 + 96 + 1  # K = 1 tuple in, status byte out
