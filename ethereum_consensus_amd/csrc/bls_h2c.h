@@ -101,8 +101,16 @@ ECG_HD Fp2 fp2_horner(const Fp2* c, int deg, const Fp2& x) {
 
 // simplified SWU onto E2' (RFC 9380 6.6.2, straight-line form) then the 3-isogeny to E2, result in
 // Jacobian coordinates (no inversion for the isogeny denominators).
-ECG_HD_NOINLINE void map_to_curve_g2(J2& r_out, const Fp2& u_in) {
+// tv2 = Z^2 u^4 + Z u^2, the quantity SSWU inverts
+ECG_HD Fp2 sswu_tv2(const Fp2& u) {
+    const Fp2 tv1 = fp2_mulx(blsc::SSWU_Z, fp2_sqrx(u));
+    return fp2_add(fp2_sqrx(tv1), tv1);
+}
+// tv2_inv_in: 1 / tv2 (ignored when tv2 = 0) -- the caller inverts the tv2 of both field elements of a message with ONE
+// exponentiation (Montgomery's trick), see hash_to_g2.
+ECG_HD_NOINLINE void map_to_curve_g2(J2& r_out, const Fp2& u_in, const Fp2& tv2_inv_in) {
     const Fp2 u = ecg_priv_load(u_in);  // operands are locals of the caller (private segment)
+    const Fp2 tv2_inv = ecg_priv_load(tv2_inv_in);
     J2 r;
     Fp2 tv1 = fp2_mulx(blsc::SSWU_Z, fp2_sqrx(u));
     Fp2 tv2 = fp2_add(fp2_sqrx(tv1), tv1);
@@ -110,7 +118,7 @@ ECG_HD_NOINLINE void map_to_curve_g2(J2& r_out, const Fp2& u_in) {
     if (fp2_is_zero(tv2)) {
         x1 = blsc::SSWU_B_OVER_ZA;
     } else {
-        x1 = fp2_mulx(blsc::SSWU_MB_OVER_A, fp2_add(fp2_one(), fp2_inv(tv2)));
+        x1 = fp2_mulx(blsc::SSWU_MB_OVER_A, fp2_add(fp2_one(), tv2_inv));
     }
     Fp2 gx1 = fp2_add(fp2_add(fp2_mulx(fp2_sqrx(x1), x1), fp2_mulx(blsc::SSWU_A, x1)), blsc::SSWU_B);
     // Exactly one of gx1, gx2 = g(Z u^2 x1) = (Z u^2)^3 gx1 is a square.  Decide on the NORM of gx1 (one Fp
@@ -187,9 +195,16 @@ ECG_HD_NOINLINE void hash_to_g2(A2& r, const u8* msg, size_t msg_len) {
     xmd_expand_256(xm, msg, msg_len);
     Fp2 u0 = Fp2{fp_from_be64(xm), fp_from_be64(xm + 64)};
     Fp2 u1 = Fp2{fp_from_be64(xm + 128), fp_from_be64(xm + 192)};
+    // one inversion for the two SSWU maps: 1/t0 = t1 / (t0 t1), 1/t1 = t0 / (t0 t1); a zero tv2 (the exceptional case
+    // of the map, which then ignores its inverse) is replaced by 1 so that it does not poison the other one
+    Fp2 t0 = sswu_tv2(u0), t1 = sswu_tv2(u1);
+    if (fp2_is_zero(t0)) t0 = fp2_one();
+    if (fp2_is_zero(t1)) t1 = fp2_one();
+    const Fp2 ti = fp2_inv(fp2_mulx(t0, t1));
+    const Fp2 i0 = fp2_mulx(ti, t1), i1 = fp2_mulx(ti, t0);
     J2 q0, q1;
-    map_to_curve_g2(q0, u0);
-    map_to_curve_g2(q1, u1);
+    map_to_curve_g2(q0, u0, i0);
+    map_to_curve_g2(q1, u1, i1);
     jac_add(q0, q0, q1);
     g2_clear_cofactor(q0, q0);
     A2 a;
