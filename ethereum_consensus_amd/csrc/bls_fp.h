@@ -4,10 +4,11 @@
 // One lane = one field operation.  Fp = 13 x 30-bit limbs, Montgomery R = 2^390, values kept
 // "almost reduced" (< 2p, limbs < 2^30): see bls_types.h for why.  The Montgomery product is
 // operand scanning over 64-bit column accumulators: 13 rows x (13 a*b + 13 m*p) independent
-// v_mad_u64_u32 + 13 v_mul_lo_u32 for the quotient digits = 351 quarter-rate multiplies and
-// ~200 full-rate ops per Fp product -- the unit the BLS roofline in DESIGN.md is priced in.
-// fp_mul / fp_sqr are real calls (ECG_HD_NOINLINE): one body per kernel instead of one per use,
-// which keeps the pairing kernels inside the instruction cache and the build in seconds.
+// v_mad_u64_u32 + 13 v_mul_lo_u32 for the quotient digits = 351 multiplies and ~200 cheap ops per Fp product.
+// Two forms are built on it: fp_mul / fp_sqr, real calls (one body per kernel: exponentiation chains, G1 arithmetic), and
+// fp_sumprod<N>, an inline sum of N products with ONE reduction over lazily reduced operands -- what the Fp2 / Fp6 / Fp12
+// tower and the G2 formulas are made of, because on this machine a modular addition costs a sixth of a product
+// (DESIGN.md 3.1).
 #pragma once
 #include "bls_consts.h"
 
@@ -341,9 +342,6 @@ static __device__ __attribute__((noinline)) fp_vec13 fp_mul_call(fp_vec13 a, fp_
     for (int i = 0; i < FP_N; i++) o[i] = r.l[i];
     return o;
 }
-#if defined(ECG_FP_MUL_INLINE)
-ECG_HD Fp fp_mul(const Fp& a, const Fp& b) { return fp_mul_body(a, b); }  // experiment: no call at all
-#else
 ECG_HD Fp fp_mul(const Fp& a, const Fp& b) {
     fp_vec13 x, y;
 #pragma unroll
@@ -357,7 +355,6 @@ ECG_HD Fp fp_mul(const Fp& a, const Fp& b) {
     for (int i = 0; i < FP_N; i++) r.l[i] = o[i];
     return r;
 }
-#endif
 #else
 ECG_HD_NOINLINE Fp fp_mul(Fp a, Fp b) {
     ECG_COUNT_MUL();

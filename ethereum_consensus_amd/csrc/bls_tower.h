@@ -1,47 +1,24 @@
 // Fp6 / Fp12 tower arithmetic for the BLS12-381 pairing on gfx950:
 //   Fp6 = Fp2[v]/(v^3 - xi), xi = 1 + i;   Fp12 = Fp6[w]/(w^2 - v).
 // (blst's fp12_tower.c layer under /root/reference/ethereum-consensus/src/crypto/bls.rs:69-71,
-// 102-106, 122-126 -- the verify calls.)  An Fp12 is 12 x 13 dwords: it never fits in VGPRs next
-// to its operands, so the Fp6-level routines work memory-to-memory on references (the lane's private
-// segment) and keep everything inside them in registers; the Fp6 additions of the Fp12 formulas are
-// fused into the routine that consumes or produces their operands, because the lane kernels are bound
-// by private-segment traffic to HBM, not by arithmetic.
+// 102-106, 122-126 -- the verify calls.)  Products are sums of half-products with one Montgomery reduction per
+// coefficient over lazy operands (bls_fp.h fp_sumprod): schoolbook in Fp2 and Fp6, Karatsuba only at the Fp12 level.
+// An Fp12 is 12 x 13 dwords; the accumulators of the Miller loop and of the final exponentiation are kept as local
+// values so that they stay in the 512-entry register file across an iteration.
 #pragma once
 #include "bls_fp.h"
 
-// Call structure of the lane kernels.  A routine that keeps values live across the out-of-line Fp products holds them
-// in callee-saved registers and must save / restore those at its own entry / exit: measured 229-282 dwords per
-// Fp6-product call, the bulk of k_pairing's private-segment traffic.  Inlining a level removes its saves (a kernel has
-// no caller to save for) at the price of code size:  ECG_INLINE_LEVEL 0: Fp6- and Fp12-level routines are calls (40.9 ms);
-// 1 (default): Fp6-level routines inline into the Fp12-level ones (39.3 ms, a third fewer saves) and the doubling iteration
-// of the Miller loop (accumulator squaring, doubling step, line multiplication) inlines into miller_loop (36.5 ms);
-// inlining the cyclotomic squaring into its loop as well changes nothing; 2: all Fp12-level routines and
-// the Miller steps inline as well (47 ms: one 2.8 MB function, the register allocator spills more than it saves).
-#ifndef ECG_INLINE_LEVEL
-#define ECG_INLINE_LEVEL 1
-#endif
-#if ECG_INLINE_LEVEL >= 1
+// Call structure of the lane kernels (every step measured on 65 536 tuples).  The Fp6-level routines and
+// the sums of products under them are inline: their operands are SSA values in VGPRs / AGPRs, and an out-of-line routine
+// that keeps values live across calls must save callee-saved registers on every entry (229-282 dwords per Fp6 product
+// when those were calls: the bulk of the round-1 private-segment traffic).  The Fp12-level routines are out of line -- one
+// copy of each per kernel, operands copied through private-segment pointers (ecg_priv_load) -- except where a loop runs
+// them on a register-resident accumulator: the doubling iteration of the Miller loop (accumulator squaring, doubling step,
+// line product) and the cyclotomic squaring inside the exponentiations by x.  Everything inline was slower (one 2.8 MB
+// function, the register allocator spills more than the calls cost).
 #define ECG_FP6_FN ECG_HD
-#else
-#define ECG_FP6_FN ECG_HD_NOINLINE
-#endif
-#if ECG_INLINE_LEVEL >= 2
-#define ECG_FP12_FN ECG_HD
-#else
 #define ECG_FP12_FN ECG_HD_NOINLINE
-#endif
-// the doubling iteration of the Miller loop (accumulator squaring, doubling step, line multiplication): one instance each
-#if ECG_INLINE_LEVEL >= 1 || defined(ECG_INLINE_MILLER_DBL)
 #define ECG_MILLER_DBL_FN ECG_HD
-#else
-#define ECG_MILLER_DBL_FN ECG_HD_NOINLINE
-#endif
-// the cyclotomic squaring inside the 63-step exponentiation loops of the final exponentiation
-#if ECG_INLINE_LEVEL >= 2 || defined(ECG_INLINE_CYC_SQR)
-#define ECG_CYC_SQR_FN ECG_HD
-#else
-#define ECG_CYC_SQR_FN ECG_HD_NOINLINE
-#endif
 
 namespace ecg {
 
