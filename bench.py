@@ -438,12 +438,13 @@ def main():
         # box self-check (csrc/selfcheck.hip): 2^21 multiply-adds per lane as a loop over 8 KB and over 1 MB of code.  On a
         # healthy box both take the same time; where the second is several times slower, so are the lane kernels above.
         import ctypes
-        ms_small, ms_large = ctypes.c_double(0), ctypes.c_double(0)
-        if L.ecgpu_selfcheck_ifetch(ctypes.byref(ms_small), ctypes.byref(ms_large)) == 0 and ms_small.value > 0:
-            line["box_selfcheck"] = {"mad_loop_8KB_ms": ms_small.value, "mad_loop_1MB_ms": ms_large.value,
-                                     "large_code_slowdown": ms_large.value / ms_small.value,
-                                     "note": "instruction fetch for straight-line code far beyond the 64 KB instruction cache; "
-                                             "~1.0 on a healthy box (DESIGN.md 3.3)"}
+        sweep = (ctypes.c_double * 4)()
+        if L.ecgpu_selfcheck_ifetch_sweep(sweep) == 0 and sweep[0] > 0:
+            line["box_selfcheck"] = {"mad_loop_8KB_ms": sweep[0], "mad_loop_64KB_ms": sweep[1], "mad_loop_256KB_ms": sweep[2],
+                                     "mad_loop_1MB_ms": sweep[3], "large_code_slowdown": sweep[3] / sweep[0],
+                                     "note": "2^21 multiply-adds per lane as loops over 8 KB .. 1 MB of code: instruction fetch far beyond the "
+                                             "64 KB instruction cache; slowdown ~1.0 on a healthy box, 2.2 measured on a slow one "
+                                             "(DESIGN.md 3.3)"}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

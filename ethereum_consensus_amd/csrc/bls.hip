@@ -260,7 +260,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     if (fork) {
         int rc = ax.init();
         if (rc) return rc;
-        s2 = ax.st[0];
+        s2 = ax.st[2];  // st[0] / st[1] carry the small fields of a state root the same thread may have in flight
         ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
         ECG_HIP_CHECK(hipStreamWaitEvent(s2, ax.fork, 0));
         if (key_heavy) {
@@ -288,8 +288,8 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         hipLaunchKernelGGL(k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
     }
     if (fork) {
-        ECG_HIP_CHECK(hipEventRecord(ax.done[0], s2));
-        ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[0], 0));
+        ECG_HIP_CHECK(hipEventRecord(ax.done[2], s2));
+        ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[2], 0));
         if (s3 != s) {
             ECG_HIP_CHECK(hipEventRecord(ax.done[1], s3));
             ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[1], 0));
@@ -353,7 +353,7 @@ static int fav_batch_host(const u8* pks48, const u32* pk_off, u32 n_pks, const u
     if (msg_off && (rc = h2d(k, d_moff, msg_off, (size_t)(n + 1) * 8))) return rc;
     u8* d_status = k.ar->take(n);
     if (!d_status) return ECGPU_ERR_OOM;
-    rc = fav_batch_device(k.s, d_pks, (const u32*)d_off, n_pks, d_msgs, (const u64*)d_moff, d_sigs, n, eth_variant, d_status, *k.ar, k.c->aux_bls);
+    rc = fav_batch_device(k.s, d_pks, (const u32*)d_off, n_pks, d_msgs, (const u64*)d_moff, d_sigs, n, eth_variant, d_status, *k.ar, k.c->aux);
     if (rc) return rc;
     ECG_HIP_CHECK(hipMemcpyAsync(status_out, d_status, n, hipMemcpyDeviceToHost, k.s));
     ECG_HIP_CHECK(hipStreamSynchronize(k.s));
@@ -383,7 +383,7 @@ int ecgpu_fast_aggregate_verify_batch_dev(const uint8_t* d_pks48, const uint32_t
     CallCtx k;
     int rc = begin_call(k, stream, fav_ws_bytes(n, n_pks_total));
     if (rc) return rc;
-    return fav_batch_device(k.s, d_pks48, d_pk_off, n_pks_total, d_msgs32, nullptr, d_sigs96, n, eth_variant, d_status_out, *k.ar, k.c->aux_bls);
+    return fav_batch_device(k.s, d_pks48, d_pk_off, n_pks_total, d_msgs32, nullptr, d_sigs96, n, eth_variant, d_status_out, *k.ar, k.c->aux);
 }
 
 int ecgpu_registry_create(uint64_t capacity, ecgpu_registry_t** out) {
@@ -442,7 +442,7 @@ int ecgpu_fast_aggregate_verify_indexed_batch_dev(const ecgpu_registry_t* reg, c
     int rc = begin_call(k, stream, fav_ws_bytes(n, 0));
     if (rc) return rc;
     return fav_batch_device(k.s, nullptr, d_idx_off, n_indices_total, d_msgs32, nullptr, d_sigs96, n, eth_variant, d_status_out, *k.ar,
-                            k.c->aux_bls, reg, d_indices);
+                            k.c->aux, reg, d_indices);
 }
 
 int ecgpu_fast_aggregate_verify_indexed_batch(const ecgpu_registry_t* reg, const uint32_t* indices, const uint32_t* idx_off,
@@ -464,7 +464,7 @@ int ecgpu_fast_aggregate_verify_indexed_batch(const ecgpu_registry_t* reg, const
     if ((rc = h2d(k, d_sigs, sigs96, (size_t)n * 96))) return rc;
     u8* d_status = k.ar->take(n);
     if (!d_status) return ECGPU_ERR_OOM;
-    rc = fav_batch_device(k.s, nullptr, (const u32*)d_off, n_idx, d_msgs, nullptr, d_sigs, n, eth_variant, d_status, *k.ar, k.c->aux_bls, reg,
+    rc = fav_batch_device(k.s, nullptr, (const u32*)d_off, n_idx, d_msgs, nullptr, d_sigs, n, eth_variant, d_status, *k.ar, k.c->aux, reg,
                           (const u32*)d_idx);
     if (rc) return rc;
     ECG_HIP_CHECK(hipMemcpyAsync(status_out, d_status, n, hipMemcpyDeviceToHost, k.s));

@@ -55,9 +55,12 @@ struct AuxStreams {
 
 struct ThreadCtx {
     hipStream_t own_stream = nullptr;
-    AuxStreams aux;      // state roots: the fields underneath the validator registry
-    AuxStreams aux_bls;  // BLS batches: signature / message stages (their own set, so that a state root and a verification
-                         // enqueued by one host thread on two streams do not serialize on shared auxiliary streams)
+    // ONE set of three auxiliary streams per host thread.  State roots use st[0] (tile stages, batched jobs) and st[1]
+    // (fields that need passes of their own); BLS batches use st[2] (message stage) and st[1] (signature stage of
+    // key-heavy batches).  Not a set each: the runtime multiplexes streams onto 4 hardware queues, and with more live streams
+    // than that the auxiliary ones start sharing a queue with the caller's stream -- measured: the state root loses its
+    // overlap (1.05 -> 1.21 ms) as soon as a second set merely exists (profiles/r01s16_hw_queues.txt).
+    AuxStreams aux;
     std::map<hipStream_t, Arena> arenas;
     PinnedBuf staging;      // host-pinned staging for small H2D/D2H payloads
     u64 last_hash64 = 0;

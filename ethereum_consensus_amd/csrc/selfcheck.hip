@@ -67,3 +67,22 @@ extern "C" int ecgpu_selfcheck_ifetch(double* ms_small_loop, double* ms_large_lo
     if (rc) return rc;
     return time_probe<131072>(s, d_out, 16, ms_large_loop);
 }
+
+// the same work over loops of 8 KB, 64 KB, 256 KB and 1 MB of code: where the slowdown of a slow box sets in
+extern "C" int ecgpu_selfcheck_ifetch_sweep(double ms[4]) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!ms) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    Arena& ar = c->arena(s);
+    ar.reset();
+    rc = ar.reserve(1024 * 64 * 4 + 256);
+    if (rc) return rc;
+    u32* d_out = (u32*)ar.take(1024 * 64 * 4);
+    if (!d_out) return ECGPU_ERR_OOM;
+    if ((rc = time_probe<1024>(s, d_out, 2048, &ms[0]))) return rc;
+    if ((rc = time_probe<8192>(s, d_out, 256, &ms[1]))) return rc;
+    if ((rc = time_probe<32768>(s, d_out, 64, &ms[2]))) return rc;
+    return time_probe<131072>(s, d_out, 16, &ms[3]);
+}

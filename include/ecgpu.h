@@ -234,6 +234,8 @@ int ecgpu_prof_read(const char* kernel_tag, double* total_ms, uint64_t* launches
 /* Box self-check: the same 2^21 multiply-adds per lane as a loop over 8 KB of code and as a loop over 1 MB of code
  * (one wave per SIMD, like the BLS lane kernels).  The two take the same time on a healthy box. */
 int ecgpu_selfcheck_ifetch(double* ms_small_loop, double* ms_large_loop);
+/* the same work over loops of 8 KB, 64 KB, 256 KB and 1 MB of code */
+int ecgpu_selfcheck_ifetch_sweep(double ms[4]);
 
 #ifdef __cplusplus
 }
