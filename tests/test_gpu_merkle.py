@@ -299,3 +299,15 @@ def test_sharded_big_lists_equal_the_unsharded_roots(gpu):
     # single-process form of the host helper (world 1: no collective)
     assert gpu.hash_tree_root_validators_sharded(None, vals, n) == full
     assert gpu.merkleize_sharded(None, bal, n_chunks, limit_chunks, n) == full_bal
+
+
+def test_box_selfcheck_runs_and_reports_positive_times(gpu):
+    """ecgpu_selfcheck_ifetch[_sweep]: the instruction-fetch probe bench.py reports next to its numbers."""
+    from ethereum_consensus_amd import _lib
+    L = _lib.load()
+    a, b = ctypes.c_double(0), ctypes.c_double(0)
+    assert L.ecgpu_selfcheck_ifetch(ctypes.byref(a), ctypes.byref(b)) == 0
+    assert 0.5 < a.value < 100 and 0.5 < b.value < 1000
+    sweep = (ctypes.c_double * 4)()
+    assert L.ecgpu_selfcheck_ifetch_sweep(sweep) == 0
+    assert all(0.5 < x < 1000 for x in sweep)
