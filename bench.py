@@ -133,7 +133,8 @@ def run_merkle(args, L, torch, dist, rank, world):
                 "sharding": "one independent state per GPU; all-gather of the 32-byte roots"},
         roofline={"bound": "hbm", "kernel": "k_merkle_pass<2, ValidatorLeaves>", "achieved": achieved,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                  "traffic": pmc_traffic("k_merkle_pass<2, ValidatorLeaves>"),
+                  "traffic": (pmc_traffic("k_merkle_pass<2, ValidatorLeaves>") or {}).get("bytes_per_launch"),
+                  "traffic_detail": pmc_traffic("k_merkle_pass<2, ValidatorLeaves>"),
                   "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches_timed": int(nl.value),
                   "launch_note": "per state root: the validator pass goes out as two half-range launches; bytes and ms are their sum",
                   "valu_int": {"unit": "G hash64/s", "achieved": val_hashes / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0,
@@ -278,7 +279,8 @@ def run_bls(args, L, torch, dist, rank, world):
                                           "decompressed + subgroup-checked, every message hashed to G2, per-tuple pairing check",
                 "sharding": "one independent batch per GPU; all-gather of the status bytes every step"},
         roofline={"bound": "hbm", "kernel": "k_pairing", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_pairing"), "algorithmic_bytes_per_launch": alg_bytes,
+                  "frac": achieved / HBM_PEAK_GBS, "traffic": (pmc_traffic("k_pairing") or {}).get("bytes_per_launch"), "traffic_detail": pmc_traffic("k_pairing"),
+                  "algorithmic_bytes_per_launch": alg_bytes,
                   "avg_launch_ms": kern_ms, "stage_ms": stages,
                   "valu_int": {"unit": "T multiplies/s (v_mad_u64_u32 + v_mul_lo_u32)", "peak": MUL_PIPE_PEAK_TOPS,
                                "achieved": {k: (mul_ops[k] / (stages[k] * 1e-3) / 1e12 if stages[k] > 0 else 0.0) for k in stages},
