@@ -444,6 +444,7 @@ def main():
         if L.ecgpu_selfcheck_ifetch_sweep(sweep) == 0 and sweep[0] > 0:
             line["box_selfcheck"] = {"mad_loop_8KB_ms": sweep[0], "mad_loop_64KB_ms": sweep[1], "mad_loop_256KB_ms": sweep[2],
                                      "mad_loop_1MB_ms": sweep[3], "large_code_slowdown": sweep[3] / sweep[0],
+                                     "pairing_kernels": {1: "sums of products", 2: "compact-code tower"}.get(int(L.ecgpu_bls_tower()), "?"),
                                      "note": "2^21 multiply-adds per lane as loops over 8 KB .. 1 MB of code: instruction fetch far beyond the "
                                              "64 KB instruction cache; slowdown ~1.0 on a healthy box, 2.2 measured on a slow one "
                                              "(DESIGN.md 3.3)"}

@@ -91,6 +91,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_prof_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_u64)]),
         "ecgpu_selfcheck_ifetch": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
         "ecgpu_selfcheck_ifetch_sweep": (c_int, [ctypes.POINTER(ctypes.c_double)]),
+        "ecgpu_bls_tower": (c_int, []),
     }
     missing = []
     for name, (res, args) in sig.items():

@@ -101,23 +101,26 @@ def build_lib(verbose: bool = True) -> str:
     return LIB
 
 
-def build_hostsim(verbose: bool = True) -> str:
-    """g++ build of the same csrc headers: CPU-side kernel simulator for tests ONLY."""
+def build_hostsim(verbose: bool = True, variant: str = "") -> str:
+    """g++ build of the same csrc headers: CPU-side kernel simulator for tests ONLY.  variant "calls": the compact-code
+    tower of the slow-box pairing kernels (-DECG_TOWER_CALLS), a library of its own."""
     d = os.path.join(ROOT, "tests", "hostsim")
     generate_vm_programs(verbose)
     srcs = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".cpp"))
-    out = os.path.join(d, "libhostsim.so")
+    tag = "_" + variant if variant else ""
+    defs = ["-DECG_TOWER_CALLS"] if variant == "calls" else []
+    out = os.path.join(d, f"libhostsim{tag}.so")
     os.makedirs(os.path.join(d, "obj"), exist_ok=True)
     objs, jobs = [], []
     for src in srcs:
-        obj = os.path.join(d, "obj", os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(d, "obj", os.path.basename(src)[:-4] + tag + ".o")
         objs.append(obj)
         if _newer(obj, [src] + _headers()):
-            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
-                         "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), src, "-o", obj])
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"] + defs
+                        + ["-I" + CSRC, "-I" + os.path.join(ROOT, "include"), src, "-o", obj])
     if jobs:
         if verbose:
-            print("[ecgpu build] building tests/hostsim", flush=True)
+            print("[ecgpu build] building tests/hostsim" + tag, flush=True)
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(_run, jobs))
     if jobs or _newer(out, objs):

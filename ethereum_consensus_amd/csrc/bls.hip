@@ -20,7 +20,9 @@
 #include "bls_kernels.h"
 #include "runtime.h"
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 
 namespace ecg {
@@ -104,27 +106,7 @@ static void launch_sum(hipStream_t s, u32 n_tuples, u32 n_pts, const Aff<F>* pts
         hipLaunchKernelGGL((k_sum<F, 64>), dim3(n_tuples), dim3(64), 0, s, pts, st, off, n_pts, out, out_st, idx, idx_limit);
 }
 
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sig(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp) {
-    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    A2 p;
-    u8 sd, sg;
-    stage_sig(p, sd, sg, sigs96 + 96 * (size_t)i);
-    pts[i] = p;
-    st_dec[i] = sd;
-    st_grp[i] = sg;
-}
-
-// msg_off == nullptr: message i = msgs + 32 i (32 bytes)
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_h2c(const u8* msgs, const u64* msg_off, u32 n, A2* hpts) {
-    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const u8* m = msg_off ? msgs + msg_off[i] : msgs + 32 * (size_t)i;
-    size_t len = msg_off ? (size_t)(msg_off[i + 1] - msg_off[i]) : 32;
-    A2 h;
-    hash_to_g2(h, m, len);
-    hpts[i] = h;
-}
+// k_sig, k_h2c: bls_g2_kernels.hip (built twice like the pairing kernels: sums of products / compact-code tower)
 
 // k_pairing, k_miller_pairs, k_aggv_final: bls_pairing_kernels.hip (a translation unit of its own: the tower code under
 // them is most of the compile time, and the two units build side by side)
@@ -214,6 +196,27 @@ static const int g_pairing_mode = [] {
     if (e && !strcmp(e, "vm2")) return 2;
     return 3;
 }();
+// Which tower the lane pairing kernels run on: 1 = sums of products (bls_pairing_kernels.hip), 2 = the compact-code tower
+// (bls_pairing_kernels_calls.hip).  ECGPU_TOWER=sums|calls forces one; otherwise the box self-check decides once per
+// process: where a 1 MB loop of multiply-adds runs more than 1.5x slower than an 8 KB one, instruction fetch does not
+// keep up with megabytes of straight-line code and the compact kernels win.
+static std::atomic<int> g_tower{0};
+static int decide_tower() {
+    int t = g_tower.load();
+    if (t) return t;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((t = g_tower.load())) return t;
+    const char* e = getenv("ECGPU_TOWER");
+    if (e && !strcmp(e, "sums")) t = 1;
+    else if (e && !strcmp(e, "calls")) t = 2;
+    else {
+        double ms_small = 0, ms_large = 0;
+        t = (ecgpu_selfcheck_ifetch(&ms_small, &ms_large) == 0 && ms_small > 0 && ms_large > 1.5 * ms_small) ? 2 : 1;
+    }
+    g_tower.store(t);
+    return t;
+}
 static const u32 g_vm2_max_tuples = [] {
     const char* e = getenv("ECGPU_VM2_MAX");
     return e ? (u32)strtoul(e, nullptr, 10) : 12288u;
@@ -281,11 +284,11 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     {
         hipStream_t s_sig = s3;
         ProfScope ps("bls_sig", s_sig);
-        hipLaunchKernelGGL(k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s_sig, d_sigs96, n, sigpts, st_dec, st_grp);
+        hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s_sig, d_sigs96, n, sigpts, st_dec, st_grp);
     }
     {
         ProfScope ps("bls_h2c", s2);
-        hipLaunchKernelGGL(k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
+        hipLaunchKernelGGL(g_tower.load() == 2 ? k_h2c_calls : k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
     }
     if (fork) {
         ECG_HIP_CHECK(hipEventRecord(ax.done[2], s2));
@@ -299,8 +302,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         ProfScope ps("bls_pairing", s);
         const bool use_vm = g_pairing_mode == 2 || (g_pairing_mode == 3 && n <= g_vm2_max_tuples);
         if (!use_vm) {
-            hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
-                               (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, 0);
+            hipLaunchKernelGGL(g_tower.load() == 2 ? k_pairing_calls : k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg,
+                               (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96,
+                               n, eth_variant, d_status, 0);
         } else {
             u32* xfer = (u32*)ar.take(vm2_xfer_bytes(n));
             if (!xfer) return ECGPU_ERR_OOM;
@@ -308,8 +312,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
                                         (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
             if (rc) return rc;
             // tuples with a point at infinity in the pairing (signature 0xc0.., H(m) = inf): rare, branchy lane kernel
-            hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
-                               (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, 1);
+            hipLaunchKernelGGL(g_tower.load() == 2 ? k_pairing_calls : k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg,
+                               (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96,
+                               n, eth_variant, d_status, 1);
         }
     }
     ECG_HIP_CHECK(hipGetLastError());
@@ -324,6 +329,7 @@ struct CallCtx {
 static int begin_call(CallCtx& k, ecgpu_stream_t stream, size_t ws) {
     int rc = ensure_init();
     if (rc) return rc;
+    (void)decide_tower();  // first call of the process: may run the box self-check, which uses this thread's arena
     k.c = tctx();
     k.s = k.c->stream_or_own(stream);
     k.ar = &k.c->arena(k.s);
@@ -513,14 +519,14 @@ int ecgpu_aggregate_verify(const uint8_t* pks48, uint32_t n_pks, const uint8_t* 
     u8* d_status = k.ar->take(1);
     if (!pts || !st || !hpts || !sigpt || !st_dec || !st_grp || !fs || !d_status) return ECGPU_ERR_OOM;
     if (np) hipLaunchKernelGGL(k_pk_validate, grid_for(np), dim3(BLS_BLOCK), 0, k.s, d_pks, np, pts, st);
-    hipLaunchKernelGGL(k_sig, grid_for(1), dim3(BLS_BLOCK), 0, k.s, d_sig, 1u, sigpt, st_dec, st_grp);
+    hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(1), dim3(BLS_BLOCK), 0, k.s, d_sig, 1u, sigpt, st_dec, st_grp);
     if (npair) {
-        hipLaunchKernelGGL(k_h2c, grid_for(nm), dim3(BLS_BLOCK), 0, k.s, d_msgs, (const u64*)d_moff, nm, hpts);
-        hipLaunchKernelGGL(k_miller_pairs, grid_for(npair + 1), dim3(BLS_BLOCK), 0, k.s, (const A1*)pts, (const A2*)hpts,
-                           (const A2*)sigpt, npair, fs);
+        hipLaunchKernelGGL(g_tower.load() == 2 ? k_h2c_calls : k_h2c, grid_for(nm), dim3(BLS_BLOCK), 0, k.s, d_msgs, (const u64*)d_moff, nm, hpts);
+        hipLaunchKernelGGL(g_tower.load() == 2 ? k_miller_pairs_calls : k_miller_pairs, grid_for(npair + 1), dim3(BLS_BLOCK), 0, k.s,
+                           (const A1*)pts, (const A2*)hpts, (const A2*)sigpt, npair, fs);
     }
-    hipLaunchKernelGGL(k_aggv_final, dim3(1), dim3(BLS_BLOCK), 0, k.s, (const u8*)st, np, nm, (const u8*)st_dec, (const u8*)st_grp,
-                       (const Fp12*)fs, d_status);
+    hipLaunchKernelGGL(g_tower.load() == 2 ? k_aggv_final_calls : k_aggv_final, dim3(1), dim3(BLS_BLOCK), 0, k.s, (const u8*)st, np, nm,
+                       (const u8*)st_dec, (const u8*)st_grp, (const Fp12*)fs, d_status);
     ECG_HIP_CHECK(hipGetLastError());
     u8 out = 0xff;
     ECG_HIP_CHECK(hipMemcpyAsync(&out, d_status, 1, hipMemcpyDeviceToHost, k.s));
@@ -542,7 +548,7 @@ int ecgpu_aggregate_sigs(const uint8_t* sigs96, uint32_t n, uint8_t* out96) {
     A2* sum = (A2*)k.ar->take(sizeof(A2));
     u8* d_out = k.ar->take(96 + 1);
     if (!pts || !st_dec || !st_grp || !sum || !d_out) return ECGPU_ERR_OOM;
-    hipLaunchKernelGGL(k_sig, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_sigs, n, pts, st_dec, st_grp);
+    hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_sigs, n, pts, st_dec, st_grp);
     hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(64), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
     launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr);
     hipLaunchKernelGGL(k_compress_g2, dim3(1), dim3(64), 0, k.s, (const A2*)sum, d_out);
@@ -634,6 +640,12 @@ int ecgpu_sign_batch(const uint8_t* sks32, const uint8_t* msgs, const uint64_t* 
     ECG_HIP_CHECK(hipMemcpyAsync(sigs96, d_sig, (size_t)n * 96, hipMemcpyDeviceToHost, k.s));
     ECG_HIP_CHECK(hipStreamSynchronize(k.s));
     return ECGPU_SUCCESS;
+}
+
+int ecgpu_bls_tower(void) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    return decide_tower();
 }
 
 }  // extern "C"

@@ -105,6 +105,25 @@ ECG_HD void jac_neg(Jac<F>& r, const Jac<F>& p) {
     r.z = p.z;
 }
 
+#if defined(ECG_TOWER_CALLS)
+// COMPACT-CODE variant: dbl-2009-l as published (5 squarings, 2 products, modular additions).  inf -> inf; y == 0 -> inf.
+template <class F>
+ECG_HD void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
+    F A = f_sqr(p.x);
+    F B = f_sqr(p.y);
+    F C = f_sqr(B);
+    F D = f_sub(f_sub(f_sqr(f_add(p.x, B)), A), C);
+    D = f_dbl(D);
+    F E = f_add(f_dbl(A), A);
+    F Fq = f_sqr(E);
+    F Z3 = f_dbl(f_mul(p.y, p.z));
+    F X3 = f_sub(Fq, f_dbl(D));
+    F C8 = f_dbl(f_dbl(f_dbl(C)));
+    r.y = f_sub(f_mul(E, f_sub(D, X3)), C8);
+    r.x = X3;
+    r.z = Z3;
+}
+#else
 // Doubling (a = 0), the dbl-2009-l quantities regrouped so that no modular addition touches a product:
 //   A = X^2, B = Y^2, D = 4 X B, E = 3A (lazy),
 //   X3 = E^2 - 2D = E E + (8p - 4X)(2B),   Y3 = E (D - X3) - 8 B^2 = E (D - X3 + 2p) + (8p - 4B)(2B),   Z3 = (2Y) Z
@@ -127,6 +146,7 @@ ECG_HD void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
     r.y = Y3;
     r.z = Z3;
 }
+#endif
 // the out-of-line forms: every point they are handed is a local of the caller (private segment, see ecg_priv_load)
 template <class F>
 ECG_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {

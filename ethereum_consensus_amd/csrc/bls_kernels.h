@@ -11,10 +11,22 @@ constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches 
                          // (re-measured after every restructuring)
 #endif
 
+// bls_g2_kernels.hip / bls_g2_kernels_calls.hip
+__global__ void k_sig(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
+__global__ void k_h2c(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
+__global__ void k_sig_calls(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
+__global__ void k_h2c_calls(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
+
 // bls_pairing_kernels.hip
 __global__ void k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out, int only_marked);
 __global__ void k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);
 __global__ void k_aggv_final(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, const Fp12* fs, u8* status_out);
+
+// bls_pairing_kernels_calls.hip: the same three kernels on the compact-code tower
+__global__ void k_pairing_calls(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
+                                const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out, int only_marked);
+__global__ void k_miller_pairs_calls(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);
+__global__ void k_aggv_final_calls(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, const Fp12* fs, u8* status_out);
 
 }  // namespace ecg

@@ -236,6 +236,10 @@ int ecgpu_prof_read(const char* kernel_tag, double* total_ms, uint64_t* launches
 int ecgpu_selfcheck_ifetch(double* ms_small_loop, double* ms_large_loop);
 /* the same work over loops of 8 KB, 64 KB, 256 KB and 1 MB of code */
 int ecgpu_selfcheck_ifetch_sweep(double ms[4]);
+/* Which build of the lane pairing kernels this process uses: 1 = sums of products (fastest on a healthy box), 2 = the
+ * compact-code tower (faster where the self-check above reports a slowdown beyond 1.5).  Decided once per process, at the
+ * first BLS call or here; the environment variable ECGPU_TOWER=sums|calls overrides the self-check. */
+int ecgpu_bls_tower(void);
 
 #ifdef __cplusplus
 }

@@ -334,3 +334,50 @@ def test_validated_key_registry_matches_the_uncached_path(gpu):
         assert got[3] == (0 if eth else B.BLST_AGGR_TYPE_MISMATCH)
         assert got[5] == B.BLST_PK_IS_INFINITY and got[6] == B.BLST_POINT_NOT_IN_GROUP and got[7] == B.BLST_BAD_ENCODING
     reg.close()
+
+
+def test_compact_code_pairing_kernels_in_a_subprocess(gpu):
+    """The second build of the lane pairing kernels (compact-code tower, chosen automatically on boxes whose instruction
+    fetch is slow) must return what the default build returns.  The choice is made once per process, so the
+    forced run lives in a subprocess: reference KAT, a forged message, a faulty batch and aggregate_verify through the lane
+    kernels (ECGPU_PAIRING=lane) of the ECGPU_TOWER=calls build."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from ethereum_consensus_amd import _lib, bls
+from tests import _blscases as C
+L = _lib.load(build_if_missing=False)
+assert L.ecgpu_init(0) == 0
+assert L.ecgpu_bls_tower() == 2
+B = C.B
+pk = bls.sk_to_pk_batch(C.CAN_SIGN_SK.to_bytes(32, "big"))
+bls.verify_signature(pk, C.CAN_SIGN_MSG, C.CAN_SIGN_SIG)
+try:
+    bls.verify_signature(pk, C.CAN_SIGN_MSG + b"x", C.CAN_SIGN_SIG)
+    raise SystemExit("forged message accepted")
+except bls.Error:
+    pass
+for pks, msg, sig, eth in C.fav_cases():
+    want = C.oracle_fav(pks, msg, sig, eth)
+    got = bls.fast_aggregate_verify_status(pks, msg, sig, eth) if hasattr(bls, "fast_aggregate_verify_status") else None
+    if got is not None:
+        assert got == want, (len(pks), eth, got, want)
+sks = [5, 7, 11]
+msgs = [b"a" * 32, b"b" * 32, b"c" * 32]
+pks = [bls.sk_to_pk_batch(s.to_bytes(32, "big")) for s in sks]
+sigs = [bls.sign_batch(s.to_bytes(32, "big"), [m]) for s, m in zip(sks, msgs)]
+agg = bls.aggregate(sigs)
+bls.aggregate_verify(pks, msgs, agg)
+try:
+    bls.aggregate_verify(pks, [msgs[0], msgs[2], msgs[1]], agg)
+    raise SystemExit("permuted messages accepted")
+except bls.Error:
+    pass
+print("compact-code kernels ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    env = dict(os.environ, ECGPU_TOWER="calls", ECGPU_PAIRING="lane")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "compact-code kernels ok" in out.stdout, out.stdout + out.stderr

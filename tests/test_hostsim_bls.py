@@ -283,29 +283,46 @@ def f12_un(b):
     return (((v[0], v[1]), (v[2], v[3]), (v[4], v[5])), ((v[6], v[7]), (v[8], v[9]), (v[10], v[11])))
 
 
-def op12(op, a, b=None):
+_variant_libs = {}
+
+
+def lib_variant(variant):
+    """"" = the sums-of-products tower (what every kernel uses on a healthy box); "calls" = the compact-code tower of the
+    slow-box pairing kernels (-DECG_TOWER_CALLS: Karatsuba over out-of-line Fp products)."""
+    if not variant:
+        return lib()
+    if variant not in _variant_libs:
+        from ethereum_consensus_amd import build
+        _variant_libs[variant] = ctypes.CDLL(build.build_hostsim(verbose=False, variant=variant))
+    return _variant_libs[variant]
+
+
+def op12(op, a, b=None, variant=""):
     out = ctypes.create_string_buffer(576)
-    lib().hs_fp12_op(op, f12_flat(a), f12_flat(b) if b else None, out)
+    lib_variant(variant).hs_fp12_op(op, f12_flat(a), f12_flat(b) if b else None, out)
     return f12_un(out.raw)
 
 
-def test_fp12_tower_and_pairing():
+@pytest.mark.parametrize("variant", ["", "calls"])
+def test_fp12_tower_and_pairing(variant):
     r = random.Random(11)
-    L = lib()
+    L = lib_variant(variant)
+    _op12 = op12
+    op12_v = lambda op, a, b=None: _op12(op, a, b, variant)  # noqa: E731
 
     def rnd12():
         return tuple(tuple((r.randrange(P), r.randrange(P)) for _ in range(3)) for _ in range(2))
 
     a, b = rnd12(), rnd12()
-    assert op12(0, a, b) == B.f12_mul(a, b)
-    assert op12(1, a) == B.f12_sqr(a)
-    assert op12(2, a) == B.f12_inv(a)
-    assert op12(3, a) == B.f12_frob(a)
-    assert op12(4, a) == B.f12_conj(a)
+    assert op12_v(0, a, b) == B.f12_mul(a, b)
+    assert op12_v(1, a) == B.f12_sqr(a)
+    assert op12_v(2, a) == B.f12_inv(a)
+    assert op12_v(3, a) == B.f12_frob(a)
+    assert op12_v(4, a) == B.f12_conj(a)
     fe = B.final_exponentiation(a)
-    assert op12(6, a) == fe
-    assert op12(5, fe) == B.f12_sqr(fe)  # Granger-Scott squaring on a cyclotomic element
-    assert op12(7, fe) == B._cyc_pow_x(fe)
+    assert op12_v(6, a) == fe
+    assert op12_v(5, fe) == B.f12_sqr(fe)  # Granger-Scott squaring on a cyclotomic element
+    assert op12_v(7, fe) == B._cyc_pow_x(fe)
     Pt, Q = B.g1_mul(B.G1, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R))
     out = ctypes.create_string_buffer(576)
     L.hs_pairing(1, a1(Pt), (ctypes.c_int * 1)(0), a2(Q), (ctypes.c_int * 1)(0), out)
@@ -318,8 +335,9 @@ def test_fp12_tower_and_pairing():
     assert f12_un(out.raw) == B.pairing(Pt, Q)
 
 
-def test_fast_aggregate_verify_status_algebra():
-    L = lib()
+@pytest.mark.parametrize("variant", ["", "calls"])
+def test_fast_aggregate_verify_status_algebra(variant):
+    L = lib_variant(variant)
     for pks, msg, sig, eth in C.fav_cases():
         got = L.hs_fast_aggregate_verify(b"".join(pks), len(pks), msg, len(msg), sig, eth)
         assert got == C.oracle_fav(pks, msg, sig, eth), (len(pks), eth)
@@ -361,3 +379,4 @@ def test_no_column_overflow_anywhere_in_the_suite():
     pk = B.sk_to_pk(C.CAN_SIGN_SK)
     assert L.hs_fast_aggregate_verify(bytes(pk), 1, bytes(C.CAN_SIGN_MSG), len(C.CAN_SIGN_MSG), bytes(C.CAN_SIGN_SIG), 0) == 0
     assert L.hs_column_overflows() == 0
+

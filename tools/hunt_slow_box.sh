@@ -1,6 +1,6 @@
 #!/bin/bash
-# One visit of the slow-box hunt: the instruction-fetch self-check; on a slow box also the field probe (loops of
-# 12 KB .. 280 KB of real tower code) and the stage probe.
+# One visit of the slow-box hunt: the instruction-fetch self-check; on a slow box also the stage probe with each build of
+# the pairing kernels (and what the automatic choice picks) and the field probe.
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT" || exit 1
 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/hunt_last.txt
@@ -13,11 +13,14 @@ sw = (ctypes.c_double * 4)()
 for rep in range(2):
     L.ecgpu_selfcheck_ifetch_sweep(sw)
     print("sweep 8KB/64KB/256KB/1MB ms:", [round(x, 2) for x in sw], "slowdown", round(sw[3] / sw[0], 2), flush=True)
+print("automatic choice of the pairing kernels:", L.ecgpu_bls_tower(), "(1 = sums of products, 2 = compact-code tower)")
 open("gpurun_out/hunt_slow", "w").write("1" if sw[3] / sw[0] > 1.4 else "0")
 PY
 if [ "$(cat gpurun_out/hunt_slow)" = "1" ]; then
   echo "SLOW BOX"
-  timeout 300 ./tools/fpbench 2>&1 | grep -v amdgpu.ids | tee gpurun_out/hunt_fpbench_slow.txt | grep -E "fp_mul \(call\)|fp2_mul 2 sums|fp6_mul|fp12|G2 doubling|miller|hash64 chain" 
-  timeout 300 python tools/bls_probe.py 65536 2>&1 | grep "verify iter" | tee gpurun_out/hunt_probe_slow.txt
-  rocm-smi --showmeminfo vram --showclocks 2>/dev/null | grep -E "VRAM|sclk|mclk|fclk" | tee gpurun_out/hunt_smi_slow.txt
+  {
+  for t in sums calls; do echo "== ECGPU_TOWER=$t"; ECGPU_TOWER=$t timeout 300 python tools/bls_probe.py 65536 2>&1 | grep "verify iter"; done
+  echo "== automatic"; timeout 300 python tools/bls_probe.py 65536 2>&1 | grep "verify iter"
+  } | tee gpurun_out/hunt_probe_slow.txt
+  timeout 600 python bench.py --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/hunt_bench_slow.json
 fi
