@@ -75,7 +75,7 @@ ECG_HD bool fp_eq(const Fp& a, const Fp& b) {
     return o == 0;
 }
 
-ECG_HD Fp fp_add(const Fp& a, const Fp& b) {
+ECG_HD Fp fp_add_inl(const Fp& a, const Fp& b) {
     Fp s;
     u32 c = 0;
 #pragma unroll
@@ -87,7 +87,7 @@ ECG_HD Fp fp_add(const Fp& a, const Fp& b) {
     return fp_cond_sub(s, blsc::P2);  // a + b < 4p -> < 2p
 }
 
-ECG_HD Fp fp_sub(const Fp& a, const Fp& b) {
+ECG_HD Fp fp_sub_inl(const Fp& a, const Fp& b) {
     Fp d;
     int32_t bw = 0;
 #pragma unroll
@@ -134,6 +134,52 @@ ECG_HD Fp fp_sub_lazy(const Fp& a, const Fp& b) {  // a - b + 2p in (0, a + 2p) 
     return s;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ECG_TOWER_CALLS) && defined(ECG_LINEAR_CALLS)
+// compact build: the modular additions are calls too (two 13-element vectors in, one out: ~30 instructions per use instead
+// of ~100), so that the Miller iteration of the compact kernels fits the 64 KB instruction cache
+typedef u32 fp_lin_vec13 __attribute__((ext_vector_type(13)));
+static __device__ __attribute__((noinline)) fp_lin_vec13 fp_add_call(fp_lin_vec13 a, fp_lin_vec13 b) {
+    Fp x, y;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        x.l[i] = a[i];
+        y.l[i] = b[i];
+    }
+    const Fp r = fp_add_inl(x, y);
+    fp_lin_vec13 o;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) o[i] = r.l[i];
+    return o;
+}
+static __device__ __attribute__((noinline)) fp_lin_vec13 fp_sub_call(fp_lin_vec13 a, fp_lin_vec13 b) {
+    Fp x, y;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        x.l[i] = a[i];
+        y.l[i] = b[i];
+    }
+    const Fp r = fp_sub_inl(x, y);
+    fp_lin_vec13 o;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) o[i] = r.l[i];
+    return o;
+}
+#define ECG_LIN_CALL(fn, a, b)                                          \
+    fp_lin_vec13 x_, y_;                                                \
+    _Pragma("unroll") for (int i = 0; i < FP_N; i++) {                  \
+        x_[i] = (a).l[i];                                               \
+        y_[i] = (b).l[i];                                               \
+    }                                                                   \
+    const fp_lin_vec13 o_ = fn(x_, y_);                                 \
+    Fp r_;                                                              \
+    _Pragma("unroll") for (int i = 0; i < FP_N; i++) r_.l[i] = o_[i];   \
+    return r_;
+ECG_HD Fp fp_add(const Fp& a, const Fp& b) { ECG_LIN_CALL(fp_add_call, a, b) }
+ECG_HD Fp fp_sub(const Fp& a, const Fp& b) { ECG_LIN_CALL(fp_sub_call, a, b) }
+#else
+ECG_HD Fp fp_add(const Fp& a, const Fp& b) { return fp_add_inl(a, b); }
+ECG_HD Fp fp_sub(const Fp& a, const Fp& b) { return fp_sub_inl(a, b); }
+#endif
 ECG_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 ECG_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 

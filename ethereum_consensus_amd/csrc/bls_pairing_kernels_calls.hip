@@ -4,5 +4,6 @@
 //  they are the faster ones.  bls.hip picks the set once per process from the box self-check
 // (ECGPU_TOWER=sums|calls overrides).
 #define ECG_TOWER_CALLS 1
+#define ECG_LINEAR_CALLS 1  // modular additions as calls as well: the Miller iteration then (nearly) fits the instruction cache
 #define ECG_KN(name) name##_calls
 #include "bls_pairing_kernels.hip"
