@@ -1,6 +1,6 @@
 #!/bin/bash
-# One visit of the slow-box hunt: the instruction-fetch self-check; on a slow box (or with HUNT_ALWAYS=1) the stage probe
-# with each build of the kernels and with the experimental compact levels under lib/variants.
+# One visit of the slow-box hunt: the instruction-fetch self-check; on a slow box the stage probe with each build of the
+# kernels and one bench.py line (which then runs on the compact build by itself).
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT" || exit 1
 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/hunt_last.txt
@@ -18,11 +18,6 @@ if [ "$(cat gpurun_out/hunt_slow)" = "1" ] || [ -n "$HUNT_ALWAYS" ]; then
   [ "$(cat gpurun_out/hunt_slow)" = "1" ] && echo "SLOW BOX"
   {
   for t in sums calls; do echo "== ECGPU_TOWER=$t"; ECGPU_TOWER=$t timeout 300 python tools/bls_probe.py 65536 2>&1 | grep "verify iter 1"; done
-  for v in; do
-    if [ -f ethereum_consensus_amd/lib/variants/libecgpu_$v.so ]; then
-      echo "== ECGPU_TOWER=calls, variant $v"
-      ECGPU_LIB=$PWD/ethereum_consensus_amd/lib/variants/libecgpu_$v.so ECGPU_TOWER=calls timeout 300 python tools/bls_probe.py 65536 2>&1 | grep "verify iter 1"
-    fi
-  done
   } | tee gpurun_out/hunt_probe_$(cat gpurun_out/hunt_slow).txt
+  timeout 900 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/hunt_bench_$(cat gpurun_out/hunt_slow).json
 fi
