@@ -436,15 +436,31 @@ def main():
         else:
             line["merkle"] = {k: m[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline",
                                                 "check", "cpu_baseline") if k in m}
+    # box self-check (csrc/selfcheck.hip): 2^21 multiply-adds per lane as loops over 8 KB .. 1 MB of code.  On a healthy box
+    # they take the same time; where the large ones are several times slower, so are the sums-of-products lane kernels, and
+    # the library has switched that rank to its compact-code build.  Every rank checks its own GPU: with N > 1 the slowest
+    # rank sets the step time, so the line carries every rank's slowdown and build.
+    import ctypes
+    sweep = (ctypes.c_double * 4)()
+    ok = L.ecgpu_selfcheck_ifetch_sweep(sweep) == 0 and sweep[0] > 0
+    mine = [sweep[3] / sweep[0] if ok else 0.0, float(L.ecgpu_bls_tower())]
+    per_rank = [mine]
+    if world > 1:
+        try:
+            t = torch.tensor(mine, dtype=torch.float64, device="cuda")
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            per_rank = [p.cpu().tolist() for p in parts]
+        except Exception:  # noqa: BLE001 - a failed diagnostic must not cost the measurement
+            per_rank = [mine]
     if rank == 0:
-        # box self-check (csrc/selfcheck.hip): 2^21 multiply-adds per lane as a loop over 8 KB and over 1 MB of code.  On a
-        # healthy box both take the same time; where the second is several times slower, so are the lane kernels above.
-        import ctypes
-        sweep = (ctypes.c_double * 4)()
-        if L.ecgpu_selfcheck_ifetch_sweep(sweep) == 0 and sweep[0] > 0:
+        names = {1: "sums of products", 2: "compact-code tower"}
+        if ok:
             line["box_selfcheck"] = {"mad_loop_8KB_ms": sweep[0], "mad_loop_64KB_ms": sweep[1], "mad_loop_256KB_ms": sweep[2],
-                                     "mad_loop_1MB_ms": sweep[3], "large_code_slowdown": sweep[3] / sweep[0],
-                                     "pairing_kernels": {1: "sums of products", 2: "compact-code tower"}.get(int(L.ecgpu_bls_tower()), "?"),
+                                     "mad_loop_1MB_ms": sweep[3], "large_code_slowdown": mine[0],
+                                     "pairing_kernels": names.get(int(mine[1]), "?"),
+                                     "per_rank": [{"large_code_slowdown": r[0], "pairing_kernels": names.get(int(r[1]), "?")}
+                                                  for r in per_rank],
                                      "note": "2^21 multiply-adds per lane as loops over 8 KB .. 1 MB of code: instruction fetch far beyond the "
                                              "64 KB instruction cache; slowdown ~1.0 on a healthy box, 2.2 measured on a slow one "
                                              "(DESIGN.md 3.3)"}
