@@ -82,6 +82,12 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
                                                               u8p]),
         "ecgpu_fast_aggregate_verify_indexed_batch_dev": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_u32, u8p, u8p,
                                                                   c_u32, c_int, u8p, ctypes.c_void_p]),
+        "ecgpu_batch_create": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+        "ecgpu_batch_destroy": (None, [ctypes.c_void_p]),
+        "ecgpu_batch_push": (ctypes.c_int64, [ctypes.c_void_p, u8p, c_u32, u8p, c_size, u8p, c_int]),
+        "ecgpu_batch_push_indexed": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, c_u32, u8p, c_size, u8p, c_int]),
+        "ecgpu_batch_len": (c_u32, [ctypes.c_void_p]),
+        "ecgpu_batch_flush": (c_int, [ctypes.c_void_p, u8p, c_u32]),
         "ecgpu_sk_to_pk_batch": (c_int, [u8p, c_u32, u8p]),
         "ecgpu_sign_batch": (c_int, [u8p, u8p, ctypes.c_void_p, c_u32, u8p]),
         "ecgpu_sk_to_pk_batch_dev": (c_int, [u8p, c_u32, u8p, ctypes.c_void_p]),
@@ -92,6 +98,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_selfcheck_ifetch": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
         "ecgpu_selfcheck_ifetch_sweep": (c_int, [ctypes.POINTER(ctypes.c_double)]),
         "ecgpu_bls_tower": (c_int, []),
+        "ecgpu_bls_last_pairing_path": (c_int, []),
     }
     missing = []
     for name, (res, args) in sig.items():

@@ -31,7 +31,11 @@ _BLST_STRINGS = {  # bls.rs:48-62
     6: "public key is infinity",
     7: "bad scalar",
 }
-_DECODE_CODES = (1, 2, 3, 6)  # raised by TryFrom<&PublicKey>/<&Signature> -> Error::BLST
+# BLST_ERRORs of the conversions TryFrom<&PublicKey> / TryFrom<&Signature> -> Error::BLST (bls.rs:69-70,100-105,119-125).
+# The same two group / infinity conditions met INSIDE blst's verify call come back as 0x43 / 0x46 (ECGPU_IN_VERIFY set,
+# include/ecgpu.h) and, like every other non-zero result of that call, are Error::InvalidSignature (bls.rs:72-76).
+_CONVERSION_CODES = (1, 2, 3, 6)
+IN_VERIFY = 0x40
 EMPTY_AGGREGATE = -100
 
 
@@ -78,14 +82,22 @@ def _buf(b: bytes):
 
 
 def _raise_for(code: int) -> None:
-    """Map a BLST_ERROR to the reference's Result: decode errors -> Error::BLST, else InvalidSignature."""
+    """Map a status of the verify functions to the reference's Result: conversion errors -> Error::BLST, whatever blst's
+    verify call returned -> InvalidSignature."""
+    if code == 0:
+        return
+    if code in _CONVERSION_CODES:
+        raise BLSTError(code)
+    raise InvalidSignature()
+
+
+def _raise_for_aggregate(code: int) -> None:
+    """aggregate / eth_aggregate_public_keys: EmptyAggregate, else every BLST_ERROR is Error::BLST (bls.rs:92,147)."""
     if code == 0:
         return
     if code == EMPTY_AGGREGATE:
         raise EmptyAggregate()
-    if code in _DECODE_CODES:
-        raise BLSTError(code)
-    raise InvalidSignature()
+    raise BLSTError(code & 7)
 
 
 # ---- status-returning layer (what the C ABI returns; used by the parity tests) -------------------
@@ -137,7 +149,7 @@ def verify_signature(public_key: bytes, msg: bytes, signature: bytes) -> None:
 def aggregate(signatures: Sequence[bytes]) -> bytes:
     """bls.rs:79-93."""
     rc, out = aggregate_status(signatures)
-    _raise_for(rc)
+    _raise_for_aggregate(rc)
     return out
 
 
@@ -154,7 +166,7 @@ def fast_aggregate_verify(public_keys: Sequence[bytes], msg: bytes, signature: b
 def eth_aggregate_public_keys(public_keys: Sequence[bytes]) -> bytes:
     """bls.rs:135-148."""
     rc, out = eth_aggregate_public_keys_status(public_keys)
-    _raise_for(rc)
+    _raise_for_aggregate(rc)
     return out
 
 
@@ -249,3 +261,66 @@ def sign_batch(secret_keys32: bytes, msgs: Sequence[bytes]) -> bytes:
     out = ctypes.create_string_buffer(max(96 * n, 1))
     _lib.check(L.ecgpu_sign_batch(_buf(secret_keys32), _buf(b"".join(msgs)), off_arr, n, out), "ecgpu_sign_batch")
     return out.raw[:96 * n]
+
+
+class SignatureBatch:
+    """Whole-block batching: queue every verification of a block -- `verify_signature`,
+    `fast_aggregate_verify`, `eth_fast_aggregate_verify` -- and verify them in ONE pass of the GPU pipeline.  `flush()`
+    returns, per queued call in order, the status the scalar call would have returned; `results()` maps them to the
+    reference's Result (None = Ok, or the Error instance the call would have raised).  Call sites it collects:
+    phase0/state_transition.rs:56, phase0/block_processing.rs:649,752-761, altair/block_processing.rs:226-234."""
+
+    def __init__(self, registry: "ValidatorKeyRegistry | None" = None):
+        self._L = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self._L.ecgpu_batch_create(registry.handle if registry is not None else None, ctypes.byref(h)), "ecgpu_batch_create")
+        self._h = h
+        self._reg = registry  # keeps the registry alive
+
+    def close(self):
+        if self._h:
+            self._L.ecgpu_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __len__(self):
+        return int(self._L.ecgpu_batch_len(self._h))
+
+    def _pushed(self, rc: int) -> int:
+        if rc < 0:
+            raise _lib.EcgpuError(int(rc), "ecgpu_batch_push")
+        return int(rc)
+
+    def verify_signature(self, public_key: bytes, msg: bytes, signature: bytes) -> int:
+        return self._pushed(self._L.ecgpu_batch_push(self._h, _buf(_pk(public_key)), 1, _buf(msg), len(msg), _buf(_sig(signature)), 0))
+
+    def fast_aggregate_verify(self, public_keys: Sequence[bytes], msg: bytes, signature: bytes, eth: bool = False) -> int:
+        pks = b"".join(_pk(p) for p in public_keys)
+        return self._pushed(self._L.ecgpu_batch_push(self._h, _buf(pks), len(public_keys), _buf(msg), len(msg), _buf(_sig(signature)),
+                                                     1 if eth else 0))
+
+    def eth_fast_aggregate_verify(self, public_keys: Sequence[bytes], msg: bytes, signature: bytes) -> int:
+        return self.fast_aggregate_verify(public_keys, msg, signature, eth=True)
+
+    def fast_aggregate_verify_indexed(self, indices: Sequence[int], msg: bytes, signature: bytes, eth: bool = False) -> int:
+        idx = (ctypes.c_uint32 * max(len(indices), 1))(*indices)
+        return self._pushed(self._L.ecgpu_batch_push_indexed(self._h, idx, len(indices), _buf(msg), len(msg), _buf(_sig(signature)),
+                                                             1 if eth else 0))
+
+    def flush(self) -> bytes:
+        n = len(self)
+        out = ctypes.create_string_buffer(max(n, 1))
+        _lib.check(self._L.ecgpu_batch_flush(self._h, out, n), "ecgpu_batch_flush")
+        return out.raw[:n]
+
+    def results(self):
+        out = []
+        for st in self.flush():
+            try:
+                _raise_for(st)
+                out.append(None)
+            except Error as e:
+                out.append(e)
+        return out

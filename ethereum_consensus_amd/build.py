@@ -36,11 +36,40 @@ def _newer(target: str, deps) -> bool:
 
 
 def _headers():
-    out = [os.path.join(ROOT, "include", "ecgpu.h")]
+    out = [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")]
     for f in os.listdir(CSRC):
         if f.endswith(".h"):
             out.append(os.path.join(CSRC, f))
     return out
+
+
+_INC = None
+
+
+def _deps(src: str, seen=None):
+    """files `src` includes with quotes, transitively (the .hip second-build units include a .hip; ECG_VM2_PROG_HEADER is a
+    macro include): an edit to one header rebuilds only the objects that see it"""
+    import re
+    global _INC
+    if _INC is None:
+        _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+    seen = seen if seen is not None else set()
+    if src in seen or not os.path.exists(src):
+        return seen
+    seen.add(src)
+    text = open(src).read()
+    names = _INC.findall(text)
+    if "ECG_VM2_PROG_HEADER" in text:
+        names.append("bls_vm2_prog.h")
+    if "ECG_VM3_PROG_HEADER" in text:
+        names.append("bls_vm3_prog.h")
+    for n in names:
+        for base in (os.path.dirname(src), CSRC, os.path.join(ROOT, "include")):
+            cand = os.path.normpath(os.path.join(base, n))
+            if os.path.exists(cand):
+                _deps(cand, seen)
+                break
+    return seen
 
 
 def _run(cmd):
@@ -80,14 +109,13 @@ def build_lib(verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     generate_vm_programs(verbose)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = _headers()
     jobs = []
     objs = []
     for f in srcs:
         src = os.path.join(CSRC, f)
         obj = os.path.join(OBJDIR, f[:-4] + ".o")
         objs.append(obj)
-        if _newer(obj, [src] + hdrs):
+        if _newer(obj, sorted(_deps(src)) + [os.path.abspath(__file__)]):
             jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
     if jobs:
         if verbose:

@@ -23,6 +23,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 #include <cstring>
 
 namespace ecg {
@@ -217,6 +218,9 @@ static int decide_tower() {
     g_tower.store(t);
     return t;
 }
+// which kernels ran the pairing check of this thread's last batch: 1 = lane kernel (k_pairing[_calls]), 2 = Fp2 lane groups
+// (bls_vm2.hip; tuples with a point at infinity still go through the lane kernel), 3 = Fp lane groups (bls_vm3.hip)
+static thread_local int t_last_pairing_path = 0;
 static const u32 g_vm2_max_tuples = [] {
     const char* e = getenv("ECGPU_VM2_MAX");
     return e ? (u32)strtoul(e, nullptr, 10) : 12288u;
@@ -301,6 +305,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     {
         ProfScope ps("bls_pairing", s);
         const bool use_vm = g_pairing_mode == 2 || (g_pairing_mode == 3 && n <= g_vm2_max_tuples);
+        t_last_pairing_path = use_vm ? 2 : 1;
         if (!use_vm) {
             hipLaunchKernelGGL(g_tower.load() == 2 ? k_pairing_calls : k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg,
                                (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96,
@@ -642,6 +647,115 @@ int ecgpu_sign_batch(const uint8_t* sks32, const uint8_t* msgs, const uint64_t* 
     return ECGPU_SUCCESS;
 }
 
+
+// ---- whole-block batching ----------------------------------------------------------------------
+}  // extern "C"
+// Every verification of a block -- proposer signature (phase0/state_transition.rs:56), randao reveal
+// (phase0/block_processing.rs:649), slashings / exits / deposits, one fast_aggregate_verify per attestation
+// (phase0/block_processing.rs:752-761 via phase0/helpers.rs:140), the sync aggregate (altair/block_processing.rs:226-234) --
+// is an independent (keys, message, signature) tuple.  A scalar call is ~25 ms of dependent latency on this backend; the
+// collector queues the tuples on the host and verifies all of them in ONE pass of the batch pipeline, returning per tuple
+// exactly what the scalar call would have returned (the eth_ rule -- no keys and the infinity signature -- is decided on
+// the host: it is the first test of eth_fast_aggregate_verify, crypto/bls.rs:155-159, and looks at nothing else).
+struct ecgpu_batch {
+    const ecgpu_registry* reg = nullptr;
+    std::mutex mu;
+    // raw-key tuples and registry-indexed tuples are two sub-batches of one flush
+    struct Sub {
+        std::vector<u8> keys;       // 48-byte keys (raw) or 4-byte indices (indexed)
+        std::vector<u32> key_off{0};
+        std::vector<u8> msgs;
+        std::vector<u64> msg_off{0};
+        std::vector<u8> sigs;
+        std::vector<u32> pos;       // position in the batch
+        std::vector<u8> eth_ok;     // eth rule already satisfied: status is SUCCESS whatever the pipeline says
+        void clear() {
+            keys.clear(), key_off.assign(1, 0), msgs.clear(), msg_off.assign(1, 0), sigs.clear(), pos.clear(), eth_ok.clear();
+        }
+    } raw, idx;
+    u32 n = 0;
+};
+namespace ecg {
+static int64_t batch_push(ecgpu_batch* b, ecgpu_batch::Sub& sub, const void* keys, size_t key_bytes, u32 k, const u8* msg, size_t msg_len,
+                          const u8* sig96, int eth_variant) {
+    std::lock_guard<std::mutex> lk(b->mu);
+    if (b->n == 0xffffffffu) return ECGPU_ERR_BAD_ARG;
+    const u8* kb = (const u8*)keys;
+    sub.keys.insert(sub.keys.end(), kb, kb + key_bytes);
+    sub.key_off.push_back(sub.key_off.back() + k);
+    sub.msgs.insert(sub.msgs.end(), msg, msg + msg_len);
+    sub.msg_off.push_back(sub.msg_off.back() + msg_len);
+    sub.sigs.insert(sub.sigs.end(), sig96, sig96 + 96);
+    sub.pos.push_back(b->n);
+    sub.eth_ok.push_back(eth_variant && k == 0 && sig_is_infinity_bytes(sig96) ? 1 : 0);
+    return (int64_t)b->n++;
+}
+// one sub-batch through the pipeline on the calling thread's stream
+static int batch_run(const ecgpu_registry* reg, const ecgpu_batch::Sub& sub, u8* status_by_pos) {
+    const u32 n = (u32)sub.pos.size();
+    if (n == 0) return ECGPU_SUCCESS;
+    const u32 n_keys = sub.key_off.back();
+    const size_t key_bytes = sub.keys.size(), msg_bytes = sub.msgs.size();
+    CallCtx k;
+    int rc = begin_call(k, nullptr, fav_ws_bytes(n, reg ? 0 : n_keys) + key_bytes + msg_bytes + (size_t)n * (96 + 1 + 4 + 8) + 16384);
+    if (rc) return rc;
+    u8 *d_keys, *d_off, *d_msgs, *d_moff, *d_sigs;
+    if ((rc = h2d(k, d_keys, sub.keys.data(), key_bytes))) return rc;
+    if ((rc = h2d(k, d_off, sub.key_off.data(), (size_t)(n + 1) * 4))) return rc;
+    if ((rc = h2d(k, d_msgs, sub.msgs.data(), msg_bytes))) return rc;
+    if ((rc = h2d(k, d_moff, sub.msg_off.data(), (size_t)(n + 1) * 8))) return rc;
+    if ((rc = h2d(k, d_sigs, sub.sigs.data(), (size_t)n * 96))) return rc;
+    u8* d_status = k.ar->take(n);
+    if (!d_status) return ECGPU_ERR_OOM;
+    rc = reg ? fav_batch_device(k.s, nullptr, (const u32*)d_off, n_keys, d_msgs, (const u64*)d_moff, d_sigs, n, 0, d_status, *k.ar, k.c->aux, reg,
+                                (const u32*)d_keys)
+             : fav_batch_device(k.s, d_keys, (const u32*)d_off, n_keys, d_msgs, (const u64*)d_moff, d_sigs, n, 0, d_status, *k.ar, k.c->aux);
+    if (rc) return rc;
+    std::vector<u8> st(n);
+    ECG_HIP_CHECK(hipMemcpyAsync(st.data(), d_status, n, hipMemcpyDeviceToHost, k.s));
+    ECG_HIP_CHECK(hipStreamSynchronize(k.s));
+    for (u32 i = 0; i < n; i++) status_by_pos[sub.pos[i]] = sub.eth_ok[i] ? (u8)ECGPU_SUCCESS : st[i];
+    return ECGPU_SUCCESS;
+}
+}  // namespace ecg
+extern "C" {
+
+int ecgpu_batch_create(const ecgpu_registry_t* reg, ecgpu_batch_t** out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!out) return ECGPU_ERR_BAD_ARG;
+    ecgpu_batch* b = new ecgpu_batch();
+    b->reg = reg;
+    *out = b;
+    return ECGPU_SUCCESS;
+}
+void ecgpu_batch_destroy(ecgpu_batch_t* b) { delete b; }
+uint32_t ecgpu_batch_len(const ecgpu_batch_t* b) { return b ? b->n : 0; }
+
+int64_t ecgpu_batch_push(ecgpu_batch_t* b, const uint8_t* pks48, uint32_t k, const uint8_t* msg, size_t msg_len, const uint8_t* sig96,
+                         int eth_variant) {
+    if (!b || (k && !pks48) || (msg_len && !msg) || !sig96) return ECGPU_ERR_BAD_ARG;
+    return batch_push(b, b->raw, pks48, (size_t)k * 48, k, msg, msg_len, sig96, eth_variant);
+}
+int64_t ecgpu_batch_push_indexed(ecgpu_batch_t* b, const uint32_t* indices, uint32_t k, const uint8_t* msg, size_t msg_len,
+                                 const uint8_t* sig96, int eth_variant) {
+    if (!b || !b->reg || (k && !indices) || (msg_len && !msg) || !sig96) return ECGPU_ERR_BAD_ARG;
+    return batch_push(b, b->idx, indices, (size_t)k * 4, k, msg, msg_len, sig96, eth_variant);
+}
+int ecgpu_batch_flush(ecgpu_batch_t* b, uint8_t* status_out, uint32_t capacity) {
+    if (!b) return ECGPU_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(b->mu);
+    if (b->n == 0) return ECGPU_SUCCESS;
+    if (!status_out || capacity < b->n) return ECGPU_ERR_BAD_ARG;
+    int rc = batch_run(nullptr, b->raw, status_out);
+    if (!rc) rc = batch_run(b->reg, b->idx, status_out);
+    b->raw.clear();
+    b->idx.clear();
+    b->n = 0;
+    return rc;
+}
+
+int ecgpu_bls_last_pairing_path(void) { return ecg::t_last_pairing_path; }
 int ecgpu_bls_tower(void) {
     int rc = ensure_init();
     if (rc) return rc;

@@ -12,7 +12,7 @@
 //   G2:  psi(Q) == [x] Q
 // which cost two / one 64-bit scalar multiplications instead of a 255-bit one.
 #pragma once
-#include "ecgpu.h"
+#include "ecgpu_status.h"
 #include "bls_tower.h"
 
 namespace ecg {

@@ -11,6 +11,10 @@ constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches 
                          // (re-measured after every restructuring)
 #endif
 
+// status-byte marker between the lane-group pairing kernels and k_pairing(only_marked = 1): a point at infinity is involved,
+// the branchy lane kernel decides
+constexpr u8 VM_NEEDS_LANE_PATH = 0xFE;
+
 // bls_g2_kernels.hip / bls_g2_kernels_calls.hip
 __global__ void k_sig(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
 __global__ void k_h2c(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);

@@ -5,7 +5,6 @@
 //   k_aggv_final     one lane       product of the Miller values, final exponentiation, status
 // (the e(pk, H(m)) == e(g1, sig) equation of /root/reference/ethereum-consensus/src/crypto/bls.rs:71,106,126)
 #include "bls_kernels.h"
-#include "bls_vm_host.h"
 
 // bls_pairing_kernels_calls.hip compiles this file a second time with -DECG_TOWER_CALLS semantics (the compact-code tower)
 // and the kernel names suffixed.
@@ -76,7 +75,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_aggv_final)
         return;
     }
     if (st_grp[0]) {
-        *status_out = st_grp[0];
+        *status_out = ECGPU_IN_VERIFY | st_grp[0];  // verify's own group check: Error::InvalidSignature (crypto/bls.rs:106-111)
         return;
     }
     Fp12 f = fs[0];

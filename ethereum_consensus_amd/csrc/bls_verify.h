@@ -3,7 +3,8 @@
 // reference wrappers (/root/reference/ethereum-consensus/src/crypto/bls.rs):
 //   fast_aggregate_verify :114-132  keys left to right (first failing key wins) -> signature
 //       decode -> empty key list (AGGR_TYPE_MISMATCH) -> signature group check -> aggregate key
-//       at infinity -> pairing equation
+//       at infinity -> pairing equation.  The first two are conversions (Error::BLST); what follows happens inside
+//       blst's verify call (Error::InvalidSignature): its POINT_NOT_IN_GROUP / PK_IS_INFINITY carry ECGPU_IN_VERIFY.
 //   eth_fast_aggregate_verify :150-160  (no keys AND sig == 0xc0 00..00) -> Ok, else as above
 //   aggregate_verify :95-112, aggregate :79-93, eth_aggregate_public_keys :135-148
 // The kernels in bls.hip run these stage by stage over a whole batch; tests/hostsim runs the same
@@ -61,8 +62,8 @@ ECG_HD u8 combine_fav_status(u32 k, bool eth_variant, bool sig_inf_bytes, u8 st_
     if (st_pk) return st_pk;
     if (st_sig_decode) return st_sig_decode;
     if (k == 0) return ECGPU_AGGR_TYPE_MISMATCH;
-    if (st_sig_group) return st_sig_group;
-    if (agg_inf) return ECGPU_PK_IS_INFINITY;
+    if (st_sig_group) return ECGPU_IN_VERIFY | st_sig_group;  // found by verify's group check: Error::InvalidSignature
+    if (agg_inf) return ECGPU_VERIFY_PK_IS_INFINITY;          // keys sum to infinity inside verify: Error::InvalidSignature
     return st_pairing;
 }
 
@@ -82,10 +83,10 @@ ECG_HD u8 fav_tuple_serial(const u8* pks48, u32 k, const u8* msg, size_t msg_len
     stage_sig(sig, sd, sg, sig96);
     if (sd) return sd;
     if (k == 0) return ECGPU_AGGR_TYPE_MISMATCH;
-    if (sg) return sg;
+    if (sg) return ECGPU_IN_VERIFY | sg;
     A1 agg;
     jac_to_aff(agg, acc);
-    if (agg.inf) return ECGPU_PK_IS_INFINITY;
+    if (agg.inf) return ECGPU_VERIFY_PK_IS_INFINITY;
     A2 h;
     hash_to_g2(h, msg, msg_len);
     return stage_pairing(agg, h, sig);

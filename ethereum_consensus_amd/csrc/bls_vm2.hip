@@ -18,7 +18,6 @@
 
 namespace ecg {
 
-constexpr int BLS_BLOCK = 64;
 constexpr int VM2_G = ECG_VM2_LANES;
 constexpr int VM2_TPW = 64 / VM2_G;     // tuples per wave (= per workgroup)
 constexpr u32 XFER2_REGS = 8;           // per tuple: 6 coefficients of f, (d, 0), (1/d, -)

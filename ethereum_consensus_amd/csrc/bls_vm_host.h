@@ -1,11 +1,9 @@
 // Host-side interface of the lane-group ("Fp2 VM") pairing kernels (bls_vm2.hip) used by bls.hip.
 #pragma once
-#include "bls_curve.h"
+#include "bls_kernels.h"
 #include "runtime.h"
 
 namespace ecg {
-
-constexpr u8 VM_NEEDS_LANE_PATH = 0xFE;  // a point at infinity is involved: the branchy lane kernel decides
 
 int init_vm2_tables();
 size_t vm2_xfer_bytes(u32 n);

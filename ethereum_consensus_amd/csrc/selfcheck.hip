@@ -8,34 +8,18 @@
 
 namespace ecg {
 
-// MADS independent-accumulator multiply-adds per loop trip, emitted as instructions (nothing for the optimizer to fold)
-template <int MADS>
-__global__ void __launch_bounds__(64) k_ifetch_probe(u32* out, u32 trips) {
-    u64 acc0 = threadIdx.x, acc1 = blockIdx.x, acc2 = 3, acc3 = 5;
-    const u32 a = threadIdx.x * 2654435761u + 1, b = blockIdx.x * 40503u + 7;
-    for (u32 t = 0; t < trips; t++) {
-#pragma unroll
-        for (int k = 0; k < MADS / 4; k++) {
-            asm volatile(
-                "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\t"
-                "v_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_mad_u64_u32 %3, vcc, %4, %5, %3"
-                : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
-                : "v"(a), "v"(b)
-                : "vcc");
-        }
-    }
-    out[blockIdx.x * 64 + threadIdx.x] = (u32)(acc0 ^ acc1 ^ acc2 ^ acc3);
-}
+// the probe kernels live in selfcheck_kernels.hip (1 MB of straight-line code takes minutes to compile; this file is the
+// host side and may change with the ABI)
+void launch_ifetch_probe(int mads, hipStream_t s, u32* out, u32 trips);
 
 template <int MADS>
 static int time_probe(hipStream_t s, u32* d_out, u32 trips, double* ms) {
     hipEvent_t e0, e1;
     ECG_HIP_CHECK(hipEventCreate(&e0));
     ECG_HIP_CHECK(hipEventCreate(&e1));
-    const dim3 grid(1024), block(64);  // one wave per SIMD, like the lane kernels
-    hipLaunchKernelGGL(k_ifetch_probe<MADS>, grid, block, 0, s, d_out, trips);  // warm-up: code load, caches
+    launch_ifetch_probe(MADS, s, d_out, trips);  // warm-up: code load, caches
     ECG_HIP_CHECK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(k_ifetch_probe<MADS>, grid, block, 0, s, d_out, trips);
+    launch_ifetch_probe(MADS, s, d_out, trips);
     ECG_HIP_CHECK(hipEventRecord(e1, s));
     ECG_HIP_CHECK(hipEventSynchronize(e1));
     float f = 0;

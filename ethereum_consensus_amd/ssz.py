@@ -97,7 +97,7 @@ def hash_tree_root_beacon_block_header(ssz112: bytes) -> bytes:
 def compute_signing_root(object_root: bytes, domain: bytes) -> bytes:
     """signing.rs:14-22 with the object's root already computed."""
     L = _lib.load()
-    return _root(L.ecgpu_signing_root, _buf(object_root), _buf(domain))
+    return _root(L.ecgpu_signing_root, _buf(_node32(object_root, "object root")), _buf(_node32(domain, "domain")))
 
 
 def hash_tree_root_beacon_state_deneb(ssz: bytes, preset: int = MAINNET) -> bytes:
@@ -166,9 +166,24 @@ def hash_tree_root(ssz_type, encoding: bytes) -> bytes:
     return out.raw
 
 
+def _node32(b, what: str) -> bytes:
+    b = bytes(b)
+    if len(b) != 32:
+        raise MerkleizationError(f"{what} must be a 32-byte node, got {len(b)} bytes")
+    return b
+
+
 def is_valid_merkle_branch(leaf: bytes, branch, depth: int, index: int, root: bytes) -> bool:
+    """ssz_rs `is_valid_merkle_branch` (phase0/block_processing.rs:433, deneb/blob_sidecar.rs:62): a branch shorter than
+    `depth` is not a proof (False); nodes are `Node`s, i.e. exactly 32 bytes each."""
     L = _lib.load()
-    b = b"".join(branch[:depth])
+    leaf, root = _node32(leaf, "leaf"), _node32(root, "root")
+    if depth < 0 or depth > 64:
+        raise MerkleizationError(f"depth {depth} out of range")
+    branch = list(branch)
+    if len(branch) < depth:
+        return False
+    b = b"".join(_node32(x, "branch node") for x in branch[:depth])
     rc = L.ecgpu_is_valid_merkle_branch(_buf(leaf), _buf(b), depth, index, _buf(root))
     _lib.check(rc, "ecgpu_is_valid_merkle_branch")
     return rc == 0

@@ -144,3 +144,125 @@ def expected_hash64_count(n: int, preset: str = "mainnet") -> int:
     """hash64 evaluations of one whole-state root: bookkeeping for bench.py (mirrors the SSZ
     rules; the library reports its own count through ecgpu_last_hash64_count)."""
     raise NotImplementedError("use ecgpu_last_hash64_count()")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BLS workload of SURVEY.md 8(d) config 2: B independent K = 1 tuples with fault injection at i = 0 (mod 64), cycling
+# through eight fault classes.  Pure data construction on compressed encodings (ZCash format, crypto/bls.rs:227-349);
+# keys and signatures themselves come from the device (ecgpu_sk_to_pk_batch / ecgpu_sign_batch).
+# ---------------------------------------------------------------------------------------------------------------------
+BLS_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+BLS_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+INFINITY_PUBLIC_KEY = bytes([0xC0]) + bytes(47)
+INFINITY_SIGNATURE = bytes([0xC0]) + bytes(95)
+# statuses by construction (include/ecgpu.h): wrong message, swapped key, signature outside G2 (found by verify's group
+# check), key outside G1, compression flag cleared, x >= p, key = infinity, signature = infinity
+BLS_FAULT_STATUS = (5, 5, 0x43, 3, 1, 1, 6, 5)
+BLS_FAULT_NAMES = ("wrong message", "swapped public key", "signature outside the G2 subgroup", "public key outside the G1 subgroup",
+                   "compression flag cleared", "x >= p", "public key = infinity", "signature = infinity")
+
+
+def bls_tag(tag: bytes, i: int) -> bytes:
+    """S(tag, i) = SHA-256("ecgpu/v1/" || tag || "/" || u32le(i)) of SURVEY.md 8(d)."""
+    import hashlib
+    return hashlib.sha256(b"ecgpu/v1/" + tag + b"/" + int(i).to_bytes(4, "little")).digest()
+
+
+def bls_secret_keys(n: int, base: int = 0) -> bytes:
+    """sk_i = 1 + S("sk", i) mod (r - 1), 32 big-endian bytes each"""
+    return b"".join((1 + int.from_bytes(bls_tag(b"sk", base + i), "big") % (BLS_R - 1)).to_bytes(32, "big") for i in range(n))
+
+
+def bls_messages(n: int, base: int = 0, tag: bytes = b"msg") -> bytes:
+    return b"".join(bls_tag(tag, base + i) for i in range(n))
+
+
+def _fp_sqrt(a: int):
+    s = pow(a, (BLS_P + 1) // 4, BLS_P)
+    return s if s * s % BLS_P == a % BLS_P else None
+
+
+def _f2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % BLS_P, (a[0] * b[1] + a[1] * b[0]) % BLS_P)
+
+
+def _f2_sqrt(a):
+    if a[1] == 0:
+        s = _fp_sqrt(a[0])
+        if s is not None:
+            return (s, 0)
+        s = _fp_sqrt(-a[0] % BLS_P)
+        return None if s is None else (0, s)
+    n = _fp_sqrt((a[0] * a[0] + a[1] * a[1]) % BLS_P)
+    if n is None:
+        return None
+    inv2 = pow(2, BLS_P - 2, BLS_P)
+    for cand in ((a[0] + n) * inv2 % BLS_P, (a[0] - n) * inv2 % BLS_P):
+        x0 = _fp_sqrt(cand)
+        if x0:
+            x1 = a[1] * pow(2 * x0, BLS_P - 2, BLS_P) % BLS_P
+            if _f2_mul((x0, x1), (x0, x1)) == (a[0] % BLS_P, a[1] % BLS_P):
+                return (x0, x1)
+    return None
+
+
+def off_subgroup_public_key(i: int) -> bytes:
+    """a compressed point ON E1: y^2 = x^3 + 4 that is (with probability 1 - 2^-125) outside G1"""
+    x = int.from_bytes(bls_tag(b"offg1", i) + bls_tag(b"offg1b", i)[:16], "big") % BLS_P
+    while True:
+        y = _fp_sqrt((x * x * x + 4) % BLS_P)
+        if y is not None:
+            break
+        x = (x + 1) % BLS_P
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if y > (BLS_P - 1) // 2 else 0)
+    return bytes(b)
+
+
+def off_subgroup_signature(i: int) -> bytes:
+    """a compressed point ON E2: y^2 = x^3 + 4 (1 + i) that is (almost surely) outside G2"""
+    x0 = int.from_bytes(bls_tag(b"offg2", i) + bls_tag(b"offg2b", i)[:16], "big") % BLS_P
+    x1 = int.from_bytes(bls_tag(b"offg2c", i) + bls_tag(b"offg2d", i)[:16], "big") % BLS_P
+    while True:
+        x = (x0, x1)
+        x3 = _f2_mul(_f2_mul(x, x), x)
+        y = _f2_sqrt(((x3[0] + 4) % BLS_P, (x3[1] + 4) % BLS_P))
+        if y is not None:
+            break
+        x0 = (x0 + 1) % BLS_P
+    largest = y[1] > (BLS_P - 1) // 2 if y[1] else y[0] > (BLS_P - 1) // 2
+    b = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if largest else 0)
+    return bytes(b)
+
+
+def bls_inject_faults(pks: bytearray, msgs: bytearray, sigs: bytearray, n: int, period: int = 64, n_distinct: int = 4):
+    """Corrupt tuple i for every i = 0 (mod period), fault class (i / period) mod 8, in place.
+    Returns the n status bytes the reference semantics assign (include/ecgpu.h numbering) and the fault class per tuple
+    (255 = untouched).  A `swapped key` takes the key of tuple i + 1 (wraps to i - 1 at the end)."""
+    want = bytearray(n)
+    kind_of = bytearray([255]) * n
+    off1 = [off_subgroup_public_key(j) for j in range(n_distinct)]
+    off2 = [off_subgroup_signature(j) for j in range(n_distinct)]
+    for i in range(0, n, period):
+        kind = (i // period) % 8
+        kind_of[i] = kind
+        want[i] = BLS_FAULT_STATUS[kind]
+        if kind == 0:
+            msgs[32 * i] ^= 1
+        elif kind == 1:
+            j = i + 1 if i + 1 < n else i - 1
+            pks[48 * i:48 * i + 48] = pks[48 * j:48 * j + 48]
+        elif kind == 2:
+            sigs[96 * i:96 * i + 96] = off2[(i // period // 8) % n_distinct]
+        elif kind == 3:
+            pks[48 * i:48 * i + 48] = off1[(i // period // 8) % n_distinct]
+        elif kind == 4:
+            pks[48 * i] &= 0x7F
+        elif kind == 5:
+            sigs[96 * i:96 * i + 48] = bytes([0x9F]) + b"\xff" * 47
+        elif kind == 6:
+            pks[48 * i:48 * i + 48] = INFINITY_PUBLIC_KEY
+        else:
+            sigs[96 * i:96 * i + 96] = INFINITY_SIGNATURE
+    return want, kind_of

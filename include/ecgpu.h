@@ -10,7 +10,8 @@
  *   - plain pointers and sizes only; all buffers caller-owned; nothing allocated by the library is
  *     handed to the caller; thread-safe (per-thread HIP stream + workspace).
  *   - return value: 0..7 = blst BLST_ERROR numbering (so the Rust shim can rebuild
- *     `BLSTError` strings, crypto/bls.rs:48-62); negative = backend fault.  There is NO CPU
+ *     `BLSTError` strings, crypto/bls.rs:48-62), 0x43 / 0x46 = the two codes that blst's verify
+ *     call (not a conversion) produced, see ECGPU_IN_VERIFY; negative = backend fault.  There is NO CPU
  *     fallback: without a usable gfx950 device every call returns ECGPU_ERR_NO_DEVICE.
  *   - "host" entry points take host memory and copy; "_dev" entry points take device pointers
  *     (already resident in HBM) plus the HIP stream to enqueue on (NULL = the library's per-thread
@@ -25,21 +26,7 @@
 extern "C" {
 #endif
 
-/* BLST_ERROR numbering (blst bindings; reference crypto/bls.rs:48-62) */
-#define ECGPU_SUCCESS 0
-#define ECGPU_BAD_ENCODING 1
-#define ECGPU_POINT_NOT_ON_CURVE 2
-#define ECGPU_POINT_NOT_IN_GROUP 3
-#define ECGPU_AGGR_TYPE_MISMATCH 4
-#define ECGPU_VERIFY_FAIL 5
-#define ECGPU_PK_IS_INFINITY 6
-#define ECGPU_BAD_SCALAR 7
-/* wrapper-level and backend conditions */
-#define ECGPU_EMPTY_AGGREGATE (-100) /* Error::EmptyAggregate, crypto/bls.rs:80-82,136-138 */
-#define ECGPU_ERR_NO_DEVICE (-1)
-#define ECGPU_ERR_HIP (-2)
-#define ECGPU_ERR_BAD_ARG (-3)
-#define ECGPU_ERR_OOM (-4)
+#include "ecgpu_status.h" /* the status codes: BLST_ERROR numbering, ECGPU_IN_VERIFY, backend faults */
 
 typedef void* ecgpu_stream_t; /* a hipStream_t */
 
@@ -214,6 +201,26 @@ int ecgpu_fast_aggregate_verify_indexed_batch_dev(const ecgpu_registry_t* reg, c
                                                   const uint8_t* d_msgs32, const uint8_t* d_sigs96, uint32_t n,
                                                   int eth_variant, uint8_t* d_status_out, ecgpu_stream_t stream);
 
+/* Whole-block batching.  A block carries ~100-200 independent verifications that the reference
+ * makes one after the other: proposer signature (phase0/state_transition.rs:56), randao reveal
+ * (phase0/block_processing.rs:649), slashings / exits / deposits / BLS changes (signing.rs:40 callers), one
+ * fast_aggregate_verify per attestation (phase0/block_processing.rs:752-761 -> phase0/helpers.rs:140) and the sync
+ * aggregate (altair/block_processing.rs:226-234).  On a GPU a scalar call is tens of ms of dependent latency; a collector
+ * queues them (host memory only, any thread) and `flush` verifies everything queued in ONE pass of the batch pipeline.
+ * status_out[p] = exactly what the scalar call pushed at position p would have returned (verify_signature = one key;
+ * eth_variant != 0 = eth_fast_aggregate_verify).  `reg` (may be NULL) enables push_indexed: keys named by validator
+ * index in a validated-key registry.  push returns the position (>= 0) or a negative error. */
+typedef struct ecgpu_batch ecgpu_batch_t;
+int ecgpu_batch_create(const ecgpu_registry_t* reg, ecgpu_batch_t** out);
+void ecgpu_batch_destroy(ecgpu_batch_t* b);
+int64_t ecgpu_batch_push(ecgpu_batch_t* b, const uint8_t* pks48, uint32_t k, const uint8_t* msg, size_t msg_len,
+                         const uint8_t sig[96], int eth_variant);
+int64_t ecgpu_batch_push_indexed(ecgpu_batch_t* b, const uint32_t* indices, uint32_t k, const uint8_t* msg, size_t msg_len,
+                                 const uint8_t sig[96], int eth_variant);
+uint32_t ecgpu_batch_len(const ecgpu_batch_t* b);
+/* verifies and empties the batch; capacity = entries available in status_out (>= ecgpu_batch_len) */
+int ecgpu_batch_flush(ecgpu_batch_t* b, uint8_t* status_out, uint32_t capacity);
+
 /* SecretKey side, used to generate workloads and test vectors on the device:
  * SecretKey::public_key (crypto/bls.rs:193-197) and SecretKey::sign (:213-219).  sk = 32 big-endian
  * bytes, taken as given (pass sk < r).  msg_off == NULL: 32-byte messages at msgs + 32 i.
@@ -240,6 +247,10 @@ int ecgpu_selfcheck_ifetch_sweep(double ms[4]);
  * compact-code tower (faster where the self-check above reports a slowdown beyond 1.5).  Decided once per process, at the
  * first BLS call or here; the environment variable ECGPU_TOWER=sums|calls overrides the self-check. */
 int ecgpu_bls_tower(void);
+/* Which kernels ran the pairing check of the calling thread's last verification: 1 = one lane per tuple (k_pairing /
+ * k_pairing_calls), 2 = 16-lane groups over Fp2 registers in LDS (bls_vm2.hip), 3 = 16-lane groups over Fp registers in
+ * LDS with sums of products (bls_vm3.hip); 0 = none yet.  ECGPU_PAIRING=lane|vm2|vm3 forces one (default: by batch size). */
+int ecgpu_bls_last_pairing_path(void);
 
 #ifdef __cplusplus
 }

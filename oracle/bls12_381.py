@@ -832,15 +832,32 @@ def sig_from_bytes(sig: bytes):
     return g2_decompress(sig)
 
 
+# A BLST_ERROR met while CONVERTING a key / signature becomes Error::BLST in the reference (crypto/bls.rs:69-70,
+# 100-105,119-125); whatever blst's verify call itself returns is collapsed to Error::InvalidSignature (:72-76,
+# 107-111,127-131).  POINT_NOT_IN_GROUP and PK_IS_INFINITY can come from either place: the verify-side ones are
+# reported with IN_VERIFY set so that a status still identifies the reference's Error variant (include/ecgpu.h).
+IN_VERIFY = 0x40
+VERIFY_POINT_NOT_IN_GROUP = IN_VERIFY | BLST_POINT_NOT_IN_GROUP
+VERIFY_PK_IS_INFINITY = IN_VERIFY | BLST_PK_IS_INFINITY
+CONVERSION_CODES = (BLST_BAD_ENCODING, BLST_POINT_NOT_ON_CURVE, BLST_POINT_NOT_IN_GROUP, BLST_PK_IS_INFINITY)
+
+
+def error_variant(status: int) -> str:
+    """the reference's Result for a status of the verify functions: 'Ok', 'BLST' or 'InvalidSignature'"""
+    if status == BLST_SUCCESS:
+        return "Ok"
+    return "BLST" if status in CONVERSION_CODES else "InvalidSignature"
+
+
 def _core_verify(agg_pk, msgs_pts, sig_pt) -> int:
     """prod e(pk_i, H_i) == e(g1, sig) with signature group check (sig_groupcheck=true).
     Infinite signatures pass the group check; infinite public keys are rejected."""
     if sig_pt is not None and not g2_in_subgroup(sig_pt):
-        return BLST_POINT_NOT_IN_GROUP
+        return VERIFY_POINT_NOT_IN_GROUP
     pairs = []
     for pk_pt, h in zip(agg_pk, msgs_pts):
         if pk_pt is None:
-            return BLST_PK_IS_INFINITY
+            return VERIFY_PK_IS_INFINITY
         pairs.append((pk_pt, h))
     pairs.append((g1_neg(G1), sig_pt))
     return BLST_SUCCESS if pairing_product_is_one(pairs) else BLST_VERIFY_FAIL
@@ -848,7 +865,8 @@ def _core_verify(agg_pk, msgs_pts, sig_pt) -> int:
 
 def verify_signature(pk: bytes, msg: bytes, sig: bytes) -> int:
     """reference crypto/bls.rs:64-77.  Returns the first BLST_ERROR met (0 == Ok);
-    codes 1,2,3,6 raised at decode time map to Error::BLST, the rest to InvalidSignature."""
+    codes 1,2,3,6 raised at conversion time map to Error::BLST, the rest (incl. 0x43 / 0x46, the
+    same two codes raised inside verify) to InvalidSignature: see error_variant."""
     st, pk_pt = key_validate(pk)
     if st:
         return st

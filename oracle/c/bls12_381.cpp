@@ -1,0 +1,974 @@
+// C++ restatement of the BLS12-381 hot path for the CPU side of the comparison -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it (through oracle/cbls.py); nothing under
+// ethereum_consensus_amd/ does.  It restates, with 6 x 64-bit Montgomery limbs and `unsigned __int128`, the same published
+// algorithms as oracle/bls12_381.py (which is the oracle pinned to the reference's fixed vectors, tests/test_oracle_bls.py)
+// and is itself checked against that file status by status, point by point and pairing value by pairing value in
+// tests/test_oracle_cbls.py.  Reference anchors: the wrappers /root/reference/ethereum-consensus/src/crypto/bls.rs:64-160
+// (verify_signature, fast_aggregate_verify, eth_fast_aggregate_verify and their error order), :279-285 (key_validate),
+// :330-336 (Signature::from_bytes); the arithmetic itself is blst's (crates.io blst 0.3.x, Cargo.toml:21, not vendored):
+// the standard BLS12-381 tower, ZCash serialization, RFC 9380 BLS12381G2_XMD:SHA-256_SSWU_RO_, optimal-ate pairing.
+//
+// Why it exists next to the Python file: SURVEY.md 8(d) asks for a restated CPU path at -O3 -march=native on 1 and N host
+// threads as the timed baseline (pure Python big-ints manage 14 verifications/s) and for a FULL status-vector comparison
+// at 65 536 tuples, which needs a checker that finishes in a minute.
+//
+// Build: g++ -O3 -march=native -std=c++17 -shared -fPIC (oracle/Makefile).
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+
+typedef uint64_t u64;
+typedef uint8_t u8;
+typedef unsigned __int128 u128;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fp: 6 x 64-bit limbs, Montgomery form, R = 2^384, always fully reduced (< p)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Fp {
+    u64 l[6];
+};
+const Fp P = {{0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL, 0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL,
+               0x1a0111ea397fe69aULL}};
+u64 N0;          // -p^-1 mod 2^64
+Fp R1, R2;       // R mod p (Montgomery one), R^2 mod p
+Fp FP_ZERO = {{0, 0, 0, 0, 0, 0}};
+u64 EXP_PM2[6], EXP_PP1D4[6], EXP_PM1D2[6], HALF_P[6];  // p-2, (p+1)/4, (p-1)/2 as plain integers
+
+inline bool geq(const u64* a, const u64* b) {
+    for (int i = 5; i >= 0; i--) {
+        if (a[i] != b[i]) return a[i] > b[i];
+    }
+    return true;
+}
+inline void sub_n(u64* r, const u64* a, const u64* b) {
+    u64 bw = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 t = (u128)a[i] - b[i] - bw;
+        r[i] = (u64)t;
+        bw = (u64)(t >> 64) & 1;
+    }
+}
+inline Fp fp_add(const Fp& a, const Fp& b) {
+    Fp r;
+    u64 c = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 t = (u128)a.l[i] + b.l[i] + c;
+        r.l[i] = (u64)t;
+        c = (u64)(t >> 64);
+    }
+    if (c || geq(r.l, P.l)) sub_n(r.l, r.l, P.l);
+    return r;
+}
+inline Fp fp_sub(const Fp& a, const Fp& b) {
+    Fp r;
+    u64 bw = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 t = (u128)a.l[i] - b.l[i] - bw;
+        r.l[i] = (u64)t;
+        bw = (u64)(t >> 64) & 1;
+    }
+    if (bw) {
+        u64 c = 0;
+        for (int i = 0; i < 6; i++) {
+            u128 t = (u128)r.l[i] + P.l[i] + c;
+            r.l[i] = (u64)t;
+            c = (u64)(t >> 64);
+        }
+    }
+    return r;
+}
+inline bool fp_is_zero(const Fp& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3] | a.l[4] | a.l[5]) == 0; }
+inline bool fp_eq(const Fp& a, const Fp& b) { return memcmp(a.l, b.l, 48) == 0; }
+inline Fp fp_neg(const Fp& a) { return fp_is_zero(a) ? a : fp_sub(FP_ZERO, a); }
+inline Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
+// CIOS Montgomery product
+inline Fp fp_mul(const Fp& a, const Fp& b) {
+    u64 t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 6; i++) {
+        u64 c = 0;
+        for (int j = 0; j < 6; j++) {
+            u128 s = (u128)a.l[j] * b.l[i] + t[j] + c;
+            t[j] = (u64)s;
+            c = (u64)(s >> 64);
+        }
+        u128 s = (u128)t[6] + c;
+        t[6] = (u64)s;
+        t[7] = (u64)(s >> 64);
+        const u64 m = t[0] * N0;
+        s = (u128)m * P.l[0] + t[0];
+        c = (u64)(s >> 64);
+        for (int j = 1; j < 6; j++) {
+            s = (u128)m * P.l[j] + t[j] + c;
+            t[j - 1] = (u64)s;
+            c = (u64)(s >> 64);
+        }
+        s = (u128)t[6] + c;
+        t[5] = (u64)s;
+        t[6] = t[7] + (u64)(s >> 64);
+    }
+    Fp r;
+    memcpy(r.l, t, 48);
+    if (t[6] || geq(r.l, P.l)) sub_n(r.l, r.l, P.l);
+    return r;
+}
+inline Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
+Fp fp_pow(const Fp& a, const u64* e) {  // plain 384-bit exponent
+    Fp r = R1;
+    bool started = false;
+    for (int i = 383; i >= 0; i--) {
+        if (started) r = fp_sqr(r);
+        if ((e[i >> 6] >> (i & 63)) & 1) {
+            r = started ? fp_mul(r, a) : a;
+            started = true;
+        }
+    }
+    return r;
+}
+inline Fp fp_inv(const Fp& a) { return fp_pow(a, EXP_PM2); }  // 0 -> 0
+bool fp_sqrt(const Fp& a, Fp& s) {                              // p = 3 mod 4 (oracle/bls12_381.py fp_sqrt)
+    s = fp_pow(a, EXP_PP1D4);
+    return fp_eq(fp_sqr(s), a);
+}
+inline Fp fp_from_raw(const u64* w) {  // plain integer < p -> Montgomery
+    Fp t;
+    memcpy(t.l, w, 48);
+    return fp_mul(t, R2);
+}
+inline void fp_to_raw(const Fp& a, u64* w) {
+    Fp one = {{1, 0, 0, 0, 0, 0}};
+    Fp t = fp_mul(a, one);
+    memcpy(w, t.l, 48);
+}
+Fp fp_from_u64(u64 v) {
+    u64 w[6] = {v, 0, 0, 0, 0, 0};
+    return fp_from_raw(w);
+}
+// 48 big-endian bytes -> plain limbs; false if >= p
+bool raw_from_be48(const u8* b, u64* w, u8 mask0) {
+    for (int i = 0; i < 6; i++) {
+        u64 v = 0;
+        for (int j = 0; j < 8; j++) {
+            u8 x = b[8 * (5 - i) + j];
+            if (i == 5 && j == 0) x &= mask0;
+            v = (v << 8) | x;
+        }
+        w[i] = v;
+    }
+    return !geq(w, P.l);
+}
+void raw_to_be48(const u64* w, u8* b) {
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 8; j++) b[8 * (5 - i) + j] = (u8)(w[i] >> (8 * (7 - j)));
+}
+bool fp_lex_largest(const Fp& a) {  // canonical value > (p-1)/2
+    u64 w[6];
+    fp_to_raw(a, w);
+    if (memcmp(w, HALF_P, 48) == 0) return false;
+    return geq(w, HALF_P);
+}
+// big-endian bytes of arbitrary length (<= 64) reduced mod p (hash_to_field: 64-byte strings)
+Fp fp_from_be_reduce(const u8* b, size_t len) {
+    // Horner over bytes: acc = acc * 256 + byte, all in Montgomery form
+    Fp acc = FP_ZERO;
+    const Fp k256 = fp_from_u64(256);
+    for (size_t i = 0; i < len; i++) acc = fp_add(fp_mul(acc, k256), fp_from_u64(b[i]));
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fp2 = Fp[i]/(i^2 + 1)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Fp2 {
+    Fp c0, c1;
+};
+Fp2 F2_ZERO, F2_ONE;
+inline Fp2 f2_add(const Fp2& a, const Fp2& b) { return {fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
+inline Fp2 f2_sub(const Fp2& a, const Fp2& b) { return {fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
+inline Fp2 f2_neg(const Fp2& a) { return {fp_neg(a.c0), fp_neg(a.c1)}; }
+inline Fp2 f2_dbl(const Fp2& a) { return f2_add(a, a); }
+inline Fp2 f2_conj(const Fp2& a) { return {a.c0, fp_neg(a.c1)}; }
+inline bool f2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+inline bool f2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+inline Fp2 f2_mul(const Fp2& a, const Fp2& b) {  // Karatsuba
+    Fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
+    Fp t2 = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+    return {fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
+}
+inline Fp2 f2_sqr(const Fp2& a) { return {fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(fp_mul(a.c0, a.c1))}; }
+inline Fp2 f2_muls(const Fp2& a, const Fp& k) { return {fp_mul(a.c0, k), fp_mul(a.c1, k)}; }
+inline Fp2 f2_mul_xi(const Fp2& a) { return {fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; }  // (1 + i) a
+inline Fp2 f2_inv(const Fp2& a) {
+    Fp d = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
+    return {fp_mul(a.c0, d), fp_neg(fp_mul(a.c1, d))};
+}
+Fp2 f2_pow_u64(const Fp2& a, u64 e) {
+    Fp2 r = F2_ONE, b = a;
+    while (e) {
+        if (e & 1) r = f2_mul(r, b);
+        b = f2_sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+Fp INV2;
+// any square root, via the norm (oracle/bls12_381.py f2_sqrt)
+bool f2_sqrt(const Fp2& a, Fp2& r) {
+    if (fp_is_zero(a.c1)) {
+        Fp s;
+        if (fp_sqrt(a.c0, s)) {
+            r = {s, FP_ZERO};
+            return true;
+        }
+        bool ok = fp_sqrt(fp_neg(a.c0), s);
+        r = {FP_ZERO, s};
+        return ok;
+    }
+    Fp n = fp_add(fp_sqr(a.c0), fp_sqr(a.c1)), s;
+    if (!fp_sqrt(n, s)) return false;
+    Fp d = fp_mul(fp_add(a.c0, s), INV2), x0;
+    if (!fp_sqrt(d, x0)) {
+        d = fp_mul(fp_sub(a.c0, s), INV2);
+        if (!fp_sqrt(d, x0)) return false;
+    }
+    Fp x1 = fp_mul(a.c1, fp_inv(fp_dbl(x0)));
+    r = {x0, x1};
+    return f2_eq(f2_sqr(r), a);
+}
+int f2_sgn0(const Fp2& a) {  // RFC 9380 sgn0, m = 2
+    u64 w0[6], w1[6];
+    fp_to_raw(a.c0, w0);
+    fp_to_raw(a.c1, w1);
+    int z0 = fp_is_zero(a.c0) ? 1 : 0;
+    return (int)(w0[0] & 1) | (z0 & (int)(w1[0] & 1));
+}
+bool f2_lex_largest(const Fp2& a) { return fp_is_zero(a.c1) ? fp_lex_largest(a.c0) : fp_lex_largest(a.c1); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fp6 = Fp2[v]/(v^3 - xi), Fp12 = Fp6[w]/(w^2 - v)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Fp6 {
+    Fp2 c0, c1, c2;
+};
+struct Fp12 {
+    Fp6 c0, c1;
+};
+inline Fp6 f6_add(const Fp6& a, const Fp6& b) { return {f2_add(a.c0, b.c0), f2_add(a.c1, b.c1), f2_add(a.c2, b.c2)}; }
+inline Fp6 f6_sub(const Fp6& a, const Fp6& b) { return {f2_sub(a.c0, b.c0), f2_sub(a.c1, b.c1), f2_sub(a.c2, b.c2)}; }
+inline Fp6 f6_neg(const Fp6& a) { return {f2_neg(a.c0), f2_neg(a.c1), f2_neg(a.c2)}; }
+inline Fp6 f6_mul_v(const Fp6& a) { return {f2_mul_xi(a.c2), a.c0, a.c1}; }
+Fp6 f6_mul(const Fp6& a, const Fp6& b) {
+    Fp2 t0 = f2_mul(a.c0, b.c0), t1 = f2_mul(a.c1, b.c1), t2 = f2_mul(a.c2, b.c2);
+    Fp2 c0 = f2_add(t0, f2_mul_xi(f2_sub(f2_mul(f2_add(a.c1, a.c2), f2_add(b.c1, b.c2)), f2_add(t1, t2))));
+    Fp2 c1 = f2_add(f2_sub(f2_mul(f2_add(a.c0, a.c1), f2_add(b.c0, b.c1)), f2_add(t0, t1)), f2_mul_xi(t2));
+    Fp2 c2 = f2_add(f2_sub(f2_mul(f2_add(a.c0, a.c2), f2_add(b.c0, b.c2)), f2_add(t0, t2)), t1);
+    return {c0, c1, c2};
+}
+// a * (b0 + b1 v)
+Fp6 f6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {
+    Fp2 t0 = f2_mul(a.c0, b0), t1 = f2_mul(a.c1, b1);
+    Fp2 c0 = f2_add(t0, f2_mul_xi(f2_mul(a.c2, b1)));
+    Fp2 c1 = f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c1), f2_add(b0, b1)), t0), t1);
+    Fp2 c2 = f2_add(f2_mul(a.c2, b0), t1);
+    return {c0, c1, c2};
+}
+// a * (b1 v)
+Fp6 f6_mul_by_1(const Fp6& a, const Fp2& b1) { return {f2_mul_xi(f2_mul(a.c2, b1)), f2_mul(a.c0, b1), f2_mul(a.c1, b1)}; }
+Fp6 f6_inv(const Fp6& a) {
+    Fp2 c0 = f2_sub(f2_sqr(a.c0), f2_mul_xi(f2_mul(a.c1, a.c2)));
+    Fp2 c1 = f2_sub(f2_mul_xi(f2_sqr(a.c2)), f2_mul(a.c0, a.c1));
+    Fp2 c2 = f2_sub(f2_sqr(a.c1), f2_mul(a.c0, a.c2));
+    Fp2 t = f2_add(f2_mul(a.c0, c0), f2_mul_xi(f2_add(f2_mul(a.c2, c1), f2_mul(a.c1, c2))));
+    Fp2 ti = f2_inv(t);
+    return {f2_mul(c0, ti), f2_mul(c1, ti), f2_mul(c2, ti)};
+}
+Fp12 F12_ONE;
+Fp12 f12_mul(const Fp12& a, const Fp12& b) {
+    Fp6 t0 = f6_mul(a.c0, b.c0), t1 = f6_mul(a.c1, b.c1);
+    Fp6 c0 = f6_add(t0, f6_mul_v(t1));
+    Fp6 c1 = f6_sub(f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1)), f6_add(t0, t1));
+    return {c0, c1};
+}
+Fp12 f12_sqr(const Fp12& a) {  // complex squaring
+    Fp6 ab = f6_mul(a.c0, a.c1);
+    Fp6 s = f6_mul(f6_add(a.c0, a.c1), f6_add(a.c0, f6_mul_v(a.c1)));
+    return {f6_sub(f6_sub(s, ab), f6_mul_v(ab)), f6_add(ab, ab)};
+}
+inline Fp12 f12_conj(const Fp12& a) { return {a.c0, f6_neg(a.c1)}; }
+Fp12 f12_inv(const Fp12& a) {
+    Fp6 t = f6_sub(f6_mul(a.c0, a.c0), f6_mul_v(f6_mul(a.c1, a.c1)));
+    Fp6 ti = f6_inv(t);
+    return {f6_mul(a.c0, ti), f6_neg(f6_mul(a.c1, ti))};
+}
+bool f12_is_one(const Fp12& a) {
+    return fp_eq(a.c0.c0.c0, R1) && fp_is_zero(a.c0.c0.c1) && f2_is_zero(a.c0.c1) && f2_is_zero(a.c0.c2) && f2_is_zero(a.c1.c0) &&
+           f2_is_zero(a.c1.c1) && f2_is_zero(a.c1.c2);
+}
+// f * ((l0 + l1 v) + (l2 v) w): the sparse line shape (13 Fp2 products)
+Fp12 f12_mul_by_line(const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+    Fp6 aa = f6_mul_by_01(f.c0, l0, l1);
+    Fp6 bb = f6_mul_by_1(f.c1, l2);
+    Fp6 m = f6_mul_by_01(f6_add(f.c0, f.c1), l0, f2_add(l1, l2));
+    return {f6_add(aa, f6_mul_v(bb)), f6_sub(f6_sub(m, aa), bb)};
+}
+// Frobenius: a = sum a_k w^k, a^p = sum conj(a_k) GAMMA[k] w^k, GAMMA[k] = xi^(k (p-1)/6) (oracle/bls12_381.py f12_frob)
+Fp2 GAMMA[6];
+Fp12 f12_frob(const Fp12& a) {
+    Fp12 r;
+    r.c0.c0 = f2_conj(a.c0.c0);
+    r.c1.c0 = f2_mul(f2_conj(a.c1.c0), GAMMA[1]);
+    r.c0.c1 = f2_mul(f2_conj(a.c0.c1), GAMMA[2]);
+    r.c1.c1 = f2_mul(f2_conj(a.c1.c1), GAMMA[3]);
+    r.c0.c2 = f2_mul(f2_conj(a.c0.c2), GAMMA[4]);
+    r.c1.c2 = f2_mul(f2_conj(a.c1.c2), GAMMA[5]);
+    return r;
+}
+// Granger-Scott squaring in the cyclotomic subgroup (valid after the easy part of the final exponentiation)
+inline void f4_sqr(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
+    Fp2 t0 = f2_sqr(a), t1 = f2_sqr(b);
+    c0 = f2_add(f2_mul_xi(t1), t0);
+    c1 = f2_sub(f2_sub(f2_sqr(f2_add(a, b)), t0), t1);
+}
+Fp12 f12_cyc_sqr(const Fp12& f) {
+    Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2, t0, t1, t2, t3;
+    f4_sqr(t0, t1, z0, z1);
+    z0 = f2_add(f2_dbl(f2_sub(t0, z0)), t0);
+    z1 = f2_add(f2_dbl(f2_add(t1, z1)), t1);
+    f4_sqr(t0, t1, z2, z3);
+    f4_sqr(t2, t3, z4, z5);
+    z4 = f2_add(f2_dbl(f2_sub(t0, z4)), t0);
+    z5 = f2_add(f2_dbl(f2_add(t1, z5)), t1);
+    t0 = f2_mul_xi(t3);
+    z2 = f2_add(f2_dbl(f2_add(t0, z2)), t0);
+    z3 = f2_add(f2_dbl(f2_sub(t2, z3)), t2);
+    return {{z0, z4, z3}, {z2, z1, z5}};
+}
+const u64 X_ABS = 0xd201000000010000ULL;
+Fp12 f12_cyc_pow_x(const Fp12& a) {  // a^x, x < 0: conjugate
+    Fp12 r = a;
+    for (int b = 62; b >= 0; b--) {
+        r = f12_cyc_sqr(r);
+        if ((X_ABS >> b) & 1) r = f12_mul(r, a);
+    }
+    return f12_conj(r);
+}
+// f^(3 (p^12 - 1)/r): easy part, then (x-1)^2 (x+p)(x^2+p^2-1) + 3 (oracle/bls12_381.py final_exponentiation)
+Fp12 final_exponentiation(const Fp12& f) {
+    Fp12 t = f12_mul(f12_conj(f), f12_inv(f));
+    t = f12_mul(f12_frob(f12_frob(t)), t);
+    Fp12 a = f12_mul(f12_cyc_pow_x(t), f12_conj(t));
+    a = f12_mul(f12_cyc_pow_x(a), f12_conj(a));
+    Fp12 b = f12_mul(f12_cyc_pow_x(a), f12_frob(a));
+    Fp12 c = f12_mul(f12_mul(f12_cyc_pow_x(f12_cyc_pow_x(b)), f12_frob(f12_frob(b))), f12_conj(b));
+    return f12_mul(c, f12_mul(f12_cyc_sqr(t), t));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// curves: E1: y^2 = x^3 + 4 over Fp, E2: y^2 = x^3 + 4 (1 + i) over Fp2; Jacobian coordinates, z = 0 is infinity
+// ---------------------------------------------------------------------------------------------------------------------
+struct FOps1 {
+    typedef Fp T;
+    static T add(const T& a, const T& b) { return fp_add(a, b); }
+    static T sub(const T& a, const T& b) { return fp_sub(a, b); }
+    static T mul(const T& a, const T& b) { return fp_mul(a, b); }
+    static T sqr(const T& a) { return fp_sqr(a); }
+    static T neg(const T& a) { return fp_neg(a); }
+    static T inv(const T& a) { return fp_inv(a); }
+    static bool is_zero(const T& a) { return fp_is_zero(a); }
+    static bool eq(const T& a, const T& b) { return fp_eq(a, b); }
+    static T zero() { return FP_ZERO; }
+    static T one() { return R1; }
+};
+struct FOps2 {
+    typedef Fp2 T;
+    static T add(const T& a, const T& b) { return f2_add(a, b); }
+    static T sub(const T& a, const T& b) { return f2_sub(a, b); }
+    static T mul(const T& a, const T& b) { return f2_mul(a, b); }
+    static T sqr(const T& a) { return f2_sqr(a); }
+    static T neg(const T& a) { return f2_neg(a); }
+    static T inv(const T& a) { return f2_inv(a); }
+    static bool is_zero(const T& a) { return f2_is_zero(a); }
+    static bool eq(const T& a, const T& b) { return f2_eq(a, b); }
+    static T zero() { return F2_ZERO; }
+    static T one() { return F2_ONE; }
+};
+template <class F>
+struct Jac {
+    typename F::T x, y, z;
+};
+template <class F>
+struct Aff {
+    typename F::T x, y;
+    bool inf;
+};
+template <class F>
+Jac<F> jac_inf() { return {F::one(), F::one(), F::zero()}; }
+template <class F>
+Jac<F> jac_from_aff(const Aff<F>& a) { return a.inf ? jac_inf<F>() : Jac<F>{a.x, a.y, F::one()}; }
+template <class F>
+Jac<F> jac_dbl(const Jac<F>& p) {  // dbl-2009-l, a = 0
+    if (F::is_zero(p.z)) return p;
+    auto A = F::sqr(p.x), B = F::sqr(p.y), C = F::sqr(B);
+    auto t = F::sub(F::sub(F::sqr(F::add(p.x, B)), A), C);
+    auto D = F::add(t, t);
+    auto E = F::add(F::add(A, A), A);
+    auto Fq = F::sqr(E);
+    auto X3 = F::sub(Fq, F::add(D, D));
+    auto C8 = F::add(C, C);
+    C8 = F::add(C8, C8);
+    C8 = F::add(C8, C8);
+    auto Y3 = F::sub(F::mul(E, F::sub(D, X3)), C8);
+    auto Z3 = F::mul(p.y, p.z);
+    return {X3, Y3, F::add(Z3, Z3)};
+}
+template <class F>
+Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {  // add-2007-bl with the special cases
+    if (F::is_zero(p.z)) return q;
+    if (F::is_zero(q.z)) return p;
+    auto Z1Z1 = F::sqr(p.z), Z2Z2 = F::sqr(q.z);
+    auto U1 = F::mul(p.x, Z2Z2), U2 = F::mul(q.x, Z1Z1);
+    auto S1 = F::mul(F::mul(p.y, q.z), Z2Z2), S2 = F::mul(F::mul(q.y, p.z), Z1Z1);
+    if (F::eq(U1, U2)) {
+        if (F::eq(S1, S2)) return jac_dbl<F>(p);
+        return jac_inf<F>();
+    }
+    auto H = F::sub(U2, U1);
+    auto I = F::sqr(F::add(H, H));
+    auto J = F::mul(H, I);
+    auto rr = F::sub(S2, S1);
+    rr = F::add(rr, rr);
+    auto V = F::mul(U1, I);
+    auto X3 = F::sub(F::sub(F::sqr(rr), J), F::add(V, V));
+    auto SJ = F::mul(S1, J);
+    auto Y3 = F::sub(F::mul(rr, F::sub(V, X3)), F::add(SJ, SJ));
+    auto Z3 = F::mul(F::sub(F::sub(F::sqr(F::add(p.z, q.z)), Z1Z1), Z2Z2), H);
+    return {X3, Y3, Z3};
+}
+template <class F>
+Jac<F> jac_neg(const Jac<F>& p) { return {p.x, F::neg(p.y), p.z}; }
+template <class F>
+Aff<F> jac_to_aff(const Jac<F>& p) {
+    if (F::is_zero(p.z)) return {F::zero(), F::zero(), true};
+    auto zi = F::inv(p.z), zi2 = F::sqr(zi);
+    return {F::mul(p.x, zi2), F::mul(p.y, F::mul(zi2, zi)), false};
+}
+template <class F>
+bool jac_eq(const Jac<F>& p, const Jac<F>& q) {
+    const bool pi = F::is_zero(p.z), qi = F::is_zero(q.z);
+    if (pi || qi) return pi && qi;
+    auto Z1Z1 = F::sqr(p.z), Z2Z2 = F::sqr(q.z);
+    return F::eq(F::mul(p.x, Z2Z2), F::mul(q.x, Z1Z1)) && F::eq(F::mul(F::mul(p.y, q.z), Z2Z2), F::mul(F::mul(q.y, p.z), Z1Z1));
+}
+// [k] P for a little-endian multi-word scalar, plain double-and-add
+template <class F>
+Jac<F> jac_mul(const Jac<F>& p, const u64* k, int words) {
+    Jac<F> r = jac_inf<F>();
+    for (int i = words * 64 - 1; i >= 0; i--) {
+        r = jac_dbl<F>(r);
+        if ((k[i >> 6] >> (i & 63)) & 1) r = jac_add<F>(r, p);
+    }
+    return r;
+}
+typedef Jac<FOps1> J1;
+typedef Jac<FOps2> J2;
+typedef Aff<FOps1> A1;
+typedef Aff<FOps2> A2;
+const u64 R_ORDER[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+Fp B1;       // 4
+Fp2 B2;      // 4 (1 + i)
+A1 G1_GEN, G1_GEN_NEG;
+Fp2 PSI_X, PSI_Y;  // psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y)
+
+bool g1_in_subgroup(const A1& p) {  // definition: [r] P == inf
+    return fp_is_zero(jac_mul<FOps1>(jac_from_aff<FOps1>(p), R_ORDER, 4).z);
+}
+J2 g2_psi(const J2& p) { return {f2_mul(f2_conj(p.x), PSI_X), f2_mul(f2_conj(p.y), PSI_Y), f2_conj(p.z)}; }
+// [x] P, x = -X_ABS
+J2 g2_mul_x(const J2& p) { return jac_neg<FOps2>(jac_mul<FOps2>(p, &X_ABS, 1)); }
+bool g2_in_subgroup_def(const A2& p) { return f2_is_zero(jac_mul<FOps2>(jac_from_aff<FOps2>(p), R_ORDER, 4).z); }
+// Scott, ePrint 2021/1130: Q on E2 is in G2 iff psi(Q) == [x] Q (checked against the definition in tests/test_oracle_cbls.py)
+bool g2_in_subgroup(const A2& p) {
+    if (p.inf) return true;
+    J2 q = jac_from_aff<FOps2>(p);
+    return jac_eq<FOps2>(g2_psi(q), g2_mul_x(q));
+}
+
+// ---- ZCash serialization -> BLST_ERROR codes (oracle/bls12_381.py g1_decompress / g2_decompress) ----------------------
+enum { OK = 0, BAD_ENCODING = 1, NOT_ON_CURVE = 2, NOT_IN_GROUP = 3, AGGR_TYPE_MISMATCH = 4, VERIFY_FAIL = 5, PK_IS_INFINITY = 6, IN_VERIFY = 0x40 };
+bool all_zero(const u8* b, size_t from, size_t to) {
+    u8 o = 0;
+    for (size_t i = from; i < to; i++) o |= b[i];
+    return o == 0;
+}
+int g1_decompress(A1& out, const u8* b) {
+    out.inf = false;
+    const u8 b0 = b[0];
+    if (!(b0 & 0x80)) return BAD_ENCODING;
+    if (b0 & 0x40) {
+        if ((b0 & 0x3f) == 0 && all_zero(b, 1, 48)) {
+            out = {FP_ZERO, FP_ZERO, true};
+            return OK;
+        }
+        return BAD_ENCODING;
+    }
+    u64 w[6];
+    if (!raw_from_be48(b, w, 0x1f)) return BAD_ENCODING;
+    Fp x = fp_from_raw(w), y;
+    if (!fp_sqrt(fp_add(fp_mul(fp_sqr(x), x), B1), y)) return NOT_ON_CURVE;
+    if (fp_lex_largest(y) != ((b0 & 0x20) != 0)) y = fp_neg(y);
+    if (fp_is_zero(x)) return NOT_IN_GROUP;
+    out = {x, y, false};
+    return OK;
+}
+void g1_compress(u8* b, const A1& p) {
+    if (p.inf) {
+        memset(b, 0, 48);
+        b[0] = 0xc0;
+        return;
+    }
+    u64 w[6];
+    fp_to_raw(p.x, w);
+    raw_to_be48(w, b);
+    b[0] |= 0x80;
+    if (fp_lex_largest(p.y)) b[0] |= 0x20;
+}
+int g2_decompress(A2& out, const u8* b) {
+    out.inf = false;
+    const u8 b0 = b[0];
+    if (!(b0 & 0x80)) return BAD_ENCODING;
+    if (b0 & 0x40) {
+        if ((b0 & 0x3f) == 0 && all_zero(b, 1, 96)) {
+            out = {F2_ZERO, F2_ZERO, true};
+            return OK;
+        }
+        return BAD_ENCODING;
+    }
+    u64 w1[6], w0[6];
+    const bool ok1 = raw_from_be48(b, w1, 0x1f), ok0 = raw_from_be48(b + 48, w0, 0xff);
+    if (!ok1 || !ok0) return BAD_ENCODING;
+    Fp2 x = {fp_from_raw(w0), fp_from_raw(w1)}, y;
+    if (!f2_sqrt(f2_add(f2_mul(f2_sqr(x), x), B2), y)) return NOT_ON_CURVE;
+    if (f2_lex_largest(y) != ((b0 & 0x20) != 0)) y = f2_neg(y);
+    if (f2_is_zero(x)) return NOT_IN_GROUP;
+    out = {x, y, false};
+    return OK;
+}
+void g2_compress(u8* b, const A2& p) {
+    if (p.inf) {
+        memset(b, 0, 96);
+        b[0] = 0xc0;
+        return;
+    }
+    u64 w[6];
+    fp_to_raw(p.x.c1, w);
+    raw_to_be48(w, b);
+    fp_to_raw(p.x.c0, w);
+    raw_to_be48(w, b + 48);
+    b[0] |= 0x80;
+    if (f2_lex_largest(p.y)) b[0] |= 0x20;
+}
+// blst PublicKey::key_validate (crypto/bls.rs:279-285): decode, reject infinity, subgroup check
+int key_validate(A1& out, const u8* pk) {
+    int st = g1_decompress(out, pk);
+    if (st) return st;
+    if (out.inf) return PK_IS_INFINITY;
+    if (!g1_in_subgroup(out)) return NOT_IN_GROUP;
+    return OK;
+}
+
+// ---- SHA-256 (FIPS 180-4), portable ----------------------------------------------------------------------------------
+const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+void sha256_block(uint32_t* h, const u8* p) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+        uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g, g = f, f = e, e = d + t1, d = c, c = b, b = a, a = t1 + t2;
+    }
+    h[0] += a, h[1] += b, h[2] += c, h[3] += d, h[4] += e, h[5] += f, h[6] += g, h[7] += hh;
+}
+void sha256(const std::vector<u8>& msg, u8* out) {
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    std::vector<u8> m(msg);
+    const u64 bits = (u64)msg.size() * 8;
+    m.push_back(0x80);
+    while (m.size() % 64 != 56) m.push_back(0);
+    for (int i = 7; i >= 0; i--) m.push_back((u8)(bits >> (8 * i)));
+    for (size_t o = 0; o < m.size(); o += 64) sha256_block(h, m.data() + o);
+    for (int i = 0; i < 8; i++) {
+        out[4 * i] = (u8)(h[i] >> 24), out[4 * i + 1] = (u8)(h[i] >> 16), out[4 * i + 2] = (u8)(h[i] >> 8), out[4 * i + 3] = (u8)h[i];
+    }
+}
+
+// ---- RFC 9380 hash_to_curve, suite BLS12381G2_XMD:SHA-256_SSWU_RO_, DST of crypto/bls.rs:22 ---------------------------
+const char DST[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";
+void expand_message_xmd(const u8* msg, size_t len, size_t out_len, u8* out) {
+    const size_t dst_len = sizeof(DST) - 1, ell = (out_len + 31) / 32;
+    std::vector<u8> m(64, 0);
+    m.insert(m.end(), msg, msg + len);
+    m.push_back((u8)(out_len >> 8));
+    m.push_back((u8)out_len);
+    m.push_back(0);
+    m.insert(m.end(), DST, DST + dst_len);
+    m.push_back((u8)dst_len);
+    u8 b0[32], bi[32];
+    sha256(m, b0);
+    std::vector<u8> t(b0, b0 + 32);
+    t.push_back(1);
+    t.insert(t.end(), DST, DST + dst_len);
+    t.push_back((u8)dst_len);
+    sha256(t, bi);
+    memcpy(out, bi, out_len < 32 ? out_len : 32);
+    for (size_t i = 2; i <= ell; i++) {
+        std::vector<u8> u(32);
+        for (int k = 0; k < 32; k++) u[k] = b0[k] ^ bi[k];
+        u.push_back((u8)i);
+        u.insert(u.end(), DST, DST + dst_len);
+        u.push_back((u8)dst_len);
+        sha256(u, bi);
+        const size_t off = 32 * (i - 1);
+        memcpy(out + off, bi, out_len - off < 32 ? out_len - off : 32);
+    }
+}
+Fp2 SSWU_A, SSWU_B, SSWU_Z, SSWU_NEG_B_OVER_A, SSWU_B_OVER_ZA;
+Fp2 ISO_XNUM[4], ISO_XDEN[3], ISO_YNUM[4], ISO_YDEN[4];
+// simplified SWU onto E2': y^2 = x^3 + A' x + B' (RFC 9380 6.6.2; oracle/bls12_381.py map_to_curve_sswu)
+void map_to_curve_sswu(const Fp2& u, Fp2& x, Fp2& y) {
+    Fp2 tv1 = f2_mul(SSWU_Z, f2_sqr(u));
+    Fp2 tv2 = f2_add(f2_sqr(tv1), tv1);
+    Fp2 x1 = f2_is_zero(tv2) ? SSWU_B_OVER_ZA : f2_mul(SSWU_NEG_B_OVER_A, f2_add(F2_ONE, f2_inv(tv2)));
+    Fp2 gx1 = f2_add(f2_add(f2_mul(f2_sqr(x1), x1), f2_mul(SSWU_A, x1)), SSWU_B);
+    if (f2_sqrt(gx1, y)) {
+        x = x1;
+    } else {
+        x = f2_mul(tv1, x1);
+        Fp2 gx2 = f2_add(f2_add(f2_mul(f2_sqr(x), x), f2_mul(SSWU_A, x)), SSWU_B);
+        f2_sqrt(gx2, y);
+    }
+    if (f2_sgn0(u) != f2_sgn0(y)) y = f2_neg(y);
+}
+Fp2 horner(const Fp2* c, int n, const Fp2& x) {
+    Fp2 acc = c[n - 1];
+    for (int i = n - 2; i >= 0; i--) acc = f2_add(f2_mul(acc, x), c[i]);
+    return acc;
+}
+A2 iso3(const Fp2& x, const Fp2& y) {  // 3-isogeny E2' -> E2
+    Fp2 xd = horner(ISO_XDEN, 3, x), yd = horner(ISO_YDEN, 4, x);
+    if (f2_is_zero(xd) || f2_is_zero(yd)) return {F2_ZERO, F2_ZERO, true};
+    Fp2 xn = horner(ISO_XNUM, 4, x), yn = horner(ISO_YNUM, 4, x);
+    return {f2_mul(xn, f2_inv(xd)), f2_mul(y, f2_mul(yn, f2_inv(yd))), false};
+}
+// Budroni-Pintore: [x^2 - x - 1] P + [x - 1] psi(P) + psi^2(2P) (oracle/bls12_381.py clear_cofactor_g2_fast)
+J2 clear_cofactor_g2(const J2& p) {
+    J2 t1 = g2_mul_x(p);
+    J2 t2 = g2_psi(p);
+    J2 t3 = g2_psi(g2_psi(jac_dbl<FOps2>(p)));
+    t3 = jac_add<FOps2>(t3, jac_neg<FOps2>(t2));
+    t2 = jac_add<FOps2>(t1, t2);
+    t2 = g2_mul_x(t2);
+    t3 = jac_add<FOps2>(t3, t2);
+    t3 = jac_add<FOps2>(t3, jac_neg<FOps2>(t1));
+    return jac_add<FOps2>(t3, jac_neg<FOps2>(p));
+}
+A2 hash_to_g2(const u8* msg, size_t len) {
+    u8 uni[256];
+    expand_message_xmd(msg, len, 256, uni);
+    Fp2 u0 = {fp_from_be_reduce(uni, 64), fp_from_be_reduce(uni + 64, 64)};
+    Fp2 u1 = {fp_from_be_reduce(uni + 128, 64), fp_from_be_reduce(uni + 192, 64)};
+    Fp2 x, y;
+    map_to_curve_sswu(u0, x, y);
+    A2 q0 = iso3(x, y);
+    map_to_curve_sswu(u1, x, y);
+    A2 q1 = iso3(x, y);
+    J2 s = jac_add<FOps2>(jac_from_aff<FOps2>(q0), jac_from_aff<FOps2>(q1));
+    return jac_to_aff<FOps2>(clear_cofactor_g2(s));
+}
+
+// ---- optimal-ate pairing: Miller loop over |x| on the M-twist with inversion-free Jacobian steps ----------------------
+// Lines are scaled by w^3 and by an Fp2 factor (both killed by the final exponentiation):
+//   doubling:  (E X - 2 Y^2) + (-E Z^2 xP) w^2 + (Z3 Z^2 yP) w^3        E = 3 X^2, Z3 = 2 Y Z
+//   addition:  (r xQ - yQ Z3) + (-r xP) w^2 + (Z3 yP) w^3               r = 2 (yQ Z^3 - Y), Z3 = 2 Z H
+// The affine-slope form in oracle/bls12_381.py (_line / miller_loop) gives the same pairing VALUE; tests compare the two.
+struct MPair {
+    Fp px, py;
+    Fp2 qx, qy;
+    J2 t;
+};
+void miller_dbl(Fp12& f, MPair& m) {
+    const J2& T = m.t;
+    Fp2 A = f2_sqr(T.x), B = f2_sqr(T.y), C = f2_sqr(B);
+    Fp2 D = f2_dbl(f2_sub(f2_sub(f2_sqr(f2_add(T.x, B)), A), C));
+    Fp2 E = f2_add(f2_dbl(A), A), Fq = f2_sqr(E), ZZ = f2_sqr(T.z);
+    Fp2 Z3 = f2_dbl(f2_mul(T.y, T.z));
+    Fp2 l0 = f2_sub(f2_mul(E, T.x), f2_dbl(B));
+    Fp2 l1 = f2_neg(f2_muls(f2_mul(E, ZZ), m.px));
+    Fp2 l2 = f2_muls(f2_mul(Z3, ZZ), m.py);
+    Fp2 X3 = f2_sub(Fq, f2_dbl(D));
+    Fp2 C8 = f2_dbl(f2_dbl(f2_dbl(C)));
+    Fp2 Y3 = f2_sub(f2_mul(E, f2_sub(D, X3)), C8);
+    m.t = {X3, Y3, Z3};
+    f = f12_mul_by_line(f, l0, l1, l2);
+}
+void miller_add(Fp12& f, MPair& m) {
+    const J2& T = m.t;
+    Fp2 Z1Z1 = f2_sqr(T.z), U2 = f2_mul(m.qx, Z1Z1), S2 = f2_mul(f2_mul(m.qy, T.z), Z1Z1);
+    Fp2 H = f2_sub(U2, T.x), HH = f2_sqr(H), I = f2_dbl(f2_dbl(HH)), J = f2_mul(H, I);
+    Fp2 rr = f2_dbl(f2_sub(S2, T.y)), V = f2_mul(T.x, I);
+    Fp2 X3 = f2_sub(f2_sub(f2_sqr(rr), J), f2_dbl(V));
+    Fp2 Y3 = f2_sub(f2_mul(rr, f2_sub(V, X3)), f2_dbl(f2_mul(T.y, J)));
+    Fp2 Z3 = f2_sub(f2_sub(f2_sqr(f2_add(T.z, H)), Z1Z1), HH);
+    Fp2 l0 = f2_sub(f2_mul(rr, m.qx), f2_mul(m.qy, Z3));
+    Fp2 l1 = f2_neg(f2_muls(rr, m.px));
+    Fp2 l2 = f2_muls(Z3, m.py);
+    m.t = {X3, Y3, Z3};
+    f = f12_mul_by_line(f, l0, l1, l2);
+}
+// prod_k f_{|x|, Q_k}(P_k), conjugated (x < 0); pairs with a point at infinity contribute 1
+Fp12 miller_loop(const A1* ps, const A2* qs, int n) {
+    std::vector<MPair> pr;
+    for (int k = 0; k < n; k++)
+        if (!ps[k].inf && !qs[k].inf) pr.push_back({ps[k].x, ps[k].y, qs[k].x, qs[k].y, {qs[k].x, qs[k].y, F2_ONE}});
+    Fp12 f = F12_ONE;
+    if (pr.empty()) return f;
+    for (int b = 62; b >= 0; b--) {
+        if (b != 62) f = f12_sqr(f);
+        for (auto& m : pr) miller_dbl(f, m);
+        if ((X_ABS >> b) & 1)
+            for (auto& m : pr) miller_add(f, m);
+    }
+    return f12_conj(f);
+}
+bool pairing_product_is_one(const A1* ps, const A2* qs, int n) { return f12_is_one(final_exponentiation(miller_loop(ps, qs, n))); }
+
+// ---- the wrappers' behaviour (oracle/bls12_381.py _core_verify / fast_aggregate_verify) -------------------------------
+int core_verify(const A1& agg, const A2& h, const A2& sig) {
+    if (!sig.inf && !g2_in_subgroup(sig)) return IN_VERIFY | NOT_IN_GROUP;
+    if (agg.inf) return IN_VERIFY | PK_IS_INFINITY;
+    A1 ps[2] = {agg, G1_GEN_NEG};
+    A2 qs[2] = {h, sig};
+    return pairing_product_is_one(ps, qs, 2) ? OK : VERIFY_FAIL;
+}
+int fast_aggregate_verify(const u8* pks48, uint32_t k, const u8* msg, size_t len, const u8* sig96, int eth) {
+    if (eth && k == 0 && sig96[0] == 0xc0 && all_zero(sig96, 1, 96)) return OK;
+    J1 acc = jac_inf<FOps1>();
+    for (uint32_t i = 0; i < k; i++) {
+        A1 p;
+        int st = key_validate(p, pks48 + 48 * (size_t)i);
+        if (st) return st;
+        acc = jac_add<FOps1>(acc, jac_from_aff<FOps1>(p));
+    }
+    A2 sig;
+    int st = g2_decompress(sig, sig96);
+    if (st) return st;
+    if (k == 0) return AGGR_TYPE_MISMATCH;
+    return core_verify(jac_to_aff<FOps1>(acc), hash_to_g2(msg, len), sig);
+}
+
+// ---- constants -----------------------------------------------------------------------------------------------------
+int hexval(char c) { return c <= '9' ? c - '0' : (c | 32) - 'a' + 10; }
+Fp fp_hex(const char* s) {  // plain integer < p in hex -> Montgomery
+    u64 w[6] = {0, 0, 0, 0, 0, 0};
+    for (const char* q = s; *q; q++) {
+        for (int i = 5; i > 0; i--) w[i] = (w[i] << 4) | (w[i - 1] >> 60);
+        w[0] = (w[0] << 4) | (u64)hexval(*q);
+    }
+    return fp_from_raw(w);
+}
+void shr1(u64* w) {
+    for (int i = 0; i < 6; i++) w[i] = (w[i] >> 1) | (i < 5 ? w[i + 1] << 63 : 0);
+}
+bool g_ready = false;
+void init_constants() {
+    if (g_ready) return;
+    // N0 = -p^-1 mod 2^64 by Newton iteration
+    u64 inv = 1;
+    for (int i = 0; i < 6; i++) inv *= 2 - P.l[0] * inv;
+    N0 = (u64)0 - inv;
+    // R mod p, R^2 mod p by doubling
+    Fp r = {{1, 0, 0, 0, 0, 0}};
+    for (int i = 0; i < 768; i++) {
+        r = fp_add(r, r);
+        if (i == 383) R1 = r;
+    }
+    R2 = r;
+    // exponents
+    u64 one[6] = {1, 0, 0, 0, 0, 0}, two[6] = {2, 0, 0, 0, 0, 0};
+    sub_n(EXP_PM2, P.l, two);
+    u64 t[6];
+    memcpy(t, P.l, 48);
+    t[0] += 1;  // p + 1 (no carry: p = ...aaab)
+    shr1(t);
+    shr1(t);
+    memcpy(EXP_PP1D4, t, 48);
+    sub_n(t, P.l, one);
+    shr1(t);
+    memcpy(EXP_PM1D2, t, 48);
+    memcpy(HALF_P, t, 48);
+    F2_ZERO = {FP_ZERO, FP_ZERO};
+    F2_ONE = {R1, FP_ZERO};
+    F12_ONE = {{F2_ONE, F2_ZERO, F2_ZERO}, {F2_ZERO, F2_ZERO, F2_ZERO}};
+    INV2 = fp_inv(fp_from_u64(2));
+    B1 = fp_from_u64(4);
+    B2 = {B1, B1};
+    G1_GEN = {fp_hex("17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"),
+              fp_hex("08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1"), false};
+    G1_GEN_NEG = {G1_GEN.x, fp_neg(G1_GEN.y), false};
+    // GAMMA[k] = xi^(k (p-1)/6); (p-1)/6 as a 384-bit exponent: square-and-multiply on Fp2 with a multi-word exponent
+    u64 e6[6];
+    {
+        // (p - 1) / 6 by schoolbook division
+        u64 pm1[6];
+        sub_n(pm1, P.l, one);
+        u128 rem = 0;
+        for (int i = 5; i >= 0; i--) {
+            u128 cur = (rem << 64) | pm1[i];
+            e6[i] = (u64)(cur / 6);
+            rem = cur % 6;
+        }
+    }
+    auto f2_pow_wide = [](const Fp2& a, const u64* e) {
+        Fp2 rr = F2_ONE;
+        for (int i = 383; i >= 0; i--) {
+            rr = f2_sqr(rr);
+            if ((e[i >> 6] >> (i & 63)) & 1) rr = f2_mul(rr, a);
+        }
+        return rr;
+    };
+    const Fp2 XI = {R1, R1};
+    const Fp2 g1 = f2_pow_wide(XI, e6);
+    GAMMA[0] = F2_ONE;
+    for (int k = 1; k < 6; k++) GAMMA[k] = f2_mul(GAMMA[k - 1], g1);
+    // psi constants: 1 / xi^((p-1)/3), 1 / xi^((p-1)/2)  (oracle/bls12_381.py PSI_X, PSI_Y)
+    PSI_X = f2_inv(GAMMA[2]);
+    PSI_Y = f2_inv(GAMMA[3]);
+    // SSWU / isogeny constants (RFC 9380 8.8.2, Appendix E.3; values as in oracle/bls12_381.py)
+    SSWU_A = {FP_ZERO, fp_from_u64(240)};
+    SSWU_B = {fp_from_u64(1012), fp_from_u64(1012)};
+    SSWU_Z = {fp_neg(fp_from_u64(2)), fp_neg(fp_from_u64(1))};
+    SSWU_NEG_B_OVER_A = f2_mul(f2_neg(SSWU_B), f2_inv(SSWU_A));
+    SSWU_B_OVER_ZA = f2_mul(SSWU_B, f2_inv(f2_mul(SSWU_Z, SSWU_A)));
+    const Fp ia = fp_hex("5c759507e8e333ebb5b7a9a47d7ed8532c52d39fd3a042a88b58423c50ae15d5c2638e343d9c71c6238aaaaaaaa97d6");
+    const Fp ib = fp_hex("1530477c7ab4113b59a4c18b076d11930f7da5d4a07f649bf54439d87d27e500fc8c25ebf8c92f6812cfc71c71c6d706");
+    ISO_XNUM[0] = {ia, ia};
+    ISO_XNUM[1] = {FP_ZERO, fp_hex("11560bf17baa99bc32126fced787c88f984f87adf7ae0c7f9a208c6b4f20a4181472aaa9cb8d555526a9ffffffffc71a")};
+    ISO_XNUM[2] = {fp_hex("11560bf17baa99bc32126fced787c88f984f87adf7ae0c7f9a208c6b4f20a4181472aaa9cb8d555526a9ffffffffc71e"),
+                   fp_hex("8ab05f8bdd54cde190937e76bc3e447cc27c3d6fbd7063fcd104635a790520c0a395554e5c6aaaa9354ffffffffe38d")};
+    ISO_XNUM[3] = {fp_hex("171d6541fa38ccfaed6dea691f5fb614cb14b4e7f4e810aa22d6108f142b85757098e38d0f671c7188e2aaaaaaaa5ed1"), FP_ZERO};
+    ISO_XDEN[0] = {FP_ZERO, fp_neg(fp_from_u64(0x48))};
+    ISO_XDEN[1] = {fp_from_u64(0xc), fp_neg(fp_from_u64(0xc))};
+    ISO_XDEN[2] = F2_ONE;
+    ISO_YNUM[0] = {ib, ib};
+    ISO_YNUM[1] = {FP_ZERO, fp_hex("5c759507e8e333ebb5b7a9a47d7ed8532c52d39fd3a042a88b58423c50ae15d5c2638e343d9c71c6238aaaaaaaa97be")};
+    ISO_YNUM[2] = {fp_hex("11560bf17baa99bc32126fced787c88f984f87adf7ae0c7f9a208c6b4f20a4181472aaa9cb8d555526a9ffffffffc71c"),
+                   fp_hex("8ab05f8bdd54cde190937e76bc3e447cc27c3d6fbd7063fcd104635a790520c0a395554e5c6aaaa9354ffffffffe38f")};
+    ISO_YNUM[3] = {fp_hex("124c9ad43b6cf79bfbf7043de3811ad0761b0f37a1e26286b0e977c69aa274524e79097a56dc4bd9e1b371c71c718b10"), FP_ZERO};
+    ISO_YDEN[0] = {fp_neg(fp_from_u64(0x1b0)), fp_neg(fp_from_u64(0x1b0))};
+    ISO_YDEN[1] = {FP_ZERO, fp_neg(fp_from_u64(0xd8))};
+    ISO_YDEN[2] = {fp_from_u64(0x12), fp_neg(fp_from_u64(0x12))};
+    ISO_YDEN[3] = F2_ONE;
+    g_ready = true;
+}
+void scalar_from_be32(const u8* b, u64* k) {
+    for (int i = 0; i < 4; i++) {
+        u64 v = 0;
+        for (int j = 0; j < 8; j++) v = (v << 8) | b[8 * (3 - i) + j];
+        k[i] = v;
+    }
+}
+void f12_to_bytes(const Fp12& a, u8* out) {  // 12 x 48 canonical big-endian bytes, order c0.c0.c0, c0.c0.c1, c0.c1.c0, ...
+    const Fp* c = (const Fp*)&a;
+    for (int i = 0; i < 12; i++) {
+        u64 w[6];
+        fp_to_raw(c[i], w);
+        raw_to_be48(w, out + 48 * i);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void cbls_init(void) { init_constants(); }
+
+// (eth_)fast_aggregate_verify -> status (include/ecgpu.h numbering, incl. 0x43 / 0x46)
+int cbls_fast_aggregate_verify(const u8* pks48, uint32_t k, const u8* msg, size_t msg_len, const u8* sig96, int eth) {
+    init_constants();
+    return fast_aggregate_verify(pks48, k, msg, msg_len, sig96, eth);
+}
+// n independent K = 1 tuples over 32-byte messages on `threads` host threads
+void cbls_fav_batch_k1(const u8* pks48, const u8* msgs32, const u8* sigs96, uint32_t n, int threads, u8* status) {
+    init_constants();
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([=] {
+            for (uint32_t i = t; i < n; i += threads)
+                status[i] = (u8)fast_aggregate_verify(pks48 + 48 * (size_t)i, 1, msgs32 + 32 * (size_t)i, 32, sigs96 + 96 * (size_t)i, 0);
+        });
+    for (auto& x : th) x.join();
+}
+// pieces, for the cross-checks against oracle/bls12_381.py
+int cbls_key_validate(const u8* pk48) {
+    init_constants();
+    A1 p;
+    return key_validate(p, pk48);
+}
+// decode + on-curve status; *in_group = subgroup verdict by the psi test, *in_group_def = by [r] Q == inf
+int cbls_sig_check(const u8* sig96, int* in_group, int* in_group_def) {
+    init_constants();
+    A2 q;
+    int st = g2_decompress(q, sig96);
+    *in_group = *in_group_def = 0;
+    if (st == OK) {
+        *in_group = g2_in_subgroup(q) ? 1 : 0;
+        *in_group_def = (q.inf || g2_in_subgroup_def(q)) ? 1 : 0;
+    }
+    return st;
+}
+void cbls_hash_to_g2(const u8* msg, size_t len, u8* out96) {
+    init_constants();
+    g2_compress(out96, hash_to_g2(msg, len));
+}
+void cbls_sk_to_pk(const u8* sk32, u8* out48) {
+    init_constants();
+    u64 k[4];
+    scalar_from_be32(sk32, k);
+    g1_compress(out48, jac_to_aff<FOps1>(jac_mul<FOps1>(jac_from_aff<FOps1>(G1_GEN), k, 4)));
+}
+void cbls_sign(const u8* sk32, const u8* msg, size_t len, u8* out96) {
+    init_constants();
+    u64 k[4];
+    scalar_from_be32(sk32, k);
+    g2_compress(out96, jac_to_aff<FOps2>(jac_mul<FOps2>(jac_from_aff<FOps2>(hash_to_g2(msg, len)), k, 4)));
+}
+// e(P, Q) after the final exponentiation f -> f^(3 (p^12-1)/r), 576 canonical bytes; returns 0, or the decode status
+int cbls_pairing(const u8* p48, const u8* q96, u8* out576) {
+    init_constants();
+    A1 p;
+    A2 q;
+    int st = g1_decompress(p, p48);
+    if (st) return st;
+    st = g2_decompress(q, q96);
+    if (st) return st;
+    f12_to_bytes(final_exponentiation(miller_loop(&p, &q, 1)), out576);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+"""ctypes loader of oracle/_build/liboracle_bls.so: the C++ restatement of the BLS12-381 hot path
+(oracle/c/bls12_381.cpp) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Used as the full-vector checker at sizes the Python
+oracle cannot reach and as bench.py's timed CPU baseline; checked against oracle/bls12_381.py in tests/test_oracle_cbls.py."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "_build", "liboracle_bls.so")
+        src = os.path.join(_HERE, "c", "bls12_381.cpp")
+        if not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        L = ctypes.CDLL(path)
+        L.cbls_fast_aggregate_verify.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                                 ctypes.c_int]
+        L.cbls_fav_batch_k1.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p]
+        L.cbls_fav_batch_k1.restype = None
+        L.cbls_key_validate.argtypes = [ctypes.c_char_p]
+        L.cbls_sig_check.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.cbls_hash_to_g2.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.cbls_sk_to_pk.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        L.cbls_sign.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.cbls_pairing.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+        L.cbls_init()
+        _lib = L
+    return _lib
+
+
+def host_threads() -> int:
+    return max(1, len(os.sched_getaffinity(0)))
+
+
+def fast_aggregate_verify(pks, msg: bytes, sig: bytes, eth: bool = False) -> int:
+    return lib().cbls_fast_aggregate_verify(b"".join(pks), len(pks), msg, len(msg), sig, 1 if eth else 0)
+
+
+def fast_aggregate_verify_batch_k1(pks48: bytes, msgs32: bytes, sigs96: bytes, threads: int = 0) -> bytes:
+    n = len(sigs96) // 96
+    assert len(pks48) == 48 * n and len(msgs32) == 32 * n
+    out = ctypes.create_string_buffer(max(n, 1))
+    lib().cbls_fav_batch_k1(pks48, msgs32, sigs96, n, threads or host_threads(), out)
+    return out.raw[:n]
+
+
+def key_validate(pk: bytes) -> int:
+    return lib().cbls_key_validate(pk)
+
+
+def sig_check(sig: bytes):
+    """(decode status, in G2 by the psi test, in G2 by [r]Q == inf)"""
+    a, b = ctypes.c_int(), ctypes.c_int()
+    st = lib().cbls_sig_check(sig, ctypes.byref(a), ctypes.byref(b))
+    return st, bool(a.value), bool(b.value)
+
+
+def hash_to_g2(msg: bytes) -> bytes:
+    out = ctypes.create_string_buffer(96)
+    lib().cbls_hash_to_g2(msg, len(msg), out)
+    return out.raw
+
+
+def sk_to_pk(sk: int) -> bytes:
+    out = ctypes.create_string_buffer(48)
+    lib().cbls_sk_to_pk(sk.to_bytes(32, "big"), out)
+    return out.raw
+
+
+def sign(sk: int, msg: bytes) -> bytes:
+    out = ctypes.create_string_buffer(96)
+    lib().cbls_sign(sk.to_bytes(32, "big"), msg, len(msg), out)
+    return out.raw
+
+
+def pairing(p48: bytes, q96: bytes):
+    """e(P, Q)^3 as 12 canonical integers (c0.c0.c0, c0.c0.c1, c0.c1.c0, ...), or the decode status"""
+    out = ctypes.create_string_buffer(576)
+    st = lib().cbls_pairing(p48, q96, out)
+    if st:
+        return st
+    return [int.from_bytes(out.raw[48 * i:48 * i + 48], "big") for i in range(12)]

@@ -1,0 +1,81 @@
+"""SURVEY.md 8(d) config 2 at full size: B K = 1 tuples generated on the device, the 8-class fault cycle at i = 0 (mod 64)
+(ethereum_consensus_amd/synthetic.py bls_inject_faults), verified by ONE ecgpu_fast_aggregate_verify_batch call per
+pairing-kernel build.  The kernel build (ECGPU_TOWER) and the pairing path (ECGPU_PAIRING) are fixed per process, so every
+configuration runs in a process of its own against one prepared workload file:
+
+    prepare(n, path)   (in the test process)  workload + three independent expectations:
+        * statuses known by construction,
+        * oracle/bls12_381.py (pure Python) on a sample: every fault class twice, neighbours, random tuples,
+        * oracle/c/bls12_381.cpp (C++ restatement, all host threads) on the FULL vector.
+    python -m tests._bls_config2 run <path> <n_first> <tower 1|2|0=any> <lane|vm2|vm3|any>
+        verifies the first n_first tuples on the GPU and compares the whole status vector with all three.
+
+Test infrastructure (imports oracle/)."""
+import json
+import pickle
+import random
+import sys
+import time
+
+PATH_NAMES = {0: "none", 1: "lane", 2: "vm2", 3: "vm3"}
+
+
+def prepare(n: int, path: str, n_samples: int = 72) -> dict:
+    from ethereum_consensus_amd import bls, synthetic as syn
+    from oracle import bls12_381 as B
+    from oracle import cbls
+    skb = syn.bls_secret_keys(n)
+    msgs = syn.bls_messages(n)
+    pks = bytearray(bls.sk_to_pk_batch(skb))
+    sigs = bytearray(bls.sign_batch(skb, [msgs[32 * i:32 * i + 32] for i in range(n)]))
+    msgb = bytearray(msgs)
+    want, kind_of = syn.bls_inject_faults(pks, msgb, sigs, n)
+    pks, msgb, sigs = bytes(pks), bytes(msgb), bytes(sigs)
+    r = random.Random(2024)
+    sample = []
+    for k in range(8):
+        idx = [i for i in range(0, n, 64) if kind_of[i] == k]
+        sample += idx[:1] + idx[-1:]
+    sample += [1, n - 1] + r.sample(range(n), max(0, n_samples - len(sample) - 2))
+    t0 = time.time()
+    py = {i: B.fast_aggregate_verify([pks[48 * i:48 * i + 48]], msgb[32 * i:32 * i + 32], sigs[96 * i:96 * i + 96]) for i in sample}
+    t_py = time.time() - t0
+    t0 = time.time()
+    cpp = cbls.fast_aggregate_verify_batch_k1(pks, msgb, sigs)
+    t_cpp = time.time() - t0
+    w = {"n": n, "pks": pks, "msgs": msgb, "sigs": sigs, "want": bytes(want), "kind_of": bytes(kind_of), "py": py, "cpp": cpp}
+    with open(path, "wb") as f:
+        pickle.dump(w, f)
+    # the three expectations must agree among themselves before any kernel is judged by them
+    assert cpp == bytes(want), [i for i in range(n) if cpp[i] != want[i]][:8]
+    assert all(py[i] == want[i] for i in py)
+    return {"python_oracle_s": round(t_py, 1), "cpp_oracle_s": round(t_cpp, 1), "cpp_threads": cbls.host_threads(), "samples": len(sample)}
+
+
+def run(path: str, n_first: int, want_tower: int, want_path: str) -> int:
+    from ethereum_consensus_amd import _lib, bls
+    with open(path, "rb") as f:
+        w = pickle.load(f)
+    n = min(n_first, w["n"])
+    L = _lib.load(build_if_missing=False)
+    assert L.ecgpu_init(0) == 0, L.ecgpu_last_error()
+    t0 = time.time()
+    got = bls.fast_aggregate_verify_batch(w["pks"][:48 * n], None, w["msgs"][:32 * n], w["sigs"][:96 * n])
+    dt = time.time() - t0
+    tower, pth = L.ecgpu_bls_tower(), PATH_NAMES.get(L.ecgpu_bls_last_pairing_path(), "?")
+    bad = [i for i in range(n) if got[i] != w["want"][i]]
+    cbad = [i for i in range(n) if got[i] != w["cpp"][i]]
+    pbad = [(i, o, got[i]) for i, o in w["py"].items() if i < n and o != got[i]]
+    classes = sorted({w["kind_of"][i] for i in range(0, n, 64)})
+    out = {"n": n, "tower": tower, "path": pth, "verify_s": round(dt, 3), "mismatch_vs_construction": bad[:8], "mismatch_vs_cpp_oracle": cbad[:8],
+           "mismatch_vs_python_oracle": pbad[:8], "python_samples_checked": sum(1 for i in w["py"] if i < n), "fault_classes": classes}
+    ok = (not bad and not cbad and not pbad and (want_tower == 0 or tower == want_tower) and (want_path == "any" or pth == want_path)
+          and len(classes) == min(8, (n + 63) // 64))
+    out["ok"] = ok
+    print(json.dumps(out))
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    assert sys.argv[1] == "run"
+    sys.exit(run(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]))

@@ -168,7 +168,7 @@ def test_batch_4096_with_fault_injection(gpu):
             want[i] = B.BLST_VERIFY_FAIL
         elif kind == 2:  # signature outside the G2 subgroup
             sigs[96 * i:96 * i + 96] = off_g2
-            want[i] = B.BLST_POINT_NOT_IN_GROUP
+            want[i] = B.VERIFY_POINT_NOT_IN_GROUP
         elif kind == 3:  # public key outside the G1 subgroup
             pks[48 * i:48 * i + 48] = off_g1
             want[i] = B.BLST_POINT_NOT_IN_GROUP
@@ -381,3 +381,147 @@ print("compact-code kernels ok")
     env = dict(os.environ, ECGPU_TOWER="calls", ECGPU_PAIRING="lane")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "compact-code kernels ok" in out.stdout, out.stdout + out.stderr
+
+
+# ---- SURVEY.md 8(d) config 2 at full size, on every shipped build of the pairing kernels -----------------------------------
+@pytest.fixture(scope="module")
+def config2_workload(gpu, tmp_path_factory):
+    """65 536 K = 1 tuples with the 8-class fault cycle, plus the statuses by construction, the Python-oracle sample and the
+    C++-oracle FULL vector (tests/_bls_config2.py prepare); built once, verified by every kernel configuration below."""
+    from tests import _bls_config2
+    path = str(tmp_path_factory.mktemp("config2") / "workload.pkl")
+    info = _bls_config2.prepare(65536, path)
+    return path, info
+
+
+@pytest.mark.parametrize("tower,pairing,n,want_tower,want_path", [
+    ("sums", "lane", 65536, 1, "lane"),     # the default large-batch kernel on a healthy box: k_pairing on the sums-of-products tower
+    ("calls", "lane", 65536, 2, "lane"),    # the compact-code build chosen on boxes with slow instruction fetch: k_pairing_calls
+    ("sums", "vm2", 8192, 1, "vm2"),        # the Fp2 lane-group path of small batches
+])
+def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, tower, pairing, n, want_tower, want_path):
+    """The whole status vector of SURVEY.md 8(d) config 2 -- every fault class: wrong message, swapped key, signature outside
+    G2, key outside G1, bad flag bits, x >= p, key = infinity, signature = infinity -- from each pairing-kernel build, forced in
+    a subprocess (the build is chosen once per process), against (a) construction, (b) oracle/bls12_381.py on >= 64 sampled
+    tuples, (c) the C++ restatement on ALL tuples."""
+    import json
+    import os
+    import subprocess
+    import sys
+    path, info = config2_workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ECGPU_TOWER=tower, ECGPU_PAIRING=pairing, PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-m", "tests._bls_config2", "run", path, str(n), str(want_tower), want_path], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["n"] == n and res["python_samples_checked"] >= (64 if n == 65536 else 8), res
+
+
+def test_error_identity_of_the_two_ambiguous_blst_codes(gpu):
+    """crypto/bls.rs:69-76,119-131: a key outside G1 / an infinite key fails its CONVERSION -> Error::BLST; a signature outside
+    G2 and keys summing to infinity are found inside blst's verify call -> Error::InvalidSignature.  Same BLST_ERROR values
+    (3, 6), different Error variant: the statuses differ by ECGPU_IN_VERIFY and the host mirror raises the right class."""
+    from ethereum_consensus_amd import bls as M
+    from ethereum_consensus_amd import synthetic as syn
+    sk = 12345
+    pk = gpu.sk_to_pk_batch(sk_bytes(sk))
+    msg = S(b"errid", 0)
+    sig = gpu.sign_batch(sk_bytes(sk), [msg])
+    off_sig, off_pk = syn.off_subgroup_signature(0), syn.off_subgroup_public_key(0)
+    neg = B.g1_compress(B.g1_neg(B.g1_decompress(pk)[1]))
+    assert M.verify_signature_status(pk, msg, off_sig) == 0x43 == B.verify_signature(pk, msg, off_sig)
+    assert M.fast_aggregate_verify_status([pk, neg], msg, sig) == 0x46 == B.fast_aggregate_verify([pk, neg], msg, sig)
+    assert M.verify_signature_status(off_pk, msg, sig) == 3 and M.verify_signature_status(B.INFINITY_PUBLIC_KEY, msg, sig) == 6
+    for call, exc in ((lambda: M.verify_signature(pk, msg, off_sig), M.InvalidSignature),
+                      (lambda: M.fast_aggregate_verify([pk], msg, off_sig), M.InvalidSignature),
+                      (lambda: M.eth_fast_aggregate_verify([pk, neg], msg, sig), M.InvalidSignature),
+                      (lambda: M.fast_aggregate_verify([pk, neg], msg, sig), M.InvalidSignature),
+                      (lambda: M.aggregate_verify([pk], [msg], off_sig), M.InvalidSignature),
+                      (lambda: M.fast_aggregate_verify([], msg, sig), M.InvalidSignature),           # AGGR_TYPE_MISMATCH inside verify
+                      (lambda: M.verify_signature(off_pk, msg, sig), M.BLSTError),
+                      (lambda: M.verify_signature(B.INFINITY_PUBLIC_KEY, msg, sig), M.BLSTError),
+                      (lambda: M.fast_aggregate_verify([pk, off_pk], msg, sig), M.BLSTError),
+                      (lambda: M.verify_signature(pk, msg, bytes(96)), M.BLSTError),                  # undecodable signature
+                      (lambda: M.aggregate([sig, off_sig]), M.BLSTError),                             # aggregate maps to Error::BLST (:92)
+                      (lambda: M.aggregate([]), M.EmptyAggregate)):
+        with pytest.raises(exc) as e:
+            call()
+        assert type(e.value) is exc
+    with pytest.raises(M.BLSTError) as e:
+        M.verify_signature(off_pk, msg, sig)
+    assert str(e.value) == "point not in group" and e.value.code == 3
+
+
+def test_whole_block_signature_batch_at_block_shape(gpu):
+    """every verification of one block queued and verified in one pass -- 128 attestations x 400 keys
+    (phase0/block_processing.rs:752-761), the sync aggregate over ~95 % of 512 keys (altair/block_processing.rs:226-234,
+    eth_ variant), 16 single-key operations (proposer, randao, exits ...: signing.rs:40) with faults of several classes.
+    Per position the collector must return what the scalar call returns: checked against the C++ oracle on every tuple, the
+    Python oracle and the scalar GPU entry on a few, and the indexed (validated-key registry) form against the raw form."""
+    from ethereum_consensus_amd import bls as M
+    from ethereum_consensus_amd import synthetic as syn
+    from oracle import cbls
+    n_val = 4096
+    skb = syn.bls_secret_keys(n_val)
+    sks = [int.from_bytes(skb[32 * i:32 * i + 32], "big") for i in range(n_val)]
+    reg_keys = gpu.sk_to_pk_batch(skb)
+    key = lambda i: reg_keys[48 * i:48 * i + 48]
+    tuples = []  # (indices or None, keys, msg, sig, eth)
+    agg_sks, agg_msgs = [], []
+    members = [[(c * 31 + j * 7) % n_val for j in range(400)] for c in range(128)]
+    sync = [i for i in range(512) if i % 20 != 3]  # ~95 % participation of the first 512 validators
+    for c, idx in enumerate(members + [sync]):
+        agg_sks.append(sum(sks[i] for i in idx) % B.R)
+        agg_msgs.append(S(b"blk", c))
+    single = list(range(1000, 1016))
+    sigs = gpu.sign_batch(b"".join(sk_bytes(s) for s in agg_sks + [sks[i] for i in single]), agg_msgs + [S(b"op", i) for i in single])
+    sig = lambda t: sigs[96 * t:96 * t + 96]
+    for c, idx in enumerate(members):
+        tuples.append((idx, [key(i) for i in idx], agg_msgs[c], sig(c), 0))
+    tuples.append((sync, [key(i) for i in sync], agg_msgs[128], sig(128), 1))
+    for t, i in enumerate(single):
+        tuples.append(([i], [key(i)], S(b"op", i), sig(129 + t), 0))
+    # faults: wrong message, a member that did not sign, a key outside G1 mid-list (raw form only: the registry holds valid keys),
+    # a signature outside G2, an undecodable signature, a forged single-key operation
+    tuples[5] = (tuples[5][0], tuples[5][1], S(b"blk", 999), tuples[5][3], 0)
+    tuples[17] = (tuples[17][0][:-1] + [7], tuples[17][1][:-1] + [key(7)], tuples[17][2], tuples[17][3], 0)
+    tuples[40] = (tuples[40][0], tuples[40][1], tuples[40][2], syn.off_subgroup_signature(1), 0)
+    tuples[41] = (tuples[41][0], tuples[41][1], tuples[41][2], bytes(96), 0)
+    tuples[130] = (tuples[130][0], tuples[130][1], tuples[130][2], sig(131), 0)
+    # the eth_ rule and the empty key list
+    tuples.append(([], [], S(b"blk", 500), B.INFINITY_SIGNATURE, 1))
+    tuples.append(([], [], S(b"blk", 500), B.INFINITY_SIGNATURE, 0))
+    want = [cbls.fast_aggregate_verify(k, m, s, bool(e)) for _, k, m, s, e in tuples]
+    assert want[0] == 0 and want[5] == 5 and want[17] == 5 and want[40] == 0x43 and want[41] == 1 and want[128] == 0 and want[130] == 5
+    assert want[-2] == 0 and want[-1] == B.BLST_AGGR_TYPE_MISMATCH
+    batch = M.SignatureBatch()
+    for _, k, m, s, e in tuples:
+        batch.fast_aggregate_verify(k, m, s, eth=bool(e)) if len(k) != 1 else batch.verify_signature(k[0], m, s)
+    assert len(batch) == len(tuples)
+    got = batch.flush()
+    assert len(batch) == 0 and list(got) == want
+    # a key outside G1 in the middle of a raw list: its conversion error wins
+    bad = list(tuples[3][1])
+    bad[200] = syn.off_subgroup_public_key(0)
+    batch.fast_aggregate_verify(bad, tuples[3][2], tuples[3][3])
+    batch.verify_signature(tuples[129][1][0], tuples[129][2], tuples[129][3])
+    res = batch.results()
+    assert isinstance(res[0], M.BLSTError) and res[0].code == 3 and res[1] is None
+    # scalar entries and the Python oracle on a few positions
+    for p in (0, 5, 128, 130, len(tuples) - 2):
+        _, k, m, s, e = tuples[p]
+        assert gpu.fast_aggregate_verify_status(k, m, s, eth=bool(e)) == got[p]
+    for p in (129, 130, len(tuples) - 1):
+        _, k, m, s, e = tuples[p]
+        assert C.oracle_fav(k, m, s, e) == got[p]
+    # the same block through a validated-key registry (indices instead of key bytes)
+    reg = gpu.ValidatorKeyRegistry(n_val)
+    reg.set(0, reg_keys)
+    rb = M.SignatureBatch(reg)
+    for idx, k, m, s, e in tuples:
+        rb.fast_aggregate_verify_indexed(idx, m, s, eth=bool(e))
+    assert list(rb.flush()) == want
+    rb.close()
+    reg.close()
+    batch.close()

@@ -159,13 +159,16 @@ def test_edge_verdicts():
     u = B.hash_to_field_fp2(b"edge", B.DST, 2)[0]
     bad = B.g2_compress(B.iso3(B.map_to_curve_sswu(u)))
     assert B.sig_from_bytes(bad)[0] == 0
-    assert B.verify_signature(pk, b"m" * 32, bad) == B.BLST_POINT_NOT_IN_GROUP
-    assert B.aggregate([sig, bad])[0] == B.BLST_POINT_NOT_IN_GROUP
+    assert B.verify_signature(pk, b"m" * 32, bad) == B.VERIFY_POINT_NOT_IN_GROUP
+    assert B.error_variant(B.VERIFY_POINT_NOT_IN_GROUP) == "InvalidSignature"   # crypto/bls.rs:72-76
+    assert B.error_variant(B.BLST_POINT_NOT_IN_GROUP) == "BLST"                 # a key outside G1: crypto/bls.rs:69
+    assert B.aggregate([sig, bad])[0] == B.BLST_POINT_NOT_IN_GROUP              # aggregate maps it to Error::BLST (:92)
     # infinity signature: decodes, never verifies for a valid key
     assert B.verify_signature(pk, b"m" * 32, B.INFINITY_SIGNATURE) == B.BLST_VERIFY_FAIL
     # keys summing to infinity are rejected
     neg = B.g1_compress(B.g1_neg(B.g1_mul(B.G1, 7)))
-    assert B.fast_aggregate_verify([pk, neg], b"m" * 32, B.INFINITY_SIGNATURE) == B.BLST_PK_IS_INFINITY
+    assert B.fast_aggregate_verify([pk, neg], b"m" * 32, B.INFINITY_SIGNATURE) == B.VERIFY_PK_IS_INFINITY
+    assert B.error_variant(B.VERIFY_PK_IS_INFINITY) == "InvalidSignature" and B.error_variant(B.BLST_PK_IS_INFINITY) == "BLST"
     # error order: first bad key wins over a later one and over a bad signature
     assert B.fast_aggregate_verify([B.INFINITY_PUBLIC_KEY, bytes(48)], b"", bytes(96)) == B.BLST_PK_IS_INFINITY
     assert B.fast_aggregate_verify([pk, bytes(48)], b"", bytes(96)) == B.BLST_BAD_ENCODING

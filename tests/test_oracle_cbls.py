@@ -1,0 +1,71 @@
+"""The C++ restatement of the BLS path (oracle/c/bls12_381.cpp, CPU baseline + full-vector checker) against the pinned
+Python oracle (oracle/bls12_381.py) and the reference's own fixed vectors (crypto/bls.rs:530-544,
+bin/ec/validator/keystores.rs:240-249).  CPU only."""
+import random
+
+from ethereum_consensus_amd import synthetic as syn
+from oracle import bls12_381 as B
+from oracle import cbls
+from tests import _blscases as C
+
+
+def test_reference_fixed_vectors():
+    assert cbls.sk_to_pk(C.EIP2335_SK) == C.EIP2335_PK
+    assert cbls.sign(C.CAN_SIGN_SK, C.CAN_SIGN_MSG) == C.CAN_SIGN_SIG  # hash-to-G2 with the ETH DST, scalar mult, compression
+    pk = cbls.sk_to_pk(C.CAN_SIGN_SK)
+    assert pk == B.sk_to_pk(C.CAN_SIGN_SK)
+    assert cbls.fast_aggregate_verify([pk], C.CAN_SIGN_MSG, C.CAN_SIGN_SIG) == 0
+    assert cbls.fast_aggregate_verify([pk], C.CAN_SIGN_MSG + b"x", C.CAN_SIGN_SIG) == B.BLST_VERIFY_FAIL
+
+
+def test_hash_to_g2_and_pairing_values_equal_the_python_oracle():
+    r = random.Random(3)
+    for n in (0, 1, 20, 32, 33, 100):
+        m = r.randbytes(n)
+        assert cbls.hash_to_g2(m) == B.g2_compress(B.hash_to_g2(m)), n
+    # the pairing VALUE after the final exponentiation (cubed: both use the exponent 3 (p^12 - 1) / r) -- pins the Jacobian
+    # Miller steps, the sparse line product, the cyclotomic squarings and the Frobenius constants
+    for _ in range(2):
+        a, b = r.randrange(1, B.R), r.randrange(1, B.R)
+        P1, Q = B.g1_mul(B.G1, a), B.g2_mul((B.G2_X, B.G2_Y), b)
+        want = B.pairing(P1, Q)
+        flat = [c for f6 in want for f2 in f6 for c in f2]
+        assert cbls.pairing(B.g1_compress(P1), B.g2_compress(Q)) == flat
+    # bilinearity through the C++ path alone
+    P1, Q = B.g1_mul(B.G1, 6), (B.G2_X, B.G2_Y)
+    assert cbls.pairing(B.g1_compress(P1), B.g2_compress(Q)) == cbls.pairing(B.g1_compress(B.g1_mul(B.G1, 2)), B.g2_compress(B.g2_mul(Q, 3)))
+
+
+def test_decoding_and_group_checks_equal_the_python_oracle():
+    r = random.Random(4)
+    for enc in C.malformed_g1(r) + [syn.off_subgroup_public_key(i) for i in range(3)] + [B.sk_to_pk(5)]:
+        assert cbls.key_validate(enc) == B.key_validate(enc)[0], enc.hex()
+    sigs = C.malformed_g2(r) + [syn.off_subgroup_signature(i) for i in range(3)] + [B.sign(7, b"m"), B.g2_compress(C.rand_g2_curve_point(r))]
+    for enc in sigs:
+        st, pt = B.sig_from_bytes(enc)
+        cst, fast, by_def = cbls.sig_check(enc)
+        assert cst == st, enc.hex()
+        if st == 0:
+            want = pt is None or B.g2_in_subgroup(pt)
+            assert fast == want and by_def == want, enc.hex()  # psi test == [r]Q == inf == the Python verdict
+
+
+def test_status_algebra_equals_the_python_oracle():
+    for pks, msg, sig, eth in C.fav_cases():
+        assert cbls.fast_aggregate_verify(pks, msg, sig, bool(eth)) == C.oracle_fav(pks, msg, sig, eth), (len(pks), eth)
+
+
+def test_config2_fault_cycle_batch_threads():
+    """1024 K = 1 tuples with the 8-class fault cycle of SURVEY.md 8(d) config 2: threaded batch == construction, and the
+    faulted tuples == the Python oracle."""
+    n = 1024
+    skb = syn.bls_secret_keys(n)
+    msgs = bytearray(syn.bls_messages(n))
+    pks = bytearray(b"".join(cbls.sk_to_pk(int.from_bytes(skb[32 * i:32 * i + 32], "big")) for i in range(n)))
+    sigs = bytearray(b"".join(cbls.sign(int.from_bytes(skb[32 * i:32 * i + 32], "big"), bytes(msgs[32 * i:32 * i + 32])) for i in range(n)))
+    want, kind_of = syn.bls_inject_faults(pks, msgs, sigs, n)
+    got = cbls.fast_aggregate_verify_batch_k1(bytes(pks), bytes(msgs), bytes(sigs))
+    assert got == bytes(want)
+    assert sorted({k for k in kind_of if k != 255}) == list(range(8))
+    for i in list(range(0, n, 64))[:8] + [1, 65]:
+        assert B.fast_aggregate_verify([bytes(pks[48 * i:48 * i + 48])], bytes(msgs[32 * i:32 * i + 32]), bytes(sigs[96 * i:96 * i + 96])) == got[i]
