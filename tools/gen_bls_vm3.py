@@ -37,7 +37,7 @@ G1_Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC74
 
 LIMIT = 600   # sum over the terms of bound(a) * bound(b), in units of p^2; the Montgomery reduction needs < R / p = 632
 MAXN = 7      # products per sum (descriptor: dst + 7 + 7 register numbers)
-MAXDER = 3    # derived outputs per lane per round
+MAXDER = 4    # derived outputs per lane per round
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -149,6 +149,12 @@ class Trace:
         re, im = [], []
         if t[0] == "mul":
             _, x, y = t
+            # a scalar multiple moves to a constant operand for free (constants' forms are more constants)
+            for _ in range(2):
+                if self.pairs[y.pid]["kind"] == "const" and x.m[0][1] == 0 and x.m[1][0] == 0 and x.m[0][0] == x.m[1][1] and x.m[0][0] not in (0, 1):
+                    c = x.m[0][0]
+                    x, y = V(x.pid), y.scale(c)
+                x, y = y, x
             # the minus sign of i^2 goes to whichever side needs fewer new forms
             neg_x1 = tuple(-a for a in x.m[1])
             neg_y1 = tuple(-a for a in y.m[1])
@@ -162,13 +168,21 @@ class Trace:
                 re.append((x1, self.row(y, 1, -1)))
             im.append((x0, y1))
             im.append((x1, y0))
-        elif t[0] == "sqr":
-            _, x = t
+        elif t[0] == "sqr":  # c X^2 = c (x0 + x1)(x0 - x1) + (2 c x0 x1) i; the factor c rides on the first operand of each product
+            x, c = t[1], (t[2] if len(t) > 2 else 1)
             r0, r1 = x.m
-            s = tuple(a + b for a, b in zip(r0, r1))
+            s = tuple(c * (a + b) for a, b in zip(r0, r1))
             d = tuple(a - b for a, b in zip(r0, r1))
             re.append((self.form(x.pid, s), self.form(x.pid, d)))
-            im.append((self.form(x.pid, tuple(2 * a for a in r0)), self.form(x.pid, r1)))
+            im.append((self.form(x.pid, tuple(2 * c * a for a in r0)), self.form(x.pid, r1)))
+        elif t[0] == "sqrxi":  # c xi X^2 = c (R - I) + c (R + I) i with R = (x0 + x1)(x0 - x1), I = 2 x0 x1
+            x, c = t[1], (t[2] if len(t) > 2 else 1)
+            r0, r1 = x.m
+            s = self.form(x.pid, tuple(c * (a + b) for a, b in zip(r0, r1)))
+            d = self.form(x.pid, tuple(a - b for a, b in zip(r0, r1)))
+            x1 = self.form(x.pid, r1)
+            re += [(s, d), (self.form(x.pid, tuple(-2 * c * a for a in r0)), x1)]
+            im += [(s, d), (self.form(x.pid, tuple(2 * c * a for a in r0)), x1)]
         else:
             _, x, k = t
             re.append((self.row(x, 0), k))
@@ -226,25 +240,23 @@ def f12_mul(f, g):
 
 
 def f12_sqr(f):
+    """f^2 with every cross product taken once (doubled through the operand) and the squares as two products each; absent
+    (zero) coefficients of f -- the first steps of the Miller loop -- are skipped"""
     out = []
     for k in range(6):
         terms = []
         for i in range(6):
             j = (k - i) % 6
-            if i > j:
+            if i > j or f[i] is None or f[j] is None:
                 continue
             wrap = i + j >= 6
             if i == j:
-                terms.append(("sqr", f[i].xi()) if False else ("sqrxi", f[i]) if wrap else ("sqr", f[i]))
+                terms.append(("sqrxi", f[i]) if wrap else ("sqr", f[i]))
             else:
                 x = f[i].scale(2)
                 terms.append(("mul", x.xi() if wrap else x, f[j]))
-        out.append(T.sum([_sqrxi(t) for t in terms], "f12sqr"))
+        out.append(T.sum(terms, "f12sqr") if terms else None)
     return out
-
-
-def _sqrxi(t):
-    return t
 
 
 def f12_mul_by_line(f, l0, l1, l2):
@@ -254,13 +266,17 @@ def f12_mul_by_line(f, l0, l1, l2):
         terms = []
         for shift, l in ((0, l0), (2, l1), (3, l2)):
             i = (k - shift) % 6
-            terms.append(("mul", f[i].xi() if i + shift >= 6 else f[i], l))
+            terms.append(("mul", l.xi() if i + shift >= 6 else l, f[i]))  # the forms go to the 3 line coefficients, f stays plain
         out.append(T.sum(terms, "line"))
     return out
 
 
 def f12_conj(f):
     return [f[k].neg() if k & 1 else f[k] for k in range(6)]
+
+
+def f12_sqr_full(f):
+    return f12_sqr(f)
 
 
 FROB_GAMMA_INT = [i2_pow((1, 1), k * (P - 1) // 6) for k in range(6)]
@@ -312,7 +328,7 @@ def f12_inv(f):
             ts.append(("mul", xx, b[j]))
         n.append(T.sum(ts, "inv_n"))
     c0 = T.sum([("sqr", n[0]), ("mul", n[1].xi().neg(), n[2])], "inv_c0")
-    c1 = T.sum([("sqr", n[2].xi()) if False else ("mul", n[2].xi(), n[2]), ("mul", n[0].neg(), n[1])], "inv_c1")
+    c1 = T.sum([("sqrxi", n[2]), ("mul", n[0].neg(), n[1])], "inv_c1")
     c2 = T.sum([("sqr", n[1]), ("mul", n[0].neg(), n[2])], "inv_c2")
     t = T.sum([("mul", n[0], c0), ("mul", n[2].xi(), c1), ("mul", n[1].xi(), c2)], "inv_t")
     tc = T.pairs[t.pid]["c"]
@@ -336,8 +352,8 @@ def f12_cyclotomic_sqr(f):
     z0, z4, z3, z2, z1, z5 = f[0], f[2], f[4], f[1], f[3], f[5]
     one = T.one
 
-    def t0_terms(a, b):  # 3 (a^2 + xi b^2): the factor 3 rides on one factor of each square
-        return [("mul", a.scale(3), a), ("mul", b.scale(3).xi(), b)]
+    def t0_terms(a, b):  # 3 (a^2 + xi b^2)
+        return [("sqr", a, 3), ("sqrxi", b, 3)]
 
     def t1_terms(a, b, xi=False):  # 3 * 2 a b
         x = a.scale(6)
@@ -423,7 +439,6 @@ def miller_loop(pairs):
         for k, (pxy, q) in enumerate(pairs):
             Ts[k], (l0, l1, l2) = miller_dbl_step(Ts[k], pxy)
             if f is None:
-                zero = None
                 f = [l0, None, l1, l2, None, None]
             else:
                 f = f12_mul_by_line_sparse(f, l0, l1, l2)
@@ -445,7 +460,7 @@ def f12_mul_by_line_sparse(f, l0, l1, l2):
             i = (k - shift) % 6
             if f[i] is None:
                 continue
-            terms.append(("mul", f[i].xi() if i + shift >= 6 else f[i], l))
+            terms.append(("mul", l.xi() if i + shift >= 6 else l, f[i]))
         out.append(T.sum(terms, "line0") if terms else None)
     return out
 
@@ -504,7 +519,7 @@ class Program:
 def round_cost(n, nder):
     """issue-cycle model of one round for one wave (measured, profiles/r02a_vm3probe.txt: ~7.2 cycles per multiply-add at
     two waves per SIMD, ~1900 for a round without products)"""
-    return 1500 + (169 * n + 182) * 7.2 + 260 * nder if n else 1900 + 260 * nder
+    return (169 * n + 182) * 7.2 + 260 * nder if n else 1900 + 260 * nder
 
 
 def build_ops(t, outputs):
@@ -588,8 +603,11 @@ def make_program(t, outputs, inputs, lanes, window):
         if not el:
             el = list(ready)
         el.sort(key=lambda i: -prio[i])
-        ncls = ops[el[0]]["n"]
-        take = [i for i in el if ops[i]["n"] <= ncls and (ops[i]["n"] > 0) == (ncls > 0)][:slots]
+        # the class of the round: the largest N among the `slots` most urgent ready ops of the leader's kind (sum / derive)
+        lead_sum = ops[el[0]]["n"] > 0
+        same = [i for i in el if (ops[i]["n"] > 0) == lead_sum]
+        ncls = max(ops[i]["n"] for i in same[:slots])
+        take = [i for i in same if ops[i]["n"] <= ncls][:slots]
         # a cheaper class that still holds the same ops?  (all taken ops smaller than the leader's class)
         ncls = max(ops[i]["n"] for i in take)
         rounds.append((ncls, take))
@@ -686,8 +704,7 @@ def make_program(t, outputs, inputs, lanes, window):
 # descriptor of one lane in one round: 8 dwords
 #   w0: dst | a0 << 8 | a1 << 16 | a2 << 24     w1: a3 | a4 << 8 | a5 << 16 | a6 << 24
 #   w2: b0 | b1 << 8 | b2 << 16 | b3 << 24      w3: b4 | b5 << 8 | b6 << 16
-#   w4 + d: derived output d: reg | (c_own & 255) << 8 | (c_partner & 255) << 16 | K << 24      (reg 0 = none)
-#   w7: unused
+#   w4 + d (d < 4): derived output d: reg | (c_own & 255) << 8 | (c_partner & 255) << 16 | K << 24      (reg 0 = none)
 # round header: N | nder << 8 (nder = the largest number of derived outputs of any lane of the round)
 def encode(pr):
     assert pr.nreg <= 256, pr.nreg
@@ -738,7 +755,7 @@ def simulate(pr, words, hdr, inputs):
             w = words[(rd * L + k) * 8:(rd * L + k) * 8 + 8]
             if n:
                 writes.append((w[0] & 255, own[k]))
-            for d in range(3):
+            for d in range(4):
                 x = w[4 + d]
                 if x & 255:
                     writes.append((x & 255, (sgn(x >> 8 & 255) * own[k] + sgn(x >> 16 & 255) * own[k ^ 1]) % P))
