@@ -57,6 +57,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_htr_beacon_state_deneb": (c_int, [u8p, c_u64, c_int, u8p]),
         "ecgpu_htr_beacon_state_deneb_dev": (c_int, [u8p, c_u64, u8p, c_int, u8p, ctypes.c_void_p]),
         "ecgpu_beacon_state_deneb_fixed_size": (c_u64, [c_int]),
+        "ecgpu_htr_beacon_state": (c_int, [c_int, u8p, c_u64, c_int, u8p]),
+        "ecgpu_htr_beacon_state_dev": (c_int, [c_int, u8p, c_u64, u8p, c_int, u8p, ctypes.c_void_p]),
+        "ecgpu_beacon_state_fixed_size": (c_u64, [c_int, c_int]),
+        "ecgpu_resident_state_create_fork": (c_int, [c_int, c_int, u8p, c_u64, ctypes.POINTER(ctypes.c_void_p)]),
         "ecgpu_last_hash64_count": (c_u64, []),
         "ecgpu_resident_state_create": (c_int, [c_int, u8p, c_u64, ctypes.POINTER(ctypes.c_void_p)]),
         "ecgpu_resident_state_destroy": (None, [ctypes.c_void_p]),
@@ -66,6 +70,12 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_compute_shuffled_indices": (c_int, [ctypes.c_void_p, c_u64, u8p, c_u32, ctypes.c_void_p]),
         "ecgpu_compute_shuffled_indices_dev": (c_int, [ctypes.c_void_p, c_u64, u8p, c_u32, ctypes.c_void_p, ctypes.c_void_p]),
         "ecgpu_htr_ssz": (c_int, [ctypes.c_void_p, c_u32, ctypes.c_void_p, c_u32, c_u32, u8p, c_u64, u8p]),
+        "ecgpu_ssz_generalized_index": (c_int, [ctypes.c_void_p, c_u32, ctypes.c_void_p, c_u32, c_u32, ctypes.c_void_p, c_u32,
+                                                ctypes.POINTER(c_u64)]),
+        "ecgpu_ssz_prove": (c_int, [ctypes.c_void_p, c_u32, ctypes.c_void_p, c_u32, c_u32, u8p, c_u64, ctypes.c_void_p, c_u32, u8p, u8p,
+                                    c_u32, ctypes.POINTER(c_u32), ctypes.POINTER(c_u64), u8p]),
+        "ecgpu_merkle_proof": (c_int, [u8p, c_u64, c_u64, c_u64, u8p]),
+        "ecgpu_beacon_state_field_roots": (c_int, [c_int, u8p, c_u64, c_int, u8p, c_u32, ctypes.POINTER(c_u32), u8p]),
         "ecgpu_verify": (c_int, [u8p, u8p, c_size, u8p]),
         "ecgpu_fast_aggregate_verify": (c_int, [u8p, c_u32, u8p, c_size, u8p, c_int]),
         "ecgpu_aggregate_verify": (c_int, [u8p, c_u32, u8p, ctypes.c_void_p, c_u32, u8p]),

@@ -1,4 +1,5 @@
-// hash_tree_root(BeaconState) for the deneb fork, driven from the state's SSZ encoding
+// hash_tree_root(BeaconState) for every fork the reference defines up to deneb (phase0 .. deneb; the file keeps its first
+// name), driven from the state's SSZ encoding
 // (plan: state_plan.h).  The host only walks SSZ offsets and emits descriptors; every hash64
 // runs on the GPU.  Big fields go through the pass kernels straight from the device-resident
 // encoding (read once); the ~60 small chunks are gathered into one staging buffer and reduced
@@ -17,9 +18,10 @@ namespace ecg {
 // current by the caller, so the registry enters the tree as a list of 2^20 ready chunks (1.0 M hash64) instead of 121-byte
 // records (9.4 M).
 static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, const u8* h_fixed,
-                             int preset, u8* d_root, const u8* d_vroots = nullptr) {
+                             int preset, u8* d_root, const u8* d_vroots = nullptr, int fork = FORK_DENEB, const u8* ext_roots = nullptr,
+                             const u8* h_payload_fixed = nullptr, u8* d_field_roots = nullptr) {
     StatePlan plan;
-    if (!build_state_plan_deneb(h_fixed, n_bytes, preset, plan)) {
+    if (!build_state_plan(fork, h_fixed, n_bytes, preset, plan, ext_roots, h_payload_fixed)) {
         set_last_error(plan.error);
         return ECGPU_ERR_BAD_ARG;
     }
@@ -53,6 +55,8 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     ECG_HIP_CHECK(hipMemsetAsync(d_small, 0, small_bytes, s));
     rc = launch_gather(s, d_ssz, n_bytes, d_gath, (u32)plan.gathers.size(), d_small);
     if (rc) return rc;
+    for (const StatePlan::ExtChunk& e : plan.ext_chunks)  // phase0: roots computed by the generic planner (pageable copy: staged before return)
+        ECG_HIP_CHECK(hipMemcpyAsync(d_small + 32ull * e.dst_chunk, ext_roots + e.src_off, 32, hipMemcpyHostToDevice, s));
     u64 hc = plan.small_hashes;
     // The 14 big fields are independent trees and so are the leaf-container jobs; only the nested containers
     // and the 28-field state container wait for them.  The validator registry (93 % of the hashes) runs on the
@@ -148,6 +152,8 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     rc = launch_tree_jobs(s, d_jobs + level_start[2], (u32)(level_start[3] - level_start[2]), ar.base);
     if (rc) return rc;
     ECG_HIP_CHECK(hipMemcpyAsync(d_root, d_small + 32ull * plan.root_chunk, 32, hipMemcpyDeviceToDevice, s));
+    if (d_field_roots)  // chunks 0 .. 31 of the small buffer are the roots of the state's fields (proofs: ssz_proof.hip)
+        ECG_HIP_CHECK(hipMemcpyAsync(d_field_roots, d_small, 32ull * 32, hipMemcpyDeviceToDevice, s));
     c->last_hash64 = hc;
     return ECGPU_SUCCESS;
 }
@@ -174,6 +180,7 @@ __global__ void k_apply_patches(u8* state, const u8* data, const PatchDesc* p) {
 
 struct ecgpu_resident_state {
     int preset = 0;
+    int fork = ecg::FORK_DENEB;
     u8* d_ssz = nullptr;   // encoding + 64 bytes of slack + the root
     u64 n_bytes = 0;
     std::vector<u8> h_fixed;  // host mirror of the fixed-size part (offsets and small fields): what the plan reads
@@ -183,6 +190,11 @@ struct ecgpu_resident_state {
     u64 vals_off = 0, n_vals = 0;       // byte offset / count of the validator records in the encoding
     std::vector<u32> dirty;             // records whose cached root is stale (deduplicated at the next root)
     bool all_dirty = true;
+    // device copy of the dirty list: owned by the state (one state must not be used from two threads / streams at once,
+    // include/ecgpu.h), double-buffered so that a root enqueued on a stream never overwrites the list of the previous one
+    u32* d_idx[2] = {nullptr, nullptr};
+    size_t d_idx_cap[2] = {0, 0};
+    int d_idx_turn = 0;
 };
 
 using namespace ecg;
@@ -190,18 +202,26 @@ using namespace ecg;
 extern "C" {
 
 int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out) {
+    return ecgpu_resident_state_create_fork(ECGPU_FORK_DENEB, preset, ssz, n_bytes, out);
+}
+
+int ecgpu_resident_state_create_fork(int fork, int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (!ssz || !out || preset < 0 || preset > 1 || n_bytes < layout_for(STATE_PRESETS[preset]).size) return ECGPU_ERR_BAD_ARG;
+    if (!ssz || !out || preset < 0 || preset > 1 || fork < FORK_ALTAIR || fork > FORK_DENEB ||
+        n_bytes < layout_for(STATE_PRESETS[preset], fork).size)
+        return ECGPU_ERR_BAD_ARG;  // phase0 states hold lists of variable-size elements: host entry only
     StatePlan plan;
-    if (!build_state_plan_deneb(ssz, n_bytes, preset, plan)) {
+    if (!build_state_plan(fork, ssz, n_bytes, preset, plan, nullptr,
+                          fork >= FORK_BELLATRIX ? ssz + rd32(ssz + layout_for(STATE_PRESETS[preset], fork).payload_header_off) : nullptr)) {
         set_last_error(plan.error);
         return ECGPU_ERR_BAD_ARG;
     }
     ecgpu_resident_state* st = new ecgpu_resident_state();
     st->preset = preset;
+    st->fork = fork;
     st->n_bytes = n_bytes;
-    st->h_fixed.assign(ssz, ssz + layout_for(STATE_PRESETS[preset]).size);
+    st->h_fixed.assign(ssz, ssz + layout_for(STATE_PRESETS[preset], fork).size);
     ECG_HIP_CHECK(hipMalloc((void**)&st->d_ssz, n_bytes + 128));
     ECG_HIP_CHECK(hipMemcpy(st->d_ssz, ssz, n_bytes, hipMemcpyHostToDevice));
     for (const BigField& b : plan.bigs)
@@ -219,6 +239,8 @@ void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st) {
     (void)hipDeviceSynchronize();
     (void)hipFree(st->d_ssz);
     (void)hipFree(st->d_vroots);
+    (void)hipFree(st->d_idx[0]);
+    (void)hipFree(st->d_idx[1]);
     delete st;
 }
 
@@ -239,12 +261,25 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
         descs[i] = {offsets[i], data_off[i], len};
     }
     // the variable-size lists keep their lengths: a patch must not rewrite the offset words of the fixed part
-    const FixedLayout L = layout_for(STATE_PRESETS[st->preset]);
-    const u64 off_words[9] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off, L.prev_participation_off,
-                              L.cur_participation_off, L.inactivity_scores_off, L.payload_header_off, L.historical_summaries_off};
+    const FixedLayout L = layout_for(STATE_PRESETS[st->preset], st->fork);
+    u64 off_words[10] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off, L.prev_participation_off,
+                         L.cur_participation_off, L.inactivity_scores_off, L.payload_header_off, L.historical_summaries_off, NO_FIELD};
+    // ... and the one offset word INSIDE the payload header (extra_data): the reference's deserializer rejects any other value
+    if (L.payload_header_off != NO_FIELD) off_words[9] = rd32(st->h_fixed.data() + L.payload_header_off) + PAYLOAD_EXTRA_DATA_OFFSET_WORD;
     for (u32 i = 0; i < n; i++)
         for (u64 w : off_words)
-            if (descs[i].dst_off < w + 4 && descs[i].dst_off + descs[i].len > w) {
+            if (w != NO_FIELD && descs[i].dst_off < w + 4 && descs[i].dst_off + descs[i].len > w) {
+                if (w >= st->h_fixed.size()) {  // the payload header's word: must stay == its fixed size
+                    const u64 want = payload_header_fixed(st->fork);
+                    bool same_w = true;
+                    for (u64 b = (descs[i].dst_off > w ? descs[i].dst_off : w); b < w + 4 && b < descs[i].dst_off + descs[i].len; b++)
+                        same_w = same_w && data[descs[i].src_off + (b - descs[i].dst_off)] == (u8)(want >> (8 * (b - w)));
+                    if (!same_w) {
+                        set_last_error("a patch may not change the extra_data offset of the payload header");
+                        return ECGPU_ERR_BAD_ARG;
+                    }
+                    continue;
+                }
                 bool same = true;
                 for (u64 b = (descs[i].dst_off > w ? descs[i].dst_off : w); b < w + 4 && b < descs[i].dst_off + descs[i].len; b++)
                     same = same && data[descs[i].src_off + (b - descs[i].dst_off)] == st->h_fixed[b];
@@ -301,12 +336,13 @@ static int refresh_validator_roots(ecgpu_resident_state* st, hipStream_t s, Thre
     if (st->dirty.empty()) return ECGPU_SUCCESS;
     std::sort(st->dirty.begin(), st->dirty.end());
     st->dirty.erase(std::unique(st->dirty.begin(), st->dirty.end()), st->dirty.end());
-    // the index list travels through an allocation of its own: the arena belongs to the root computation that follows
-    static thread_local u32* d_idx = nullptr;
-    static thread_local size_t d_idx_cap = 0;
+    // the index list travels through an allocation of the state's own: the arena belongs to the root computation that follows
+    const int turn = st->d_idx_turn ^= 1;
+    u32*& d_idx = st->d_idx[turn];
+    size_t& d_idx_cap = st->d_idx_cap[turn];
     if (st->dirty.size() > d_idx_cap) {
         if (d_idx) {
-            ECG_HIP_CHECK(hipStreamSynchronize(s));
+            ECG_HIP_CHECK(hipDeviceSynchronize());
             ECG_HIP_CHECK(hipFree(d_idx));
         }
         d_idx_cap = st->dirty.size() * 2 + 1024;
@@ -328,7 +364,7 @@ int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, e
     hipStream_t s = c->stream_or_own(stream);
     rc = refresh_validator_roots(st, s, c);
     if (rc) return rc;
-    return state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots);
+    return state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots, st->fork);
 }
 
 int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
@@ -340,8 +376,108 @@ int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
     u8* d_root = st->d_ssz + ((st->n_bytes + 31) / 32) * 32 + 32;
     rc = refresh_validator_roots(st, s, c);
     if (rc) return rc;
-    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots);
+    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots, st->fork);
     if (rc) return rc;
+    ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ECGPU_SUCCESS;
+}
+
+uint64_t ecgpu_beacon_state_fixed_size(int fork, int preset) {
+    if (preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_DENEB) return 0;
+    return layout_for(STATE_PRESETS[preset], fork).size;
+}
+
+int ecgpu_htr_beacon_state_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset, uint8_t* d_root,
+                               ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!d_ssz || !h_fixed || !d_root || fork < FORK_ALTAIR || fork > FORK_DENEB) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(stream);
+    return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork);
+}
+
+// List<PendingAttestation<MAX_VALIDATORS_PER_COMMITTEE>, MAX_ATTESTATIONS * SLOTS_PER_EPOCH> (phase0/operations.rs:45-52,
+// phase0/presets/*.rs:84) for the generic planner
+static int pending_attestations_root(const u8* ssz, u64 n_bytes, int preset, u8 root[32]) {
+    static const uint32_t fields[] = {0, 1,           // Checkpoint: epoch, root
+                                      0, 0, 1, 2, 2,  // AttestationData: slot, index, beacon_block_root, source, target
+                                      4, 3, 0, 0};    // PendingAttestation: aggregation_bits, data, inclusion_delay, proposer_index
+    const ecgpu_ssz_type types[7] = {{ECGPU_SSZ_UINT, 0, 8, 0, 0},          {ECGPU_SSZ_BYTEVECTOR, 0, 32, 0, 0},
+                                     {ECGPU_SSZ_CONTAINER, 0, 0, 2, 0},     {ECGPU_SSZ_CONTAINER, 0, 0, 5, 2},
+                                     {ECGPU_SSZ_BITLIST, 0, 2048, 0, 0},    {ECGPU_SSZ_CONTAINER, 0, 0, 4, 7},
+                                     {ECGPU_SSZ_LIST, 5, preset == 0 ? 4096ull : 1024ull, 0, 0}};
+    return ecgpu_htr_ssz(types, 7, fields, 11, 6, ssz, n_bytes, root);
+}
+
+static int beacon_state_host(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32], uint8_t* field_roots);
+
+int ecgpu_htr_beacon_state(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32]) {
+    return beacon_state_host(fork, ssz, n_bytes, preset, root, nullptr);
+}
+
+int ecgpu_beacon_state_field_roots(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t* roots, uint32_t capacity,
+                                   uint32_t* n_fields, uint8_t root[32]) {
+    if (!roots || !n_fields || !root || fork < FORK_PHASE0 || fork > FORK_DENEB || capacity < state_field_count(fork)) return ECGPU_ERR_BAD_ARG;
+    u8 all[32 * 32];
+    int rc = beacon_state_host(fork, ssz, n_bytes, preset, root, all);
+    if (rc) return rc;
+    *n_fields = state_field_count(fork);
+    std::memcpy(roots, all, 32ull * *n_fields);
+    return ECGPU_SUCCESS;
+}
+
+static int beacon_state_host(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32], uint8_t* field_roots) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!ssz || !root) return ECGPU_ERR_BAD_ARG;
+    if (preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_DENEB || n_bytes < layout_for(STATE_PRESETS[preset], fork).size) {
+        set_last_error("bad fork / preset or truncated state");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    const FixedLayout L = layout_for(STATE_PRESETS[preset], fork);
+    u8 ext[64];
+    if (fork == FORK_PHASE0) {
+        // the two lists of variable-size elements go through the generic planner first (their encodings are on the host here)
+        const u64 a = rd32(ssz + L.prev_attestations_off), b = rd32(ssz + L.cur_attestations_off);
+        if (a > b || b > n_bytes) {
+            set_last_error("SSZ offsets not monotonic");
+            return ECGPU_ERR_BAD_ARG;
+        }
+        if ((rc = pending_attestations_root(ssz + a, b - a, preset, ext))) return rc;
+        if ((rc = pending_attestations_root(ssz + b, n_bytes - b, preset, ext + 32))) return rc;
+    }
+    const u8* h_payload = nullptr;
+    if (fork >= FORK_BELLATRIX) {
+        const u64 h = rd32(ssz + L.payload_header_off);
+        if (h > n_bytes || n_bytes - h < payload_header_fixed(fork)) {
+            set_last_error("payload header outside the encoding");
+            return ECGPU_ERR_BAD_ARG;
+        }
+        h_payload = ssz + h;
+    }
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    // the encoding lives in its own allocation (the arena is rebuilt by the driver)
+    static thread_local u8* d_state = nullptr;
+    static thread_local size_t d_state_cap = 0;
+    if (n_bytes + 64 > d_state_cap) {
+        if (d_state) {
+            ECG_HIP_CHECK(hipStreamSynchronize(s));
+            ECG_HIP_CHECK(hipFree(d_state));
+            d_state = nullptr;
+            d_state_cap = 0;
+        }
+        ECG_HIP_CHECK(hipMalloc((void**)&d_state, n_bytes + 2048 + (n_bytes >> 3)));
+        d_state_cap = n_bytes + 64 + (n_bytes >> 3);
+    }
+    ECG_HIP_CHECK(hipMemcpyAsync(d_state, ssz, n_bytes, hipMemcpyHostToDevice, s));
+    u8* d_root = d_state + ((n_bytes + 31) / 32) * 32;
+    rc = state_root_device(s, c, d_state, n_bytes, ssz, preset, d_root, nullptr, fork, fork == FORK_PHASE0 ? ext : nullptr, h_payload,
+                           field_roots ? d_root + 32 : nullptr);
+    if (rc) return rc;
+    if (field_roots) ECG_HIP_CHECK(hipMemcpyAsync(field_roots, d_root + 32, 32 * 32, hipMemcpyDeviceToHost, s));
     ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
     ECG_HIP_CHECK(hipStreamSynchronize(s));
     return ECGPU_SUCCESS;
@@ -363,35 +499,7 @@ int ecgpu_htr_beacon_state_deneb_dev(const uint8_t* d_ssz, uint64_t n_bytes, con
 }
 
 int ecgpu_htr_beacon_state_deneb(const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32]) {
-    int rc = ensure_init();
-    if (rc) return rc;
-    if (!ssz || !root) return ECGPU_ERR_BAD_ARG;
-    if (preset < 0 || preset > 1 || n_bytes < layout_for(STATE_PRESETS[preset]).size) {
-        set_last_error("bad preset or truncated state");
-        return ECGPU_ERR_BAD_ARG;
-    }
-    ThreadCtx* c = tctx();
-    hipStream_t s = c->stream_or_own(nullptr);
-    // the encoding lives in its own allocation (the arena is rebuilt by the driver)
-    static thread_local u8* d_state = nullptr;
-    static thread_local size_t d_state_cap = 0;
-    if (n_bytes + 64 > d_state_cap) {
-        if (d_state) {
-            ECG_HIP_CHECK(hipStreamSynchronize(s));
-            ECG_HIP_CHECK(hipFree(d_state));
-            d_state = nullptr;
-            d_state_cap = 0;
-        }
-        ECG_HIP_CHECK(hipMalloc((void**)&d_state, n_bytes + 64 + (n_bytes >> 3)));
-        d_state_cap = n_bytes + 64 + (n_bytes >> 3);
-    }
-    ECG_HIP_CHECK(hipMemcpyAsync(d_state, ssz, n_bytes, hipMemcpyHostToDevice, s));
-    u8* d_root = d_state + ((n_bytes + 31) / 32) * 32;
-    rc = state_root_device(s, c, d_state, n_bytes, ssz, preset, d_root);
-    if (rc) return rc;
-    ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
-    ECG_HIP_CHECK(hipStreamSynchronize(s));
-    return ECGPU_SUCCESS;
+    return ecgpu_htr_beacon_state(FORK_DENEB, ssz, n_bytes, preset, root);
 }
 
 }  // extern "C"

@@ -151,6 +151,11 @@ struct StatePlan {
     u32 n_small_chunks = 0;
     u32 root_chunk = 0;
     u64 small_hashes = 0;  // hash64 performed by the jobs
+    struct ExtChunk {
+        u32 dst_chunk, src_off;  // 32 bytes of the caller's ext_roots buffer -> this chunk (phase0 attestation-list roots)
+    };
+    std::vector<ExtChunk> ext_chunks;
+    u64 payload_header_off = ~0ull;  // byte offset of the payload header in the encoding (bellatrix+)
     std::string error;
 };
 
@@ -163,20 +168,37 @@ static const Preset STATE_PRESETS[2] = {
     {64, 1ull << 24, 32, 1ull << 40, 64, 64, 32},            // minimal
 };
 
-// byte offsets of the fields inside the fixed-size part of the encoding
+// The forks whose BeaconState this plan knows: phase0/beacon_state.rs:50-88 (21 fields),
+// altair/beacon_state.rs:13-55 (24), bellatrix/beacon_state.rs:13-58 (25: + latest_execution_payload_header),
+// capella/beacon_state.rs:13-64 (28: + withdrawal indices, historical_summaries), deneb/beacon_state.rs:13-64 (28).
+// Fields 0..14 are the same in every fork; altair replaced phase0's two PendingAttestation lists (fields 15, 16) by the
+// participation-flag lists and appended inactivity_scores and the sync committees; the payload header grew from 14 fields
+// (bellatrix/execution_payload.rs:58-81) to 15 (capella: + withdrawals_root) to 17 (deneb: + blob_gas_used, excess_blob_gas).
+enum StateFork : int { FORK_PHASE0 = 0, FORK_ALTAIR = 1, FORK_BELLATRIX = 2, FORK_CAPELLA = 3, FORK_DENEB = 4 };
+constexpr u64 NO_FIELD = ~0ull;
+
+inline u32 state_field_count(int fork) {
+    return fork == FORK_PHASE0 ? 21u : fork == FORK_ALTAIR ? 24u : fork == FORK_BELLATRIX ? 25u : 28u;
+}
+// fixed part of the fork's ExecutionPayloadHeader (the offset word of extra_data sits at byte 436 and must hold this value)
+inline u64 payload_header_fixed(int fork) { return fork == FORK_BELLATRIX ? 536 : fork == FORK_CAPELLA ? 568 : 584; }
+
+// byte offsets of the fields inside the fixed-size part of the encoding (NO_FIELD: the fork has no such field)
 struct FixedLayout {
     u64 genesis_time, genesis_validators_root, slot, fork, latest_block_header, block_roots, state_roots,
         historical_roots_off, eth1_data, eth1_data_votes_off, eth1_deposit_index, validators_off, balances_off,
         randao_mixes, slashings, prev_participation_off, cur_participation_off, justification_bits,
         prev_justified, cur_justified, finalized, inactivity_scores_off, current_sync_committee,
         next_sync_committee, payload_header_off, next_withdrawal_index, next_withdrawal_validator_index,
-        historical_summaries_off, size;
+        historical_summaries_off, prev_attestations_off, cur_attestations_off, size;
 };
 
-inline FixedLayout layout_for(const Preset& p) {
+inline FixedLayout layout_for(const Preset& p, int fork = FORK_DENEB) {
     FixedLayout L;
     u64 o = 0;
     auto take = [&](u64 n) { u64 r = o; o += n; return r; };
+    auto take_if = [&](bool have, u64 n) { return have ? take(n) : NO_FIELD; };
+    const bool altair = fork >= FORK_ALTAIR, bellatrix = fork >= FORK_BELLATRIX, capella = fork >= FORK_CAPELLA;
     L.genesis_time = take(8);
     L.genesis_validators_root = take(32);
     L.slot = take(8);
@@ -192,19 +214,21 @@ inline FixedLayout layout_for(const Preset& p) {
     L.balances_off = take(4);
     L.randao_mixes = take(32 * p.epochs_per_historical_vector);
     L.slashings = take(8 * p.epochs_per_slashings_vector);
-    L.prev_participation_off = take(4);
-    L.cur_participation_off = take(4);
+    L.prev_attestations_off = take_if(!altair, 4);
+    L.cur_attestations_off = take_if(!altair, 4);
+    L.prev_participation_off = take_if(altair, 4);
+    L.cur_participation_off = take_if(altair, 4);
     L.justification_bits = take(1);
     L.prev_justified = take(40);
     L.cur_justified = take(40);
     L.finalized = take(40);
-    L.inactivity_scores_off = take(4);
-    L.current_sync_committee = take(48 * p.sync_committee_size + 48);
-    L.next_sync_committee = take(48 * p.sync_committee_size + 48);
-    L.payload_header_off = take(4);
-    L.next_withdrawal_index = take(8);
-    L.next_withdrawal_validator_index = take(8);
-    L.historical_summaries_off = take(4);
+    L.inactivity_scores_off = take_if(altair, 4);
+    L.current_sync_committee = take_if(altair, 48 * p.sync_committee_size + 48);
+    L.next_sync_committee = take_if(altair, 48 * p.sync_committee_size + 48);
+    L.payload_header_off = take_if(bellatrix, 4);
+    L.next_withdrawal_index = take_if(capella, 8);
+    L.next_withdrawal_validator_index = take_if(capella, 8);
+    L.historical_summaries_off = take_if(capella, 4);
     L.size = o;
     return L;
 }
@@ -212,6 +236,7 @@ inline FixedLayout layout_for(const Preset& p) {
 inline u32 rd32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
 
 constexpr u64 PAYLOAD_HEADER_FIXED = 584;  // deneb ExecutionPayloadHeader fixed part (extra_data offset at 436)
+constexpr u64 PAYLOAD_EXTRA_DATA_OFFSET_WORD = 436;
 
 struct Builder {
     std::vector<GatherDesc> gathers;
@@ -237,51 +262,72 @@ struct Builder {
     }
 };
 
-// Returns false (plan.error set) when the encoding is malformed.
-inline bool build_state_plan_deneb(const u8* h_fixed, u64 n_bytes, int preset, StatePlan& plan) {
+// Returns false (plan.error set) when the encoding is malformed.  `h_fixed`: at least the fixed part of the encoding.
+// phase0: the roots of the two PendingAttestation lists (variable-size elements: the generic planner of ssz_plan.h computes
+// them) are supplied by the caller as two 32-byte nodes in `ext_roots`; `h_payload_fixed` (optional, bellatrix+): the first
+// 440 bytes of the payload header on the host, to check its extra_data offset word like the reference's deserializer does.
+inline bool build_state_plan(int fork, const u8* h_fixed, u64 n_bytes, int preset, StatePlan& plan, const u8* ext_roots = nullptr,
+                             const u8* h_payload_fixed = nullptr) {
     auto fail = [&](const char* m) { plan.error = m; return false; };
     if (preset < 0 || preset > 1) return fail("bad preset");
+    if (fork < FORK_PHASE0 || fork > FORK_DENEB) return fail("unknown fork");
     const Preset& P = STATE_PRESETS[preset];
-    const FixedLayout L = layout_for(P);
+    const FixedLayout L = layout_for(P, fork);
+    const bool altair = fork >= FORK_ALTAIR, bellatrix = fork >= FORK_BELLATRIX, capella = fork >= FORK_CAPELLA;
     if (n_bytes < L.size) {
         return fail("state encoding shorter than its fixed part");
     }
+    if (fork == FORK_PHASE0 && !ext_roots) return fail("phase0: the PendingAttestation list roots must be supplied");
     // variable parts, in field order
+    const u64 off_words[10] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off,
+                               altair ? L.prev_participation_off : L.prev_attestations_off,
+                               altair ? L.cur_participation_off : L.cur_attestations_off, L.inactivity_scores_off, L.payload_header_off,
+                               L.historical_summaries_off, NO_FIELD};
     u64 off[10];
-    off[0] = rd32(h_fixed + L.historical_roots_off);
-    off[1] = rd32(h_fixed + L.eth1_data_votes_off);
-    off[2] = rd32(h_fixed + L.validators_off);
-    off[3] = rd32(h_fixed + L.balances_off);
-    off[4] = rd32(h_fixed + L.prev_participation_off);
-    off[5] = rd32(h_fixed + L.cur_participation_off);
-    off[6] = rd32(h_fixed + L.inactivity_scores_off);
-    off[7] = rd32(h_fixed + L.payload_header_off);
-    off[8] = rd32(h_fixed + L.historical_summaries_off);
-    off[9] = n_bytes;
-    if (off[0] != L.size) {
-        return fail("first SSZ offset does not match the fixed part");
-    }
-    for (int i = 0; i < 9; i++)
-        if (off[i] > off[i + 1]) {
-            return fail("SSZ offsets not monotonic");
+    u64 prev = L.size;
+    bool first = true;
+    for (int i = 0; i < 9; i++) {
+        if (off_words[i] == NO_FIELD) {
+            off[i] = NO_FIELD;
+            continue;
         }
-    const u64 len_hroots = off[1] - off[0], len_votes = off[2] - off[1], len_vals = off[3] - off[2],
-              len_bal = off[4] - off[3], len_pp = off[5] - off[4], len_cp = off[6] - off[5],
-              len_inact = off[7] - off[6], len_hdr = off[8] - off[7], len_hsum = off[9] - off[8];
+        off[i] = rd32(h_fixed + off_words[i]);
+        if (first && off[i] != L.size) return fail("first SSZ offset does not match the fixed part");
+        if (off[i] < prev || off[i] > n_bytes) return fail("SSZ offsets not monotonic");
+        prev = off[i];
+        first = false;
+    }
+    auto end_of = [&](int i) {  // where variable part i ends: the next present offset, or the end of the encoding
+        for (int k = i + 1; k < 9; k++)
+            if (off[k] != NO_FIELD) return off[k];
+        return n_bytes;
+    };
+    const u64 HDR_FIXED = payload_header_fixed(fork);
+    const u64 len_hroots = end_of(0) - off[0], len_votes = end_of(1) - off[1], len_vals = end_of(2) - off[2], len_bal = end_of(3) - off[3],
+              len_pp = altair ? end_of(4) - off[4] : 0, len_cp = altair ? end_of(5) - off[5] : 0, len_inact = altair ? end_of(6) - off[6] : 0,
+              len_hdr = bellatrix ? end_of(7) - off[7] : 0, len_hsum = capella ? end_of(8) - off[8] : 0;
     if (len_hroots % 32 || len_votes % 72 || len_vals % 121 || len_bal % 8 || len_inact % 8 || len_hsum % 64 ||
-        len_hdr < PAYLOAD_HEADER_FIXED || len_hdr > PAYLOAD_HEADER_FIXED + 32) {
+        (bellatrix && (len_hdr < HDR_FIXED || len_hdr > HDR_FIXED + 32))) {
         return fail("variable-size field has an impossible length");
     }
+    if (bellatrix && h_payload_fixed && rd32(h_payload_fixed + PAYLOAD_EXTRA_DATA_OFFSET_WORD) != HDR_FIXED)
+        return fail("payload header: extra_data offset does not match the fixed part");
     const u64 n_hroots = len_hroots / 32, n_votes = len_votes / 72, n_vals = len_vals / 121, n_bal = len_bal / 8,
-              n_inact = len_inact / 8, n_hsum = len_hsum / 64, extra_len = len_hdr - PAYLOAD_HEADER_FIXED;
+              n_inact = len_inact / 8, n_hsum = len_hsum / 64, extra_len = bellatrix ? len_hdr - HDR_FIXED : 0;
     if (n_hroots > P.historical_roots_limit || n_votes > P.eth1_data_votes_bound ||
         n_vals > P.validator_registry_limit || n_hsum > P.historical_roots_limit) {
         return fail("list longer than its limit");
     }
+    // chunk numbers of the field roots = field positions in the fork's container
+    const u32 F_BITS = 17, F_CP0 = 18, F_INACT = 21, F_SC0 = 22, F_HDR = 24, F_NWI = 25, F_NWVI = 26, F_HSUM = 27;
 
     Builder B;
     std::vector<BigField>& bigs = plan.bigs;
-    const u32 sc_pk_root[2] = {B.alloc(2), B.alloc(2)};  // SyncCommittee container chunks: [pubkeys root, agg root]
+    u32 sc_pk_root[2] = {0, 0};
+    if (altair) {  // SyncCommittee container chunks: [pubkeys root, agg root]
+        sc_pk_root[0] = B.alloc(2);
+        sc_pk_root[1] = B.alloc(2);
+    }
     auto lg = [](u64 x) { return ceil_log2_u64(x); };
     bigs.push_back({LEAF_CHUNKS, L.block_roots, 32 * P.slots_per_historical_root, P.slots_per_historical_root,
                     lg(P.slots_per_historical_root), false, 0, 5});
@@ -295,14 +341,19 @@ inline bool build_state_plan_deneb(const u8* h_fixed, u64 n_bytes, int preset, S
                     lg(P.epochs_per_historical_vector), false, 0, 13});
     bigs.push_back({LEAF_CHUNKS, L.slashings, 8 * P.epochs_per_slashings_vector, P.epochs_per_slashings_vector / 4,
                     lg(P.epochs_per_slashings_vector / 4), false, 0, 14});
-    bigs.push_back({LEAF_CHUNKS, off[4], len_pp, (len_pp + 31) / 32, lg(P.validator_registry_limit / 32), true, len_pp, 15});
-    bigs.push_back({LEAF_CHUNKS, off[5], len_cp, (len_cp + 31) / 32, lg(P.validator_registry_limit / 32), true, len_cp, 16});
-    bigs.push_back({LEAF_CHUNKS, off[6], len_inact, (len_inact + 31) / 32, lg(P.validator_registry_limit / 4), true, n_inact, 21});
-    bigs.push_back({LEAF_BYTES48, L.current_sync_committee, 48 * P.sync_committee_size, P.sync_committee_size,
-                    lg(P.sync_committee_size), false, 0, sc_pk_root[0]});
-    bigs.push_back({LEAF_BYTES48, L.next_sync_committee, 48 * P.sync_committee_size, P.sync_committee_size,
-                    lg(P.sync_committee_size), false, 0, sc_pk_root[1]});
-    bigs.push_back({LEAF_PAIR64, off[8], len_hsum, n_hsum, lg(P.historical_roots_limit), true, n_hsum, 27});
+    if (altair) {
+        bigs.push_back({LEAF_CHUNKS, off[4], len_pp, (len_pp + 31) / 32, lg(P.validator_registry_limit / 32), true, len_pp, 15});
+        bigs.push_back({LEAF_CHUNKS, off[5], len_cp, (len_cp + 31) / 32, lg(P.validator_registry_limit / 32), true, len_cp, 16});
+        bigs.push_back({LEAF_CHUNKS, off[6], len_inact, (len_inact + 31) / 32, lg(P.validator_registry_limit / 4), true, n_inact, F_INACT});
+        bigs.push_back({LEAF_BYTES48, L.current_sync_committee, 48 * P.sync_committee_size, P.sync_committee_size,
+                        lg(P.sync_committee_size), false, 0, sc_pk_root[0]});
+        bigs.push_back({LEAF_BYTES48, L.next_sync_committee, 48 * P.sync_committee_size, P.sync_committee_size,
+                        lg(P.sync_committee_size), false, 0, sc_pk_root[1]});
+    } else {
+        plan.ext_chunks.push_back({15u, 0u});  // previous_epoch_attestations, current_epoch_attestations: roots from the caller
+        plan.ext_chunks.push_back({16u, 32u});
+    }
+    if (capella) bigs.push_back({LEAF_PAIR64, off[8], len_hsum, n_hsum, lg(P.historical_roots_limit), true, n_hsum, F_HSUM});
 
     // ---- small fields: gathers + jobs ----------------------------------------------------------
     // basic fields: the root is the zero-padded chunk itself
@@ -310,9 +361,11 @@ inline bool build_state_plan_deneb(const u8* h_fixed, u64 n_bytes, int preset, S
     B.gather(L.genesis_validators_root, 32, 1);
     B.gather(L.slot, 8, 2);
     B.gather(L.eth1_deposit_index, 8, 10);
-    B.gather(L.justification_bits, 1, 17);
-    B.gather(L.next_withdrawal_index, 8, 25);
-    B.gather(L.next_withdrawal_validator_index, 8, 26);
+    B.gather(L.justification_bits, 1, F_BITS);
+    if (capella) {
+        B.gather(L.next_withdrawal_index, 8, F_NWI);
+        B.gather(L.next_withdrawal_validator_index, 8, F_NWVI);
+    }
     {   // Fork: previous_version[4], current_version[4], epoch u64
         u32 c0 = B.alloc(3);
         B.gather(L.fork, 4, c0);
@@ -339,21 +392,21 @@ inline bool build_state_plan_deneb(const u8* h_fixed, u64 n_bytes, int preset, S
         u32 c0 = B.alloc(2);
         B.gather(cps[k], 8, c0);
         B.gather(cps[k] + 8, 32, c0 + 1);
-        B.job(0, c0, 2, 1, 18 + k);
+        B.job(0, c0, 2, 1, F_CP0 + k);
     }
     const u64 scs[2] = {L.current_sync_committee, L.next_sync_committee};
-    for (u32 k = 0; k < 2; k++) {  // SyncCommittee: htr(Vector<PublicKey>) (big pass), htr(aggregate_public_key)
+    for (u32 k = 0; k < 2 && altair; k++) {  // SyncCommittee: htr(Vector<PublicKey>) (big pass), htr(aggregate_public_key)
         u32 c0 = B.alloc(2);
         u64 agg = scs[k] + 48 * P.sync_committee_size;
         B.gather(agg, 32, c0);
         B.gather(agg + 32, 16, c0 + 1);
         B.job(0, c0, 2, 1, sc_pk_root[k] + 1);
-        B.job(1, sc_pk_root[k], 2, 1, 22 + k);
-        B.hashes += 0;
+        B.job(1, sc_pk_root[k], 2, 1, F_SC0 + k);
     }
-    {   // ExecutionPayloadHeader (deneb): 17 fields
+    if (bellatrix) {   // ExecutionPayloadHeader: 14 (bellatrix), 15 (capella) or 17 (deneb) fields
         const u64 h = off[7];
-        u32 f = B.alloc(17);
+        const u32 nf = fork == FORK_BELLATRIX ? 14u : fork == FORK_CAPELLA ? 15u : 17u;
+        u32 f = B.alloc(nf);
         B.gather(h + 0, 32, f + 0);      // parent_hash
         B.gather(h + 32, 20, f + 1);     // fee_recipient
         B.gather(h + 52, 32, f + 2);     // state_root
@@ -367,25 +420,31 @@ inline bool build_state_plan_deneb(const u8* h_fixed, u64 n_bytes, int preset, S
         B.gather(h + 420, 8, f + 8);     // gas_used
         B.gather(h + 428, 8, f + 9);     // timestamp
         u32 extra = B.alloc(1);          // extra_data: ByteList<32> -> one chunk, mix in length
-        B.gather(h + PAYLOAD_HEADER_FIXED, (u32)extra_len, extra);
+        B.gather(h + HDR_FIXED, (u32)extra_len, extra);
         B.job(0, extra, extra_len ? 1 : 0, 0, f + 10, true, extra_len);
         B.gather(h + 440, 32, f + 11);   // base_fee_per_gas (U256 LE)
         B.gather(h + 472, 32, f + 12);   // block_hash
         B.gather(h + 504, 32, f + 13);   // transactions_root
-        B.gather(h + 536, 32, f + 14);   // withdrawals_root
-        B.gather(h + 568, 8, f + 15);    // blob_gas_used
-        B.gather(h + 576, 8, f + 16);    // excess_blob_gas
-        B.job(1, f, 17, 5, 24);
+        if (capella) B.gather(h + 536, 32, f + 14);  // withdrawals_root
+        if (fork == FORK_DENEB) {
+            B.gather(h + 568, 8, f + 15);  // blob_gas_used
+            B.gather(h + 576, 8, f + 16);  // excess_blob_gas
+        }
+        B.job(1, f, nf, lg(nf), F_HDR);
     }
     const u32 root_chunk = B.alloc(1);
-    B.job(2, 0, 28, 5, root_chunk);
+    B.job(2, 0, state_field_count(fork), 5, root_chunk);
 
     plan.gathers = B.gathers;
     for (int l = 0; l < 3; l++) plan.jobs[l] = B.jobs[l];
     plan.n_small_chunks = B.next_chunk;
     plan.root_chunk = root_chunk;
     plan.small_hashes = B.hashes;
+    plan.payload_header_off = bellatrix ? off[7] : NO_FIELD;
     return true;
+}
+inline bool build_state_plan_deneb(const u8* h_fixed, u64 n_bytes, int preset, StatePlan& plan) {
+    return build_state_plan(FORK_DENEB, h_fixed, n_bytes, preset, plan);
 }
 
 }  // namespace ecg

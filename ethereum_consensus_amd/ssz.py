@@ -105,15 +105,28 @@ def hash_tree_root_beacon_state_deneb(ssz: bytes, preset: int = MAINNET) -> byte
     return _root(L.ecgpu_htr_beacon_state_deneb, _buf(ssz), len(ssz), preset)
 
 
+FORKS = {"phase0": 0, "altair": 1, "bellatrix": 2, "capella": 3, "deneb": 4}
+
+
+def hash_tree_root_beacon_state(fork, ssz: bytes, preset: int = MAINNET) -> bytes:
+    """`BeaconState::hash_tree_root` of any fork up to deneb (phase0/beacon_state.rs:50, altair/beacon_state.rs:13,
+    bellatrix/beacon_state.rs:13, capella/beacon_state.rs:13, deneb/beacon_state.rs:13) from the state's SSZ serialization;
+    called per slot (phase0/slot_processing.rs:67) and per block (phase0/state_transition.rs:60)."""
+    L = _lib.load()
+    return _root(L.ecgpu_htr_beacon_state, FORKS[fork] if isinstance(fork, str) else int(fork), _buf(ssz), len(ssz), preset)
+
+
 class ResidentBeaconStateDeneb:
-    """A deneb BeaconState kept in HBM: uploaded once, then patched in place with the bytes a block changed and
+    """A BeaconState (deneb unless `fork` says altair / bellatrix / capella) kept in HBM: uploaded once, then patched in place with the bytes a block changed and
     re-Merkleized on the device (the reference re-hashes the host-resident state every slot,
     phase0/slot_processing.rs:67)."""
 
-    def __init__(self, encoding: bytes, preset: int = MAINNET):
+    def __init__(self, encoding: bytes, preset: int = MAINNET, fork="deneb"):
+        self._h = None
         self._L = _lib.load()
         h = ctypes.c_void_p()
-        rc = self._L.ecgpu_resident_state_create(preset, _buf(encoding), len(encoding), ctypes.byref(h))
+        rc = self._L.ecgpu_resident_state_create_fork(FORKS[fork] if isinstance(fork, str) else int(fork), preset, _buf(encoding),
+                                                      len(encoding), ctypes.byref(h))
         if rc == -3:
             raise MerkleizationError((self._L.ecgpu_last_error() or b"bad state").decode())
         _lib.check(rc, "ecgpu_resident_state_create")
@@ -187,6 +200,101 @@ def is_valid_merkle_branch(leaf: bytes, branch, depth: int, index: int, root: by
     rc = L.ecgpu_is_valid_merkle_branch(_buf(leaf), _buf(b), depth, index, _buf(root))
     _lib.check(rc, "ecgpu_is_valid_merkle_branch")
     return rc == 0
+
+
+# ---- proofs (ssz_rs `Prove` / `GeneralizedIndexable`; spec-tests/runners/light_client.rs:42-69, deneb/blob_sidecar.rs:47-64) ----
+LENGTH = "__len__"
+
+
+def _path_positions(ssz_type, path):
+    """field names -> field positions, element indices as they are, LENGTH -> ECGPU_SSZ_PATH_LENGTH"""
+    from . import ssz_types as T
+    out, t = [], ssz_type
+    for p in path:
+        if p == LENGTH:
+            out.append(0xFFFFFFFFFFFFFFFF)
+            t = None
+            continue
+        if t is not None and t[0] == T.CONTAINER:
+            i = t[2].index(p) if isinstance(p, str) else int(p)
+            out.append(i)
+            t = t[1][i]
+        else:
+            out.append(int(p))
+            t = t[1] if t is not None and t[0] in (T.VECTOR, T.LIST) and t[1][0] != T.UINT else None
+    return out
+
+
+def generalized_index(ssz_type, path) -> int:
+    """`T::generalized_index(path)` (deneb/beacon_block.rs:139-154, deneb/blob_sidecar.rs:56-57)"""
+    from . import ssz_types
+    L = _lib.load()
+    if ssz_type not in _compiled:
+        _compiled[ssz_type] = ssz_types.compile(ssz_type)
+    arr, farr, nf, root_idx = _compiled[ssz_type]
+    pos = _path_positions(ssz_type, path)
+    parr = (ctypes.c_uint64 * max(len(pos), 1))(*pos)
+    g = ctypes.c_uint64(0)
+    rc = L.ecgpu_ssz_generalized_index(arr, len(arr), farr, nf, root_idx, parr, len(pos), ctypes.byref(g))
+    if rc == -3:
+        raise MerkleizationError((L.ecgpu_last_error() or b"bad path").decode())
+    _lib.check(rc, "ecgpu_ssz_generalized_index")
+    return g.value
+
+
+def prove(ssz_type, encoding: bytes, path):
+    """`value.prove(path)` from the value's serialization -> (leaf, branch [bottom-up], generalized index, witness root)"""
+    from . import ssz_types
+    L = _lib.load()
+    if ssz_type not in _compiled:
+        _compiled[ssz_type] = ssz_types.compile(ssz_type)
+    arr, farr, nf, root_idx = _compiled[ssz_type]
+    pos = _path_positions(ssz_type, path)
+    parr = (ctypes.c_uint64 * max(len(pos), 1))(*pos)
+    leaf, root = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    branch = ctypes.create_string_buffer(32 * 128)
+    depth, g = ctypes.c_uint32(0), ctypes.c_uint64(0)
+    rc = L.ecgpu_ssz_prove(arr, len(arr), farr, nf, root_idx, _buf(encoding), len(encoding), parr, len(pos), leaf, branch, 128,
+                           ctypes.byref(depth), ctypes.byref(g), root)
+    if rc == -3:
+        raise MerkleizationError((L.ecgpu_last_error() or b"bad path or encoding").decode())
+    _lib.check(rc, "ecgpu_ssz_prove")
+    return leaf.raw, [branch.raw[32 * i:32 * i + 32] for i in range(depth.value)], g.value, root.raw
+
+
+def merkle_proof(chunks: bytes, limit_chunks: int, index: int):
+    """the branch of chunk `index` in merkleize(chunks, limit_chunks), bottom-up"""
+    L = _lib.load()
+    n = len(chunks) // 32
+    depth = max(limit_chunks - 1, 0).bit_length()
+    out = ctypes.create_string_buffer(max(32 * depth, 1))
+    rc = L.ecgpu_merkle_proof(_buf(chunks), n, limit_chunks, index, out)
+    if rc == -3:
+        raise MerkleizationError("bad proof request")
+    _lib.check(rc, "ecgpu_merkle_proof")
+    return [out.raw[32 * i:32 * i + 32] for i in range(depth)]
+
+
+def beacon_state_field_roots(fork, ssz: bytes, preset: int = MAINNET):
+    """(roots of the state's fields, state root): one state root's worth of work"""
+    L = _lib.load()
+    roots = ctypes.create_string_buffer(32 * 32)
+    n = ctypes.c_uint32(0)
+    root = ctypes.create_string_buffer(32)
+    rc = L.ecgpu_beacon_state_field_roots(FORKS[fork] if isinstance(fork, str) else int(fork), _buf(ssz), len(ssz), preset, roots, 32,
+                                          ctypes.byref(n), root)
+    if rc == -3:
+        raise MerkleizationError((L.ecgpu_last_error() or b"bad state").decode())
+    _lib.check(rc, "ecgpu_beacon_state_field_roots")
+    return [roots.raw[32 * i:32 * i + 32] for i in range(n.value)], root.raw
+
+
+def prove_beacon_state_field(fork, ssz: bytes, preset: int, field_position: int):
+    """light-client style branch of one field of a BeaconState (spec-tests/runners/light_client.rs:32-40: current / next sync
+    committee; finalized_checkpoint, continued below the field by `prove` on the field's own encoding):
+    -> (leaf = the field's root, branch of depth 5, generalized index 32 + position, state root)"""
+    roots, root = beacon_state_field_roots(fork, ssz, preset)
+    return roots[field_position], merkle_proof(b"".join(roots), 32, field_position), 32 + field_position, root
 
 
 def last_hash64_count() -> int:

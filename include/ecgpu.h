@@ -94,6 +94,20 @@ int ecgpu_htr_beacon_state_deneb(const uint8_t* ssz, uint64_t n_bytes, int prese
 int ecgpu_htr_beacon_state_deneb_dev(const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed,
                                      int preset, uint8_t* d_root, ecgpu_stream_t stream);
 uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);
+/* The same for every fork the reference defines up to deneb: phase0/beacon_state.rs:50-88 (21 fields),
+ * altair/beacon_state.rs:13-55 (24), bellatrix/beacon_state.rs:13-58 (25), capella/beacon_state.rs:13-64 (28),
+ * deneb/beacon_state.rs:13-64 (28).  The host-pointer entry takes any fork; phase0 states hold two lists of variable-size
+ * elements (PendingAttestation), whose offset tables live in the encoding itself, so the device-resident forms
+ * (_dev, resident states) start at altair. */
+#define ECGPU_FORK_PHASE0 0
+#define ECGPU_FORK_ALTAIR 1
+#define ECGPU_FORK_BELLATRIX 2
+#define ECGPU_FORK_CAPELLA 3
+#define ECGPU_FORK_DENEB 4
+int ecgpu_htr_beacon_state(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32]);
+int ecgpu_htr_beacon_state_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
+                               uint8_t* d_root, ecgpu_stream_t stream);
+uint64_t ecgpu_beacon_state_fixed_size(int fork, int preset);
 /* number of hash64 the last state root of this thread performed (work accounting for benches) */
 uint64_t ecgpu_last_hash64_count(void);
 
@@ -107,7 +121,8 @@ uint64_t ecgpu_last_hash64_count(void);
  * (32 B each): a patch marks the records its bytes belong to, `root` re-hashes only those and feeds the registry to the
  * tree as ready chunks (first level) -- same roots, half the time. */
 typedef struct ecgpu_resident_state ecgpu_resident_state_t;
-int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out);
+int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out); /* deneb */
+int ecgpu_resident_state_create_fork(int fork, int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out);
 void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st);
 /* n patches: bytes data[data_off[i] .. data_off[i+1]) replace the encoding at offsets[i]; the patches of one call must
  * not overlap (they are applied concurrently) */
@@ -141,6 +156,27 @@ typedef struct {
 } ecgpu_ssz_type;
 int ecgpu_htr_ssz(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs,
                   uint32_t root_type, const uint8_t* ssz, uint64_t n_bytes, uint8_t root[32]);
+
+/* Merkle proofs and generalized indices (second half): ssz_rs `GeneralizedIndexable::generalized_index`
+ * and `Prove::prove` for any described type, as exercised at spec-tests/runners/light_client.rs:42-69,
+ * deneb/blob_sidecar.rs:47-64 and deneb/beacon_block.rs:139-154.  A path element is a field POSITION (containers) or an
+ * element index (vectors / lists; for packed basic sequences the proof ends at the chunk holding the element);
+ * ECGPU_SSZ_PATH_LENGTH selects a list's length node.  prove: leaf, branch (bottom-up, 32 bytes per node, at most
+ * max_depth nodes; *depth = nodes written), the generalized index and the witness root; every hash64 runs on the GPU.
+ * Verify with ecgpu_is_valid_merkle_branch(leaf, branch, depth, gindex - (1 << depth), root). */
+#define ECGPU_SSZ_PATH_LENGTH 0xffffffffffffffffull
+int ecgpu_ssz_generalized_index(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs,
+                                uint32_t root_type, const uint64_t* path, uint32_t path_len, uint64_t* gindex);
+int ecgpu_ssz_prove(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs, uint32_t root_type,
+                    const uint8_t* ssz, uint64_t n_bytes, const uint64_t* path, uint32_t path_len, uint8_t leaf[32], uint8_t* branch,
+                    uint32_t max_depth, uint32_t* depth, uint64_t* gindex, uint8_t root[32]);
+/* the branch of chunk `index` in merkleize(chunks, limit_chunks): ceil_log2(limit_chunks) sibling nodes, bottom-up */
+int ecgpu_merkle_proof(const uint8_t* chunks, uint64_t n_chunks, uint64_t limit_chunks, uint64_t index, uint8_t* branch);
+/* the roots of the fields of a BeaconState (the chunks of its container tree) next to its root: with ecgpu_merkle_proof
+ * they give the light-client branches (current / next sync committee, finalized_checkpoint -> root) of a 2^20-validator
+ * state at the cost of one state root.  roots: 32 * capacity bytes, *n_fields = 21 / 24 / 25 / 28 by fork. */
+int ecgpu_beacon_state_field_roots(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t* roots, uint32_t capacity,
+                                   uint32_t* n_fields, uint8_t root[32]);
 
 /* Swap-or-not shuffling: `compute_shuffled_indices(indices, seed, context)`
  * (phase0/helpers.rs:287-360; out[i] = indices[compute_shuffled_index(i, n, seed)], :249-282), the SHA-256 consumer

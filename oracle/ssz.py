@@ -475,6 +475,155 @@ def BeaconStateDeneb(p: Preset) -> Container:
     )
 
 
+# ---- proofs: an independent restatement of ssz_rs `Prove::prove` / `generalized_index` --------------
+LENGTH = "__len__"
+
+
+def _data_chunks(typ: SSZType, v):
+    """(chunks of the data tree of `typ` for value `v`, leaf limit, mixes a length in?, length, child types or None)"""
+    if isinstance(typ, Container):
+        return [t.htr(v[n]) for n, t in typ.fields], len(typ.fields), False, 0, [t for _, t in typ.fields]
+    if isinstance(typ, (Vector, SSZList)):
+        is_list = isinstance(typ, SSZList)
+        bound = typ.limit if is_list else typ.n
+        if isinstance(typ.elem, (UInt, Boolean)):
+            data = typ.serialize(v)
+            data += bytes(-len(data) % 32)
+            return [data[i:i + 32] for i in range(0, len(data), 32)], (bound * typ.elem.fixed_size + 31) // 32, is_list, len(v), None
+        return [typ.elem.htr(x) for x in v], bound, is_list, len(v), [typ.elem] * len(v)
+    if isinstance(typ, (ByteVector, ByteList)):
+        data = bytes(v) + bytes(-len(v) % 32)
+        bound = typ.limit if isinstance(typ, ByteList) else typ.n
+        return [data[i:i + 32] for i in range(0, len(data), 32)], (bound + 31) // 32, isinstance(typ, ByteList), len(v), None
+    if isinstance(typ, (Bitvector, Bitlist)):
+        out = bytearray((len(v) + 7) // 8)
+        for i, b in enumerate(v):
+            if b:
+                out[i // 8] |= 1 << (i % 8)
+        data = bytes(out) + bytes(-len(out) % 32)
+        bound = typ.limit if isinstance(typ, Bitlist) else typ.n
+        return [data[i:i + 32] for i in range(0, len(data), 32)], (bound + 255) // 256, isinstance(typ, Bitlist), len(v), None
+    raise TypeError("a basic value has no children")
+
+
+def _branch_in_chunks(chunks, limit: int, index: int):
+    """siblings of leaf `index` in merkleize_chunks(chunks, limit), bottom-up, from the full level arrays"""
+    depth = _depth_for(max(limit, 1))
+    level = list(chunks)
+    zero = bytes(32)
+    out = []
+    for d in range(depth):
+        sib = (index >> d) ^ 1
+        out.append(level[sib] if sib < len(level) else zero)
+        nxt = [hash64(level[i], level[i + 1] if i + 1 < len(level) else zero) for i in range(0, len(level), 2)]
+        level, zero = nxt, hash64(zero, zero)
+    return out
+
+
+def _child_position(typ: SSZType, p):
+    """position of path element `p` in the data tree of `typ`, and the child's value accessor"""
+    if isinstance(typ, Container):
+        i = [n for n, _ in typ.fields].index(p) if isinstance(p, str) else int(p)
+        return i
+    if isinstance(typ, (Vector, SSZList)) and isinstance(typ.elem, (UInt, Boolean)):
+        return int(p) * typ.elem.fixed_size // 32
+    if isinstance(typ, (ByteVector, ByteList)):
+        return int(p) // 32
+    if isinstance(typ, (Bitvector, Bitlist)):
+        return int(p) // 256
+    return int(p)
+
+
+def generalized_index(typ: SSZType, path) -> int:
+    g = 1
+    for p in path:
+        _, limit, mix, _, _ = _data_chunks(typ, typ.default())
+        if p == LENGTH:
+            assert mix
+            return g * 2 + 1
+        if mix:
+            g *= 2
+        pos = _child_position(typ, p)
+        g = (g << _depth_for(max(limit, 1))) + pos
+        if isinstance(typ, Container):
+            typ = typ.fields[pos][1]
+        elif isinstance(typ, (Vector, SSZList)) and not isinstance(typ.elem, (UInt, Boolean)):
+            typ = typ.elem
+        else:
+            typ = None
+    return g
+
+
+def prove(typ: SSZType, v, path):
+    """-> (leaf, branch bottom-up, generalized index, witness root)"""
+    root = typ.htr(v)
+    parts = []
+    g = 1
+    leaf = None
+    for p in path:
+        assert leaf is None, "path continues below a leaf"
+        chunks, limit, mix, length, child_types = _data_chunks(typ, v)
+        depth = _depth_for(max(limit, 1))
+        len_chunk = int(length).to_bytes(32, "little")
+        if p == LENGTH:
+            assert mix
+            parts.append([merkleize_chunks(chunks, limit)])
+            g = g * 2 + 1
+            leaf = len_chunk
+            continue
+        pos = _child_position(typ, p)
+        part = _branch_in_chunks(chunks, limit, pos)
+        if mix:
+            part.append(len_chunk)
+            g *= 2
+        g = (g << depth) + pos
+        parts.append(part)
+        if child_types is None:
+            leaf = chunks[pos] if pos < len(chunks) else bytes(32)
+        else:
+            v = v[typ.fields[pos][0]] if isinstance(typ, Container) else v[pos]
+            typ = child_types[pos]
+    if leaf is None:
+        leaf = typ.htr(v)
+    branch = [n for part in reversed(parts) for n in part]
+    return leaf, branch, g, root
+
+
+# ---- the other forks' states (row a14), restated from the reference field for field ----------------------------------
+def ExecutionPayloadHeader(fork: str) -> Container:
+    """bellatrix/execution_payload.rs:58-81 (14 fields), capella/execution_payload.rs (+ withdrawals_root), deneb/
+    execution_payload.rs:48-76 (+ blob_gas_used, excess_blob_gas)"""
+    full = ExecutionPayloadHeaderDeneb()
+    n = {"bellatrix": 14, "capella": 15, "deneb": 17}[fork]
+    return Container("ExecutionPayloadHeader", full.fields[:n])
+
+
+def PendingAttestation(max_validators_per_committee: int = 2048) -> Container:
+    """phase0/operations.rs:45-52"""
+    return Container("PendingAttestation", [("aggregation_bits", Bitlist(max_validators_per_committee)), ("data", AttestationData),
+                                            ("inclusion_delay", uint64), ("proposer_index", uint64)])
+
+
+PENDING_ATTESTATIONS_BOUND = {"mainnet": 128 * 32, "minimal": 128 * 8}  # MAX_ATTESTATIONS * SLOTS_PER_EPOCH, phase0/presets/*.rs:84
+
+
+def BeaconState(fork: str, p: Preset) -> Container:
+    """phase0/beacon_state.rs:50-88, altair/beacon_state.rs:13-55, bellatrix/beacon_state.rs:13-58,
+    capella/beacon_state.rs:13-64, deneb/beacon_state.rs:13-64: the common 15 fields, then the fork's own tail"""
+    d = BeaconStateDeneb(p).fields
+    common, bits_cps = d[:15], d[17:21]
+    if fork == "phase0":
+        att = SSZList(PendingAttestation(), PENDING_ATTESTATIONS_BOUND[p.name])
+        return Container("BeaconState", common + [("previous_epoch_attestations", att), ("current_epoch_attestations", att)] + bits_cps)
+    fields = d[:24]
+    if fork in ("bellatrix", "capella", "deneb"):
+        fields = fields + [("latest_execution_payload_header", ExecutionPayloadHeader(fork))]
+    if fork in ("capella", "deneb"):
+        fields = fields + d[25:28]
+    assert len(fields) == {"altair": 24, "bellatrix": 25, "capella": 28, "deneb": 28}[fork]
+    return Container("BeaconState", fields)
+
+
 # ---- deneb block types (row a15), restated from the reference field for field ------------------------------------
 SignedBeaconBlockHeader = Container("SignedBeaconBlockHeader", [("message", BeaconBlockHeader), ("signature", BlsSignature)])  # phase0/beacon_block.rs:93-100
 ProposerSlashing = Container("ProposerSlashing", [("signed_header_1", SignedBeaconBlockHeader), ("signed_header_2", SignedBeaconBlockHeader)])  # phase0/operations.rs:97-100

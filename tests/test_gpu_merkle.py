@@ -311,3 +311,183 @@ def test_box_selfcheck_runs_and_reports_positive_times(gpu):
     sweep = (ctypes.c_double * 4)()
     assert L.ecgpu_selfcheck_ifetch_sweep(sweep) == 0
     assert all(0.5 < x < 1000 for x in sweep)
+
+
+def _fork_state_value(fork, f, rnd):
+    """the oracle value of a `fork` BeaconState built from the deneb field dict of ethereum_consensus_amd.synthetic"""
+    from oracle import ssz as O
+    v = dict(oracle_state_value(f))
+    if fork == "phase0":
+        att = lambda k: {"aggregation_bits": [rnd.random() < 0.6 for _ in range(rnd.choice([0, 1, 7, 8, 9, 130, 2048][:k % 7 + 1]))],
+                         "data": {"slot": rnd.randrange(1 << 40), "index": rnd.randrange(64), "beacon_block_root": rnd.randbytes(32),
+                                  "source": {"epoch": rnd.randrange(1 << 30), "root": rnd.randbytes(32)},
+                                  "target": {"epoch": rnd.randrange(1 << 30), "root": rnd.randbytes(32)}},
+                         "inclusion_delay": rnd.randrange(1, 33), "proposer_index": rnd.randrange(1 << 20)}
+        v["previous_epoch_attestations"] = [att(k) for k in range(rnd.choice([0, 3, 40]))]
+        v["current_epoch_attestations"] = [att(k) for k in range(rnd.choice([1, 17]))]
+    if fork in ("bellatrix", "capella"):
+        hdr = dict(v["latest_execution_payload_header"])
+        for k in (["blob_gas_used", "excess_blob_gas"] + (["withdrawals_root"] if fork == "bellatrix" else [])):
+            hdr.pop(k)
+        v["latest_execution_payload_header"] = hdr
+    t = O.BeaconState(fork, O.MINIMAL if f["_preset"] == "minimal" else O.MAINNET)
+    return t, {n: v[n] for n, _ in t.fields}
+
+
+@pytest.mark.parametrize("fork", ["phase0", "altair", "bellatrix", "capella", "deneb"])
+def test_beacon_state_root_of_every_fork(gpu, fork):
+    """hash_tree_root(BeaconState) for phase0 / altair / bellatrix / capella / deneb, both presets,
+    against the oracle's independent restatement of each fork's container (oracle/ssz.py BeaconState); the encodings are the
+    oracle's own serializations of random states (phase0: with pending attestations whose bit lists end in every byte
+    position), plus malformed encodings."""
+    import random
+    from ethereum_consensus_amd import synthetic
+    from oracle import ssz as O
+    ssz = gpu
+    rnd = random.Random({"phase0": 1, "altair": 2, "bellatrix": 3, "capella": 4, "deneb": 5}[fork])
+    for preset_name, preset, n in (("minimal", ssz.MINIMAL, 37), ("mainnet", ssz.MAINNET, 300), ("minimal", ssz.MINIMAL, 0)):
+        f = synthetic.state_fields(n, preset_name, seed=rnd.randrange(1000), extra_data=rnd.randbytes(rnd.choice([0, 5, 32])))
+        f["_preset"] = preset_name
+        t, v = _fork_state_value(fork, f, rnd)
+        enc = t.serialize(v)
+        assert ssz.hash_tree_root_beacon_state(fork, enc, preset) == t.htr(v), (fork, preset_name, n)
+        assert len(enc) >= ssz._lib.load().ecgpu_beacon_state_fixed_size(ssz.FORKS[fork], preset) > 0
+        if fork == "deneb":
+            assert ssz.hash_tree_root_beacon_state_deneb(enc, preset) == t.htr(v)
+    # malformed: truncated below the fixed part; a first offset that does not match; (bellatrix+) a wrong extra_data offset
+    with pytest.raises(ssz.MerkleizationError):
+        ssz.hash_tree_root_beacon_state(fork, enc[:1000], ssz.MINIMAL)
+    bad = bytearray(enc)
+    fixed = ssz._lib.load().ecgpu_beacon_state_fixed_size(ssz.FORKS[fork], ssz.MINIMAL)
+    pos = bytes(enc).find(fixed.to_bytes(4, "little"))
+    bad[pos] ^= 1
+    with pytest.raises(ssz.MerkleizationError):
+        ssz.hash_tree_root_beacon_state(fork, bytes(bad), ssz.MINIMAL)
+    if fork in ("bellatrix", "capella", "deneb"):
+        hdr_fixed = {"bellatrix": 536, "capella": 568, "deneb": 584}[fork]
+        t = O.BeaconState(fork, O.MINIMAL)
+        names = [n for n, _ in t.fields]
+        # the payload header starts at the offset stored in its slot of the fixed part
+        off_pos = sum((ft.fixed_size if ft.fixed_size is not None else 4) for _, ft in t.fields[:names.index("latest_execution_payload_header")])
+        h = int.from_bytes(enc[off_pos:off_pos + 4], "little")
+        assert int.from_bytes(enc[h + 436:h + 440], "little") == hdr_fixed
+        bad = bytearray(enc)
+        bad[h + 436] ^= 4
+        with pytest.raises(ssz.MerkleizationError):
+            ssz.hash_tree_root_beacon_state(fork, bytes(bad), ssz.MINIMAL)
+
+
+def test_resident_state_of_an_older_fork(gpu):
+    """a capella state kept resident: patches + roots equal the from-scratch roots of the patched encoding"""
+    import random
+    from ethereum_consensus_amd import synthetic
+    from oracle import ssz as O
+    ssz = gpu
+    rnd = random.Random(77)
+    f = synthetic.state_fields(500, "minimal", seed=3)
+    f["_preset"] = "minimal"
+    t, v = _fork_state_value("capella", f, rnd)
+    enc = bytearray(t.serialize(v))
+    st = ssz.ResidentBeaconStateDeneb(bytes(enc), ssz.MINIMAL, fork="capella")
+    assert st.hash_tree_root() == t.htr(v)
+    for _ in range(3):
+        patches = []
+        for _ in range(20):
+            off = rnd.randrange(2736 + 200, len(enc) - 700)  # somewhere in the variable part, away from offset words
+            b = rnd.randbytes(rnd.choice([1, 8]))
+            patches.append((off, b))
+        patches = sorted(dict(patches).items())
+        ok = all(patches[i][0] + len(patches[i][1]) <= patches[i + 1][0] for i in range(len(patches) - 1))
+        if not ok:
+            continue
+        try:
+            st.patch(patches)
+        except ssz.MerkleizationError:
+            continue  # touched an offset word
+        for off, b in patches:
+            enc[off:off + len(b)] = b
+        try:
+            want = ssz.hash_tree_root_beacon_state("capella", bytes(enc), ssz.MINIMAL)
+        except ssz.MerkleizationError:
+            break  # a patch made the encoding itself invalid (e.g. a slashed byte is still a byte: never here)
+        assert st.hash_tree_root() == want
+    st.close()
+
+
+def test_proofs_and_generalized_indices(gpu):
+    """`prove` / `generalized_index` over the generic SSZ description against the oracle's restatement
+    (oracle/ssz.py prove), the reference's pinned indices (deneb/beacon_block.rs:139-154) and ecgpu_is_valid_merkle_branch
+    with the index arithmetic of deneb/blob_sidecar.rs:56-63."""
+    import random
+    from ethereum_consensus_amd import ssz_types as T
+    from tests import _sszrand
+    ssz = gpu
+    for p_gpu, p_or in ((T.MAINNET, ossz.BLOCK_MAINNET), (T.MINIMAL, ossz.BLOCK_MINIMAL)):
+        body_g = T.BeaconBlockBodyDeneb(p_gpu)
+        body_o = dict(ossz.BeaconBlockDeneb(p_or).fields)["body"]
+        if p_gpu is T.MAINNET:
+            idx = [ssz.generalized_index(body_g, ["blob_kzg_commitments"])] + [ssz.generalized_index(body_g, ["blob_kzg_commitments", i]) for i in range(6)]
+            assert idx == [27, 221184, 221185, 221186, 221187, 221188, 221189]
+        r = random.Random(11)
+        for trial in range(3):
+            v = _sszrand.random_value(body_o, r, fill=["full", None, None][trial])
+            enc = body_o.serialize(v)
+            paths = [["execution_payload"], ["eth1_data", "deposit_count"], ["attestations", ssz.LENGTH], ["graffiti"], ["randao_reveal"],
+                     ["sync_aggregate", "sync_committee_bits", 5], ["execution_payload", "block_hash"], ["execution_payload", "extra_data", ssz.LENGTH],
+                     ["execution_payload", "logs_bloom", 100]]
+            if v["blob_kzg_commitments"]:
+                paths += [["blob_kzg_commitments", 0], ["blob_kzg_commitments", len(v["blob_kzg_commitments"]) - 1]]
+            if v["execution_payload"]["transactions"]:
+                paths += [["execution_payload", "transactions", 0]]
+            if v["attestations"]:
+                paths += [["attestations", 0, "data", "target", "root"], ["attestations", len(v["attestations"]) - 1, "aggregation_bits", ssz.LENGTH]]
+            if v["deposits"]:
+                paths += [["deposits", 0, "proof", 32], ["deposits", 0, "data", "amount"]]
+            for path in paths:
+                opath = [ossz.LENGTH if p == ssz.LENGTH else p for p in path]
+                want = ossz.prove(body_o, v, opath)
+                got = ssz.prove(body_g, enc, path)
+                assert got == want, path
+                leaf, branch, g, root = got
+                depth = g.bit_length() - 1
+                assert g == ssz.generalized_index(body_g, path) and len(branch) == depth
+                assert ssz.is_valid_merkle_branch(leaf, branch, depth, g - (1 << depth), root)
+                bad = bytes([leaf[0] ^ 1]) + leaf[1:]
+                assert not ssz.is_valid_merkle_branch(bad, branch, depth, g - (1 << depth), root)
+    with pytest.raises(ssz.MerkleizationError):
+        ssz.generalized_index(T.BeaconBlockBodyDeneb(T.MAINNET), ["graffiti", 40])
+    with pytest.raises(ssz.MerkleizationError):
+        ssz.prove(T.BeaconBlockBodyDeneb(T.MAINNET), enc, ["blob_kzg_commitments", 4095, 3])
+
+
+def test_light_client_branches_of_a_beacon_state(gpu):
+    """The light-client proofs of spec-tests/runners/light_client.rs:32-40 on a BeaconState: current / next sync committee
+    and finalized_checkpoint -> root, from the field roots the state plan computes anyway; against the oracle on a small
+    state and by verification against the state root at 2^17 validators."""
+    from ethereum_consensus_amd import ssz_types as T
+    from ethereum_consensus_amd import synthetic
+    ssz = gpu
+    f = synthetic.state_fields(37, "minimal", seed=4)
+    t = ossz.BeaconStateDeneb(ossz.MINIMAL)
+    v = oracle_state_value(f)
+    enc = synthetic.serialize_state(f)
+    names = [n for n, _ in t.fields]
+    for name in ("current_sync_committee", "next_sync_committee", "finalized_checkpoint", "validators", "slot"):
+        pos = names.index(name)
+        leaf, branch, g, root = ssz.prove_beacon_state_field("deneb", enc, ssz.MINIMAL, pos)
+        assert (leaf, branch, g, root) == ossz.prove(t, v, [name])
+    # finalized_checkpoint -> root: the field's branch continued by a proof inside the 40-byte Checkpoint
+    pos = names.index("finalized_checkpoint")
+    cp_enc = ossz.Checkpoint.serialize(v["finalized_checkpoint"])
+    leaf2, br2, g2, cp_root = ssz.prove(T.Checkpoint, cp_enc, ["root"])
+    leaf, branch, g, root = ssz.prove_beacon_state_field("deneb", enc, ssz.MINIMAL, pos)
+    assert cp_root == leaf
+    full = ossz.prove(t, v, ["finalized_checkpoint", "root"])
+    assert (leaf2, br2 + branch, (g << 1) + (g2 - 2), root) == full and full[2] == 105
+    # mainnet size: branches verify against the state root
+    f = synthetic.state_fields(1 << 17, "mainnet", seed=9)
+    enc = synthetic.serialize_state(f)
+    want_root = ssz.hash_tree_root_beacon_state_deneb(enc, ssz.MAINNET)
+    for pos in (22, 23, 20, 11):
+        leaf, branch, g, root = ssz.prove_beacon_state_field("deneb", enc, ssz.MAINNET, pos)
+        assert root == want_root and g == 32 + pos and ssz.is_valid_merkle_branch(leaf, branch, 5, pos, root)

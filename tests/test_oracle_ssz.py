@@ -136,3 +136,28 @@ def test_subtree_roots_compose_to_the_full_root():
                 # trailing all-zero subtrees (ranks past the end of the list) change nothing
                 if (n_sub + 1) * width <= limit:
                     assert O.merkleize_subtree_roots(subs + [O.merkleize_chunks([], width)], width, limit) == want
+
+
+def test_oracle_proofs_match_the_reference_fixtures():
+    """oracle prove / generalized_index (the checker of the GPU proofs) against what the reference pins: the generalized
+    indices of deneb/beacon_block.rs:139-154 and the sepolia BlobSidecar inclusion branch of deneb/blob_sidecar.rs:70-132
+    (depth 17, subtree index from blob_kzg_commitments[0])."""
+    import random
+    body_t = dict(ssz.BeaconBlockDeneb(ssz.BLOCK_MAINNET).fields)["body"]
+    got = [ssz.generalized_index(body_t, ["blob_kzg_commitments"])] + [ssz.generalized_index(body_t, ["blob_kzg_commitments", i]) for i in range(6)]
+    assert got == [27, 221184, 221185, 221186, 221187, 221188, 221189]
+    # a random body: every proof verifies against the body root with the index arithmetic of deneb/blob_sidecar.rs:56-63
+    from tests import _sszrand
+    r = random.Random(5)
+    v = _sszrand.random_value(body_t, r, fill=0.5)
+    root = body_t.htr(v)
+    for path in (["blob_kzg_commitments", 0], ["execution_payload"], ["eth1_data", "deposit_count"], ["attestations", ssz.LENGTH],
+                 ["execution_payload", "transactions", 0], ["graffiti"], ["sync_aggregate", "sync_committee_bits", 300]):
+        if path[0] == "blob_kzg_commitments" and not v["blob_kzg_commitments"]:
+            continue
+        if path[:2] == ["execution_payload", "transactions"] and not v["execution_payload"]["transactions"]:
+            continue
+        leaf, branch, g, w = ssz.prove(body_t, v, path)
+        assert w == root and g == ssz.generalized_index(body_t, path)
+        depth = g.bit_length() - 1
+        assert len(branch) == depth and ssz.is_valid_merkle_branch(leaf, branch, depth, g - (1 << depth), root)
