@@ -149,12 +149,18 @@ def run_merkle(args, L, torch, dist, rank, world):
 
 
 R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-# Integer multiplies of ONE K = 1 verification, counted on the lane programs themselves (tests/hostsim hs_op_census, valid
-# tuple): (fp_mul calls, fp_sqr calls, multiplies inside sums of products) per stage.  An Fp product is 351 (273 for a
-# square) multiply instructions (v_mad_u64_u32 / v_mul_lo_u32), a sum of N products with one reduction 169 N + 182, see
-# csrc/bls_fp.h.
-BLS_OPS = {"bls_pk_validate": (485, 686, 131040), "bls_sig": (218, 756, 522626), "bls_h2c": (875, 3037, 1189422),
-           "bls_pairing": (651, 382, 7239674)}
+# Integer multiplies of ONE K = 1 verification, counted on the lane programs themselves (tests/hostsim hs_op_census, mean over
+# the first 16 tuples of this workload): (fp_mul calls, fp_sqr calls, multiplies inside sums of products) per stage, for each
+# build of the kernels.  An Fp product is 351 (273 for a square) multiply instructions (v_mad_u64_u32 / v_mul_lo_u32), a sum
+# of N products with one reduction 169 N + 182, see csrc/bls_fp.h.  The census used is the one of the build that RAN
+# (ecgpu_bls_tower(): 1 = sums of products, 2 = compact-code tower over out-of-line Fp products; the key stage is shared).
+BLS_OPS_BY_BUILD = {
+    1: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (218, 756, 522626), "bls_h2c": (768, 2655, 1197430),
+        "bls_pairing": (651, 382, 7239674)},
+    2: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (1476, 756, 0), "bls_h2c": (3718, 2655, 0), "bls_pairing": (19643, 382, 0)},
+}
+BLS_OPS = BLS_OPS_BY_BUILD[1]
+PAIRING_KERNEL_BY_BUILD = {1: "k_pairing", 2: "k_pairing_calls"}
 BLS_MULTS_PER_SIG = sum(m * 351 + s * 273 + x for m, s, x in BLS_OPS.values())
 BLS_BYTES_PER_SIG = 48 + 32 + 96 + 1  # K = 1 tuple in, status byte out
 
@@ -171,33 +177,29 @@ def bls_inputs(n: int, base: int):
     return sks, msgs
 
 
-def cpu_baseline_bls(budget_s: float = 15.0):
+def cpu_baseline_bls(sample, budget_s: float = 20.0):
     """oracle/c/bls12_381.cpp -- the C++ restatement of the blst behaviour (6 x 64-bit Montgomery limbs, unsigned __int128,
-    -O3) -- on 1 and on all host threads, on the first tuples of the same workload (same secret keys, messages and fault
-    cycle; statuses asserted equal to the ones known by construction).  Reported, never the target.  blst itself cannot be
-    built offline; its published figure is ~1.2-1.5 k verifications/s per core, i.e. several times this restatement."""
-    from ethereum_consensus_amd import synthetic as syn
+    -O3) -- on 1 and on all host threads, on the FIRST tuples of the very workload the GPU verified (host copies of the same
+    keys, messages, signatures and fault cycle; statuses asserted equal to the ones known by construction).  Reported, never
+    the target.  blst itself cannot be built offline; its published figure is ~1.2-1.5 k verifications/s per core, i.e.
+    several times this restatement."""
     from oracle import cbls
+    pks, msgs, sigs, want = sample
     nthr = cbls.host_threads()
-    m = 256 * max(1, min(nthr, 8))
-    skb = syn.bls_secret_keys(m)
-    msgs = bytearray(syn.bls_messages(m))
-    sk = [int.from_bytes(skb[32 * i:32 * i + 32], "big") for i in range(m)]
-    pks = bytearray(b"".join(cbls.sk_to_pk(x) for x in sk))
-    sigs = bytearray(b"".join(cbls.sign(x, bytes(msgs[32 * i:32 * i + 32])) for i, x in enumerate(sk)))
-    want, _ = syn.bls_inject_faults(pks, msgs, sigs, m)
-    pks, msgs, sigs = bytes(pks), bytes(msgs), bytes(sigs)
-    t0 = time.time()
-    st = cbls.fast_aggregate_verify_batch_k1(pks, msgs, sigs, nthr)
-    dt_n = time.time() - t0
-    assert st == bytes(want), "C++ restatement disagrees with the statuses known by construction"
-    m1 = min(m, 512)
+    # calibrate on one thread, then size the all-thread sample for ~budget_s / 2 of wall time
+    m1 = min(len(want), 256)
     t0 = time.time()
     st1 = cbls.fast_aggregate_verify_batch_k1(pks[:48 * m1], msgs[:32 * m1], sigs[:96 * m1], 1)
     dt_1 = time.time() - t0
-    assert st1 == bytes(want[:m1])
+    assert st1 == want[:m1], "C++ restatement disagrees with the statuses known by construction"
+    rate1 = m1 / dt_1
+    m = int(min(len(want), max(64 * nthr, rate1 * nthr * budget_s / 2)))
+    t0 = time.time()
+    st = cbls.fast_aggregate_verify_batch_k1(pks[:48 * m], msgs[:32 * m], sigs[:96 * m], nthr)
+    dt_n = time.time() - t0
+    assert st == want[:m], "C++ restatement disagrees with the statuses known by construction"
     return {"value": m / dt_n, "unit": "sigs/s", "cores": nthr, "kind": "port",
-            "one_thread": {"value": m1 / dt_1, "unit": "sigs/s", "cores": 1, "sample": f"first {m1} tuples in {dt_1:.1f} s"},
+            "one_thread": {"value": rate1, "unit": "sigs/s", "cores": 1, "sample": f"first {m1} tuples in {dt_1:.1f} s"},
             "sample": f"first {m} K = 1 tuples of the same workload (fault cycle included, statuses equal to construction) in {dt_n:.1f} s on "
                       f"{nthr} threads; oracle/c/bls12_381.cpp, g++ -O3 -march=x86-64-v3, 6 x 64-bit limbs with unsigned __int128 "
                       "(blst itself is not available offline: ~1.2-1.5 k/s per core published)"}
@@ -255,8 +257,12 @@ def run_bls(args, L, torch, dist, rank, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    build = int(L.ecgpu_bls_tower())
+    ops = BLS_OPS_BY_BUILD.get(build, BLS_OPS)
+    pairing_kernel = PAIRING_KERNEL_BY_BUILD.get(build, "k_pairing")
+    mults_per_sig = sum(m * 351 + s_ * 273 + x for m, s_, x in ops.values())
     stages = {}
-    for tag in BLS_OPS:
+    for tag in ops:
         ms, cnt = _prof(L, tag)
         stages[tag] = ms / max(cnt, 1)
     L.ecgpu_prof_enable(0)
@@ -268,8 +274,11 @@ def run_bls(args, L, torch, dist, rank, world):
     kern_ms = stages[dom]
     alg_bytes = BLS_BYTES_PER_SIG * n
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    mul_ops = {k: (m * 351 + s * 273 + x) * n for k, (m, s, x) in BLS_OPS.items()}
+    mul_ops = {k: (m * 351 + s_ * 273 + x) * n for k, (m, s_, x) in ops.items()}
+    traffic = pmc_traffic(pairing_kernel)  # None unless a PMC pass of THIS kernel build is committed under profiles/
+    m_cpu = min(n, 16384)
     return dict(
+        host_sample=(bytes(h_pk[:48 * m_cpu]), bytes(msgs[:32 * m_cpu]), bytes(h_sig[:96 * m_cpu]), bytes(want_bytes[:m_cpu])),
         dt=dt, units_per_step=n, metric="bls_signatures_verified_per_sec", unit="sigs/s", dtype="u32",
         config={"workload": f"fast_aggregate_verify of {n} synthetic (pk, msg, sig) tuples, K = 1, 32-byte messages, "
                             "1/64 tuples corrupted, cycling through 8 fault classes (wrong message, swapped key, signature outside G2, key "
@@ -278,14 +287,16 @@ def run_bls(args, L, torch, dist, rank, world):
                 "tuples": n, "semantics": "reference: every key decompressed + subgroup-checked, every signature "
                                           "decompressed + subgroup-checked, every message hashed to G2, per-tuple pairing check",
                 "sharding": "one independent batch per GPU; all-gather of the status bytes every step"},
-        roofline={"bound": "hbm", "kernel": "k_pairing", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": achieved / HBM_PEAK_GBS, "traffic": (pmc_traffic("k_pairing") or {}).get("bytes_per_launch"), "traffic_detail": pmc_traffic("k_pairing"),
+        roofline={"bound": "hbm", "kernel": pairing_kernel, "kernel_build": {1: "sums of products", 2: "compact-code tower"}.get(build, "?"),
+                  "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"), "traffic_detail": traffic,
                   "algorithmic_bytes_per_launch": alg_bytes,
                   "avg_launch_ms": kern_ms, "stage_ms": stages,
                   "valu_int": {"unit": "T multiplies/s (v_mad_u64_u32 + v_mul_lo_u32)", "peak": MUL_PIPE_PEAK_TOPS,
                                "achieved": {k: (mul_ops[k] / (stages[k] * 1e-3) / 1e12 if stages[k] > 0 else 0.0) for k in stages},
-                               "note": f"the path is integer-multiplier bound, not HBM bound: {BLS_MULTS_PER_SIG / 1e6:.1f} M multiplies vs 177 B per "
-                                       "signature"}},
+                               "multiplies_per_signature": mults_per_sig,
+                               "note": f"the path is integer-multiplier bound, not HBM bound: {mults_per_sig / 1e6:.1f} M multiplies vs 177 B per "
+                                       "signature (census of the kernel build that ran)"}},
         check={"statuses_match_construction": ok, "expected_failures": int(want.astype(bool).sum())},
     )
 
@@ -654,11 +665,12 @@ def main():
     if workload == "slots":
         line = finish(run_slots(args, L, torch, dist, rank, world))
     if workload in ("bls", "both"):
-        line = finish(run_bls(args, L, torch, dist, rank, world))
+        r_bls = run_bls(args, L, torch, dist, rank, world)
+        line = finish(r_bls)
         if world == 1 and not args.no_aggregates:
             line["aggregates_k2048"] = run_bls_aggregate(args, L, torch, dist, rank, world)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_bls()
+            line["cpu_baseline"] = cpu_baseline_bls(r_bls["host_sample"])
     if workload in ("merkle", "both"):
         r = run_merkle(args, L, torch, dist, rank, world)
         r["check"] = {"root": r.get("root")}

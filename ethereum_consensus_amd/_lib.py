@@ -39,6 +39,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     sig = {
         "ecgpu_init": (c_int, [c_int]),
         "ecgpu_device_count": (c_int, []),
+        "ecgpu_bind_thread": (c_int, [c_int]),
+        "ecgpu_fast_aggregate_verify_batch_multi": (c_int, [ctypes.c_void_p, c_u32, u8p, ctypes.c_void_p, u8p, u8p, c_u32, c_int, u8p]),
+        "ecgpu_htr_validators_multi": (c_int, [ctypes.c_void_p, c_u32, u8p, c_u64, c_u64, u8p]),
         "ecgpu_version": (ctypes.c_char_p, []),
         "ecgpu_last_error": (ctypes.c_char_p, []),
         "ecgpu_sha256": (c_int, [u8p, c_size, u8p]),
@@ -65,6 +68,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_resident_state_create": (c_int, [c_int, u8p, c_u64, ctypes.POINTER(ctypes.c_void_p)]),
         "ecgpu_resident_state_destroy": (None, [ctypes.c_void_p]),
         "ecgpu_resident_state_patch": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, u8p, c_u32]),
+        "ecgpu_resident_state_append": (c_int, [ctypes.c_void_p, c_int, u8p, c_u64]),
+        "ecgpu_resident_state_truncate": (c_int, [ctypes.c_void_p, c_int, c_u64]),
+        "ecgpu_resident_state_size": (c_u64, [ctypes.c_void_p]),
         "ecgpu_resident_state_root": (c_int, [ctypes.c_void_p, u8p]),
         "ecgpu_resident_state_root_dev": (c_int, [ctypes.c_void_p, u8p, ctypes.c_void_p]),
         "ecgpu_compute_shuffled_indices": (c_int, [ctypes.c_void_p, c_u64, u8p, c_u32, ctypes.c_void_p]),

@@ -324,3 +324,17 @@ class SignatureBatch:
             except Error as e:
                 out.append(e)
         return out
+
+
+def fast_aggregate_verify_batch_multi(devices: Sequence[int], public_keys: bytes, pk_offsets, msgs32: bytes, signatures: bytes,
+                                      eth: bool = False) -> bytes:
+    """`fast_aggregate_verify_batch` sharded over several GPUs of this process (one host thread per device inside the
+    library).  Same statuses as the single-device call."""
+    L = _lib.load()
+    n = len(signatures) // 96
+    off = (ctypes.c_uint32 * (n + 1))(*pk_offsets) if pk_offsets is not None else None
+    devs = (ctypes.c_int * len(devices))(*devices)
+    out = ctypes.create_string_buffer(max(n, 1))
+    _lib.check(L.ecgpu_fast_aggregate_verify_batch_multi(devs, len(devices), _buf(public_keys), off, _buf(msgs32), _buf(signatures), n,
+                                                         1 if eth else 0, out), "ecgpu_fast_aggregate_verify_batch_multi")
+    return out.raw[:n]

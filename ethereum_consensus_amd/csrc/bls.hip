@@ -23,6 +23,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 #include <cstring>
 
@@ -753,6 +755,51 @@ int ecgpu_batch_flush(ecgpu_batch_t* b, uint8_t* status_out, uint32_t capacity) 
     b->idx.clear();
     b->n = 0;
     return rc;
+}
+
+// ---- several GPUs in one process --------------------------------------------------------------------------
+// Tuples are independent: shard g gets a contiguous range and runs the whole pipeline on devices[g] from a host thread of
+// its own (bound with ecgpu_bind_thread); every shard writes its statuses straight into the caller's array -- in ONE
+// process the "all-gather of the verify booleans" is that shared host buffer.  (One process per GPU exchanges the same bytes
+// with RCCL: ethereum_consensus_amd/shard.py.)
+int ecgpu_fast_aggregate_verify_batch_multi(const int* devices, uint32_t n_devices, const uint8_t* pks48, const uint32_t* pk_off,
+                                            const uint8_t* msgs32, const uint8_t* sigs96, uint32_t n, int eth_variant,
+                                            uint8_t* status_out) {
+    if (!devices || n_devices == 0 || n_devices > (uint32_t)MAX_DEVICES || (n && (!msgs32 || !sigs96 || !status_out))) return ECGPU_ERR_BAD_ARG;
+    if (pk_off)
+        for (u32 i = 0; i < n; i++)
+            if (pk_off[i + 1] < pk_off[i]) return ECGPU_ERR_BAD_ARG;
+    const u32 per = (n + n_devices - 1) / n_devices;
+    std::vector<int> rcs(n_devices, 0);
+    std::vector<std::string> errs(n_devices);
+    std::vector<std::thread> th;
+    for (u32 g = 0; g < n_devices; g++) {
+        const u32 lo = g * per < n ? g * per : n, hi = (g + 1) * per < n ? (g + 1) * per : n;
+        if (lo == hi) continue;
+        th.emplace_back([=, &rcs, &errs] {
+            int rc = ecgpu_bind_thread(devices[g]);
+            if (!rc) {
+                if (pk_off) {
+                    std::vector<u32> off(hi - lo + 1);
+                    for (u32 i = lo; i <= hi; i++) off[i - lo] = pk_off[i] - pk_off[lo];
+                    rc = fav_batch_host(pks48 + 48ull * pk_off[lo], off.data(), off.back(), msgs32 + 32ull * lo, nullptr, 32ull * (hi - lo),
+                                        sigs96 + 96ull * lo, hi - lo, eth_variant, status_out + lo);
+                } else {
+                    rc = fav_batch_host(pks48 + 48ull * lo, nullptr, hi - lo, msgs32 + 32ull * lo, nullptr, 32ull * (hi - lo), sigs96 + 96ull * lo,
+                                        hi - lo, eth_variant, status_out + lo);
+                }
+            }
+            rcs[g] = rc;
+            if (rc) errs[g] = ecgpu_last_error();
+        });
+    }
+    for (auto& t : th) t.join();
+    for (u32 g = 0; g < n_devices; g++)
+        if (rcs[g]) {
+            set_last_error("device shard " + std::to_string(g) + ": " + errs[g]);
+            return rcs[g];
+        }
+    return ECGPU_SUCCESS;
 }
 
 int ecgpu_bls_last_pairing_path(void) { return ecg::t_last_pairing_path; }

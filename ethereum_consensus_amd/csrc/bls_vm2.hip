@@ -31,7 +31,9 @@ struct Vm2Desc {
     u32 rounds, nreg, nconst, nin, nout;
     u32 in_reg[8], out_reg[8];
 };
-static Vm2Desc g_vm2_a, g_vm2_c;
+static Vm2Desc g_vm2_a_dev[MAX_DEVICES], g_vm2_c_dev[MAX_DEVICES];  // program tables live in each device's memory
+#define g_vm2_a g_vm2_a_dev[current_device()]
+#define g_vm2_c g_vm2_c_dev[current_device()]
 
 static int upload_u32(const unsigned int* h, size_t n, const u32** d) {
     u32* p = nullptr;

@@ -1,4 +1,7 @@
 // gfx950 SHA-256 Merkle kernels + host driver + C ABI entry points (see include/ecgpu.h).
+#include <thread>
+#include <vector>
+
 #include "merkle_driver.h"
 
 #include <cstring>
@@ -22,11 +25,11 @@ __global__ void k_init_zero_table() {
     }
 }
 
-static ZeroTable* g_zero_table_ptr = nullptr;
-const ZeroTable* device_zero_table() { return g_zero_table_ptr; }
+static ZeroTable* g_zero_table_ptr[MAX_DEVICES] = {};  // the __device__ table has one instance per device
+const ZeroTable* device_zero_table() { return g_zero_table_ptr[current_device()]; }
 
 int init_merkle_tables(hipStream_t s) {
-    ECG_HIP_CHECK(hipGetSymbolAddress((void**)&g_zero_table_ptr, HIP_SYMBOL(g_zero_table)));
+    ECG_HIP_CHECK(hipGetSymbolAddress((void**)&g_zero_table_ptr[current_device()], HIP_SYMBOL(g_zero_table)));
     hipLaunchKernelGGL(k_init_zero_table, dim3(1), dim3(64), 0, s);
     ECG_HIP_CHECK(hipGetLastError());
     return ECGPU_SUCCESS;
@@ -541,6 +544,37 @@ int ecgpu_sha256_batch(const uint8_t* data, size_t len, uint64_t n, uint8_t* out
 }
 
 int ecgpu_sha256(const uint8_t* data, size_t len, uint8_t out[32]) { return ecgpu_sha256_batch(data, len, 1, out); }
+
+// One big list over several GPUs of ONE process (second row): device g reduces the aligned subtree of W
+// validators starting at g W on a host thread bound to it, the 32-byte sub-roots meet in host memory (the exchange step),
+// and the first device finishes the top of the tree.
+int ecgpu_htr_validators_multi(const int* devices, uint32_t n_devices, const uint8_t* ssz121, uint64_t n, uint64_t limit, uint8_t root[32]) {
+    if (!devices || n_devices == 0 || n_devices > (uint32_t)MAX_DEVICES || (!ssz121 && n) || !root || n > limit) return ECGPU_ERR_BAD_ARG;
+    u64 W = 1;
+    while (W * n_devices < n) W <<= 1;
+    const u32 n_sub = n ? (u32)((n + W - 1) / W) : 0;
+    std::vector<u8> sub(32ull * (n_sub ? n_sub : 1));
+    std::vector<int> rcs(n_devices, 0);
+    std::vector<std::thread> th;
+    for (u32 g = 0; g < n_sub; g++) {
+        th.emplace_back([=, &rcs, &sub] {
+            int rc = ecgpu_bind_thread(devices[g]);
+            const u64 lo = g * W, cnt = n - lo < W ? n - lo : W;
+            if (!rc) rc = ecgpu_validators_subtree_root(ssz121 + 121 * lo, cnt, W, sub.data() + 32ull * g);
+            rcs[g] = rc;
+        });
+    }
+    for (auto& t : th) t.join();
+    for (u32 g = 0; g < n_sub; g++)
+        if (rcs[g]) return rcs[g];
+    int rc = 0;  // the top of the tree on devices[0], again on a thread of its own: the caller's binding is left alone
+    std::thread top([&] {
+        rc = ecgpu_bind_thread(devices[0]);
+        if (!rc) rc = ecgpu_merkleize_subtree_roots(sub.data(), n_sub, W, limit, 1, n, root);
+    });
+    top.join();
+    return rc;
+}
 
 int ecgpu_is_valid_merkle_branch(const uint8_t leaf[32], const uint8_t* branch, uint32_t depth, uint64_t index,
                                  const uint8_t root[32]) {

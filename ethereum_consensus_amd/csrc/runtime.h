@@ -68,7 +68,9 @@ struct ThreadCtx {
     Arena& arena(hipStream_t s) { return arenas[s]; }
 };
 
-int ensure_init();          // ECGPU_SUCCESS or ECGPU_ERR_NO_DEVICE
+constexpr int MAX_DEVICES = 16;
+int current_device();       // the device the calling thread is bound to (ecgpu_bind_thread; default: the process's first)
+int ensure_init();          // ECGPU_SUCCESS or ECGPU_ERR_NO_DEVICE; binds the thread to current_device()
 ThreadCtx* tctx();          // per-thread context (after ensure_init)
 
 // kernel timing with HIP events on the launch stream

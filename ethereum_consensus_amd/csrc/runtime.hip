@@ -11,10 +11,38 @@ void set_last_error(const std::string& s) { t_last_error = s; }
 
 static std::mutex g_init_mu;
 static std::atomic<int> g_init_state{0};  // 0 = not tried, 1 = ok, -1 = no device
-static int g_device = -1;
+static int g_device = -1;                 // the process default: the device of the first ecgpu_init
+// Several GPUs in ONE process (a Rust host has no torch.distributed): a host thread may bind itself to any device
+// (ecgpu_bind_thread); device tables, streams and arenas exist per device, handles (registry, resident state, batch results)
+// belong to the device their creating thread was bound to.
+static thread_local int t_device = -1;
+static std::atomic<int> g_dev_state[MAX_DEVICES];
+int current_device() { return t_device >= 0 ? t_device : g_device; }
 
 int init_merkle_tables(hipStream_t s);  // merkle.hip
 int init_bls_tables(hipStream_t s);     // bls.hip
+
+// tables of one device (zero-hash ladder, lane-group programs); g_init_mu held
+static int init_device_locked(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return ECGPU_ERR_BAD_ARG;
+    if (g_dev_state[device].load() == 1) return ECGPU_SUCCESS;
+    ECG_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ECG_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_last_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return ECGPU_ERR_NO_DEVICE;
+    }
+    const int saved = t_device;
+    t_device = device;  // the table builders address "the current device"
+    int rc = init_merkle_tables(nullptr);
+    if (!rc) rc = init_bls_tables(nullptr);
+    t_device = saved;
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipDeviceSynchronize());
+    g_dev_state[device].store(1);
+    return ECGPU_SUCCESS;
+}
 
 static int do_init(int device) {
     std::lock_guard<std::mutex> lk(g_init_mu);
@@ -33,39 +61,40 @@ static int do_init(int device) {
         set_last_error("device index out of range");
         return ECGPU_ERR_BAD_ARG;
     }
-    ECG_HIP_CHECK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    ECG_HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        set_last_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-        g_init_state.store(-1);
-        return ECGPU_ERR_NO_DEVICE;
-    }
     g_device = device;
-    int rc = init_merkle_tables(nullptr);
-    if (rc) return rc;
-    rc = init_bls_tables(nullptr);
-    if (rc) return rc;
-    ECG_HIP_CHECK(hipDeviceSynchronize());
+    int rc = init_device_locked(device);
+    if (rc) {
+        if (rc == ECGPU_ERR_NO_DEVICE) g_init_state.store(-1);
+        return rc;
+    }
     g_init_state.store(1);
     return ECGPU_SUCCESS;
 }
 
 int ensure_init() {
-    int st = g_init_state.load();
-    if (st == 1) {
-        // bind this thread to the library's device
-        int cur = -1;
-        if (hipGetDevice(&cur) == hipSuccess && cur != g_device) (void)hipSetDevice(g_device);
-        return ECGPU_SUCCESS;
+    if (g_init_state.load() != 1) {
+        int rc = do_init(-1);
+        if (rc) return rc;
     }
-    return do_init(-1);
+    // bind this thread to its device (the process default unless ecgpu_bind_thread chose another)
+    const int dev = current_device();
+    if (g_dev_state[dev].load() != 1) {
+        std::lock_guard<std::mutex> lk(g_init_mu);
+        int rc = init_device_locked(dev);
+        if (rc) return rc;
+    }
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != dev) ECG_HIP_CHECK(hipSetDevice(dev));
+    return ECGPU_SUCCESS;
 }
 
-static thread_local ThreadCtx* t_ctx = nullptr;
+// per (host thread, device): streams and arenas are device objects
+static thread_local std::map<int, ThreadCtx*>* t_ctxs = nullptr;
 ThreadCtx* tctx() {
-    if (!t_ctx) t_ctx = new ThreadCtx();  // lives for the thread; a handful of bytes + arenas
-    return t_ctx;
+    if (!t_ctxs) t_ctxs = new std::map<int, ThreadCtx*>();  // lives for the thread; a handful of bytes + arenas
+    ThreadCtx*& c = (*t_ctxs)[current_device()];
+    if (!c) c = new ThreadCtx();
+    return c;
 }
 
 hipStream_t ThreadCtx::stream_or_own(ecgpu_stream_t s) {
@@ -160,6 +189,18 @@ extern "C" {
 int ecgpu_init(int device) {
     if (g_init_state.load() == 1) return ensure_init();
     return do_init(device);
+}
+
+int ecgpu_bind_thread(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ECGPU_ERR_NO_DEVICE;
+    if (device < 0 || device >= n || device >= MAX_DEVICES) return ECGPU_ERR_BAD_ARG;
+    if (g_init_state.load() != 1) {
+        int rc = do_init(device);
+        if (rc) return rc;
+    }
+    t_device = device;
+    return ensure_init();
 }
 
 int ecgpu_device_count(void) {

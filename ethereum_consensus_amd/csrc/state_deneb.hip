@@ -181,8 +181,10 @@ __global__ void k_apply_patches(u8* state, const u8* data, const PatchDesc* p) {
 struct ecgpu_resident_state {
     int preset = 0;
     int fork = ecg::FORK_DENEB;
-    u8* d_ssz = nullptr;   // encoding + 64 bytes of slack + the root
-    u64 n_bytes = 0;
+    u8* d_ssz = nullptr;   // encoding (cap_bytes allocated: lists grow in place, ecgpu_resident_state_append)
+    u64 n_bytes = 0, cap_bytes = 0;
+    u8* d_rootbuf = nullptr;  // 64 bytes: where the host-pointer root entry leaves its result
+    u64 vroots_cap = 0;       // validator-root cache capacity (records)
     std::vector<u8> h_fixed;  // host mirror of the fixed-size part (offsets and small fields): what the plan reads
     // SURVEY.md 8f rank 2, first level: the root of every validator record, kept current by the patches.  93 % of a state
     // root's hash64 are these 8 per validator, and a slot touches a handful of records.
@@ -222,22 +224,154 @@ int ecgpu_resident_state_create_fork(int fork, int preset, const uint8_t* ssz, u
     st->fork = fork;
     st->n_bytes = n_bytes;
     st->h_fixed.assign(ssz, ssz + layout_for(STATE_PRESETS[preset], fork).size);
-    ECG_HIP_CHECK(hipMalloc((void**)&st->d_ssz, n_bytes + 128));
+    st->cap_bytes = n_bytes + (n_bytes >> 6) + (1u << 16);  // room for ~1.5 % growth before the buffer is reallocated
+    ECG_HIP_CHECK(hipMalloc((void**)&st->d_ssz, st->cap_bytes));
+    ECG_HIP_CHECK(hipMalloc((void**)&st->d_rootbuf, 64));
     ECG_HIP_CHECK(hipMemcpy(st->d_ssz, ssz, n_bytes, hipMemcpyHostToDevice));
     for (const BigField& b : plan.bigs)
         if (b.kind == LEAF_VALIDATORS) {
             st->vals_off = b.src;
             st->n_vals = b.n0;
         }
-    if (st->n_vals) ECG_HIP_CHECK(hipMalloc((void**)&st->d_vroots, 32 * st->n_vals));
+    st->vroots_cap = st->n_vals + (st->n_vals >> 6) + 1024;
+    ECG_HIP_CHECK(hipMalloc((void**)&st->d_vroots, 32 * st->vroots_cap));
     *out = st;
     return ECGPU_SUCCESS;
 }
+
+// ---- lists that change length (add_validator_to_registry, phase0/block_processing.rs:317-349; the eth1_data_votes reset of
+// process_eth1_data_reset; historical_summaries growing once per period) ------------------------------------------------------
+namespace {
+// variable-size fields of the state in encoding order: position of the offset word in the fixed part, element size
+struct VarField {
+    u64 word;
+    u32 elem;
+};
+static int var_fields(const ecgpu_resident_state* st, VarField out[9]) {
+    const FixedLayout L = layout_for(STATE_PRESETS[st->preset], st->fork);
+    const VarField f[9] = {{L.historical_roots_off, 32}, {L.eth1_data_votes_off, 72}, {L.validators_off, 121}, {L.balances_off, 8},
+                           {L.prev_participation_off, 1}, {L.cur_participation_off, 1}, {L.inactivity_scores_off, 8},
+                           {L.payload_header_off, 0}, {L.historical_summaries_off, 64}};
+    for (int i = 0; i < 9; i++) out[i] = f[i];
+    return 9;
+}
+static void wr32(u8* p, u32 v) {
+    p[0] = (u8)v, p[1] = (u8)(v >> 8), p[2] = (u8)(v >> 16), p[3] = (u8)(v >> 24);
+}
+// replace bytes [pos, pos + remove) of the encoding by `insert_len` bytes (host pointer); the tail moves on the device
+static int splice(ecgpu_resident_state* st, hipStream_t s, Arena& ar, u64 pos, u64 remove, const u8* insert, u64 insert_len) {
+    const u64 tail = st->n_bytes - (pos + remove), new_bytes = st->n_bytes - remove + insert_len;
+    if (new_bytes > 0xffffffffull) return ECGPU_ERR_BAD_ARG;  // SSZ offsets are 32 bits
+    if (new_bytes > st->cap_bytes) {
+        const u64 cap = new_bytes + (new_bytes >> 5) + (1u << 16);
+        u8* nb = nullptr;
+        ECG_HIP_CHECK(hipMalloc((void**)&nb, cap));
+        ECG_HIP_CHECK(hipMemcpyAsync(nb, st->d_ssz, pos, hipMemcpyDeviceToDevice, s));
+        if (tail) ECG_HIP_CHECK(hipMemcpyAsync(nb + pos + insert_len, st->d_ssz + pos + remove, tail, hipMemcpyDeviceToDevice, s));
+        ECG_HIP_CHECK(hipStreamSynchronize(s));
+        ECG_HIP_CHECK(hipFree(st->d_ssz));
+        st->d_ssz = nb;
+        st->cap_bytes = cap;
+    } else if (tail && remove != insert_len) {
+        ar.reset();
+        int rc = ar.reserve(tail + 4096);  // overlapping move: through a temporary
+        if (rc) return rc;
+        u8* tmp = ar.take(tail);
+        ECG_HIP_CHECK(hipMemcpyAsync(tmp, st->d_ssz + pos + remove, tail, hipMemcpyDeviceToDevice, s));
+        ECG_HIP_CHECK(hipMemcpyAsync(st->d_ssz + pos + insert_len, tmp, tail, hipMemcpyDeviceToDevice, s));
+    }
+    if (insert_len) ECG_HIP_CHECK(hipMemcpyAsync(st->d_ssz + pos, insert, insert_len, hipMemcpyHostToDevice, s));
+    st->n_bytes = new_bytes;
+    return ECGPU_SUCCESS;
+}
+// change the byte length of variable field `fi` to new_len (append `data` when it grows, drop the tail when it shrinks)
+static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 add_len, u64 new_len_or_keep, bool truncate) {
+    VarField vf[9];
+    var_fields(st, vf);
+    if (fi < 0 || fi >= 9 || vf[fi].word == NO_FIELD || vf[fi].elem == 0) {
+        set_last_error("not a variable-length list of this fork");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    const u64 start = rd32(st->h_fixed.data() + vf[fi].word);
+    u64 end = st->n_bytes;
+    for (int k = fi + 1; k < 9; k++)
+        if (vf[k].word != NO_FIELD) {
+            end = rd32(st->h_fixed.data() + vf[k].word);
+            break;
+        }
+    const u64 cur = end - start;
+    u64 pos, remove, insert;
+    if (truncate) {
+        if (new_len_or_keep > cur || new_len_or_keep % vf[fi].elem) return ECGPU_ERR_BAD_ARG;
+        pos = start + new_len_or_keep, remove = cur - new_len_or_keep, insert = 0;
+    } else {
+        if (add_len % vf[fi].elem || (!data && add_len)) return ECGPU_ERR_BAD_ARG;
+        pos = end, remove = 0, insert = add_len;
+    }
+    if (remove == 0 && insert == 0) return ECGPU_SUCCESS;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    int rc = splice(st, s, c->arena(s), pos, remove, data, insert);
+    if (rc) return rc;
+    // later fields start `insert - remove` bytes later: their offset words change on the host mirror and on the device
+    const int64_t delta = (int64_t)insert - (int64_t)remove;
+    for (int k = fi + 1; k < 9; k++)
+        if (vf[k].word != NO_FIELD) {
+            const u32 v = (u32)((int64_t)rd32(st->h_fixed.data() + vf[k].word) + delta);
+            wr32(st->h_fixed.data() + vf[k].word, v);
+            ECG_HIP_CHECK(hipMemcpyAsync(st->d_ssz + vf[k].word, st->h_fixed.data() + vf[k].word, 4, hipMemcpyHostToDevice, s));
+        }
+    // the validator-root cache follows the registry
+    const u64 old_vals_off = st->vals_off, old_n = st->n_vals;
+    st->vals_off = rd32(st->h_fixed.data() + vf[2].word);
+    (void)old_vals_off;
+    if (fi == 2) {
+        const u64 new_n = truncate ? new_len_or_keep / 121 : old_n + add_len / 121;
+        if (new_n > st->vroots_cap) {
+            const u64 cap = new_n + (new_n >> 5) + 1024;
+            u8* nv = nullptr;
+            ECG_HIP_CHECK(hipMalloc((void**)&nv, 32 * cap));
+            if (old_n && !st->all_dirty) ECG_HIP_CHECK(hipMemcpyAsync(nv, st->d_vroots, 32 * old_n, hipMemcpyDeviceToDevice, s));
+            ECG_HIP_CHECK(hipStreamSynchronize(s));
+            ECG_HIP_CHECK(hipFree(st->d_vroots));
+            st->d_vroots = nv;
+            st->vroots_cap = cap;
+        }
+        for (u64 v = old_n; v < new_n && !st->all_dirty; v++) st->dirty.push_back((u32)v);
+        if (truncate) {
+            std::vector<u32> keep;
+            for (u32 v : st->dirty)
+                if (v < new_n) keep.push_back(v);
+            st->dirty.swap(keep);
+        }
+        st->n_vals = new_n;
+    }
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    return ECGPU_SUCCESS;
+}
+}  // namespace
+
+int ecgpu_resident_state_append(ecgpu_resident_state_t* st, int field, const uint8_t* data, uint64_t n_bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!st) return ECGPU_ERR_BAD_ARG;
+    return resize_field(st, field, data, n_bytes, 0, false);
+}
+
+int ecgpu_resident_state_truncate(ecgpu_resident_state_t* st, int field, uint64_t new_n_bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!st) return ECGPU_ERR_BAD_ARG;
+    return resize_field(st, field, nullptr, 0, new_n_bytes, true);
+}
+
+uint64_t ecgpu_resident_state_size(const ecgpu_resident_state_t* st) { return st ? st->n_bytes : 0; }
 
 void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st) {
     if (!st) return;
     (void)hipDeviceSynchronize();
     (void)hipFree(st->d_ssz);
+    (void)hipFree(st->d_rootbuf);
     (void)hipFree(st->d_vroots);
     (void)hipFree(st->d_idx[0]);
     (void)hipFree(st->d_idx[1]);
@@ -373,7 +507,7 @@ int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
     if (rc) return rc;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
-    u8* d_root = st->d_ssz + ((st->n_bytes + 31) / 32) * 32 + 32;
+    u8* d_root = st->d_rootbuf;
     rc = refresh_validator_roots(st, s, c);
     if (rc) return rc;
     rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots, st->fork);
@@ -460,8 +594,13 @@ static int beacon_state_host(int fork, const uint8_t* ssz, uint64_t n_bytes, int
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
     // the encoding lives in its own allocation (the arena is rebuilt by the driver)
-    static thread_local u8* d_state = nullptr;
-    static thread_local size_t d_state_cap = 0;
+    struct StateBuf {
+        u8* p = nullptr;
+        size_t cap = 0;
+    };
+    static thread_local std::map<int, StateBuf> bufs;  // per (host thread, device)
+    u8*& d_state = bufs[current_device()].p;
+    size_t& d_state_cap = bufs[current_device()].cap;
     if (n_bytes + 64 > d_state_cap) {
         if (d_state) {
             ECG_HIP_CHECK(hipStreamSynchronize(s));

@@ -54,6 +54,15 @@ def hash_tree_root_validators(ssz121: bytes, limit: int = VALIDATOR_REGISTRY_LIM
     return _root(L.ecgpu_htr_validators, _buf(ssz121), len(ssz121) // 121, limit)
 
 
+def hash_tree_root_validators_multi(devices, ssz121: bytes, limit: int = VALIDATOR_REGISTRY_LIMIT) -> bytes:
+    """hash_tree_root(List<Validator, limit>) with the registry sharded over several GPUs of this process."""
+    if len(ssz121) % 121:
+        raise MerkleizationError("validator encoding is not a multiple of 121 bytes")
+    L = _lib.load()
+    devs = (ctypes.c_int * len(devices))(*devices)
+    return _root(L.ecgpu_htr_validators_multi, devs, len(devices), _buf(ssz121), len(ssz121) // 121, limit)
+
+
 def validators_subtree_root(ssz121: bytes, width: int) -> bytes:
     """One shard's share of a sharded `List<Validator, N>`: root of the aligned subtree of `width`
     validators (a power of two), no length mix-in."""
@@ -158,6 +167,33 @@ class ResidentBeaconStateDeneb:
         if rc == -3:
             raise MerkleizationError((self._L.ecgpu_last_error() or b"bad patch").decode())
         _lib.check(rc, "ecgpu_resident_state_patch")
+
+    VALIDATORS, BALANCES, PREVIOUS_EPOCH_PARTICIPATION, CURRENT_EPOCH_PARTICIPATION, INACTIVITY_SCORES = 2, 3, 4, 5, 6
+    HISTORICAL_ROOTS, ETH1_DATA_VOTES, HISTORICAL_SUMMARIES = 0, 1, 8
+
+    def append(self, field: int, data: bytes) -> None:
+        """whole elements appended to a variable-length list of the state (a new validator = five appends)"""
+        rc = self._L.ecgpu_resident_state_append(self._h, field, _buf(data), len(data))
+        if rc == -3:
+            raise MerkleizationError((self._L.ecgpu_last_error() or b"bad append").decode())
+        _lib.check(rc, "ecgpu_resident_state_append")
+
+    def truncate(self, field: int, new_n_bytes: int) -> None:
+        rc = self._L.ecgpu_resident_state_truncate(self._h, field, new_n_bytes)
+        if rc == -3:
+            raise MerkleizationError((self._L.ecgpu_last_error() or b"bad truncate").decode())
+        _lib.check(rc, "ecgpu_resident_state_truncate")
+
+    def add_validator(self, validator121: bytes, balance: int) -> None:
+        """add_validator_to_registry (phase0/block_processing.rs:317-349, altair form: + participation flags, inactivity score)"""
+        self.append(self.VALIDATORS, validator121)
+        self.append(self.BALANCES, int(balance).to_bytes(8, "little"))
+        self.append(self.PREVIOUS_EPOCH_PARTICIPATION, b"\x00")
+        self.append(self.CURRENT_EPOCH_PARTICIPATION, b"\x00")
+        self.append(self.INACTIVITY_SCORES, bytes(8))
+
+    def __len__(self):
+        return int(self._L.ecgpu_resident_state_size(self._h))
 
     def hash_tree_root(self) -> bytes:
         return _root(self._L.ecgpu_resident_state_root, self._h)

@@ -35,6 +35,10 @@ typedef void* ecgpu_stream_t; /* a hipStream_t */
  * tables (zero-hash ladder, BLS constants).  Idempotent. */
 int ecgpu_init(int device);
 int ecgpu_device_count(void);
+/* Several GPUs in one process (a Rust host has no torch.distributed): bind the calling host thread to `device`; every later
+ * call of this thread runs there (tables, streams and workspaces exist per device; a registry / resident state / batch
+ * belongs to the device of the thread that created it).  The *_multi entries below do this on threads of their own. */
+int ecgpu_bind_thread(int device);
 const char* ecgpu_version(void);
 const char* ecgpu_last_error(void); /* thread-local description of the last negative return */
 
@@ -70,6 +74,11 @@ int ecgpu_merkleize_subtree_roots(const uint8_t* sub_roots, uint32_t n_sub, uint
                                   uint64_t len, uint8_t root[32]);
 int ecgpu_merkleize_subtree_roots_dev(const uint8_t* d_sub_roots, uint32_t n_sub, uint64_t width, uint64_t limit,
                                       int mix_in_len, uint64_t len, uint8_t* d_root, ecgpu_stream_t stream);
+
+/* hash_tree_root(List<Validator, limit>) with the registry sharded over `n_devices` GPUs of this process: aligned subtrees
+ * on one host thread per device, sub-roots exchanged through host memory, top of the tree on devices[0]. */
+int ecgpu_htr_validators_multi(const int* devices, uint32_t n_devices, const uint8_t* ssz121, uint64_t n, uint64_t limit,
+                               uint8_t root[32]);
 
 /* hash_tree_root(BeaconBlockHeader) from its 112-byte SSZ encoding (phase0/beacon_block.rs:83-91;
  * called at phase0/slot_processing.rs:75, block_processing.rs:579). */
@@ -116,7 +125,7 @@ uint64_t ecgpu_last_hash64_count(void);
  * (phase0/slot_processing.rs:67); shipping 148 MB of serialization over PCIe per slot would cost more than hashing
  * it.  A resident state is uploaded once; afterwards only the bytes a block changed travel: `patch` overwrites byte
  * ranges of the encoding in place (same total length: field values, balances, participation flags, roots ...),
- * `root` re-Merkleizes on the device.  A change of length (a new validator) needs `create` again.  One resident
+ * `root` re-Merkleizes on the device; lists change length through `append` / `truncate` below.  One resident
  * state must not be used from two threads at once.  The state also caches hash_tree_root(Validator) of every record
  * (32 B each): a patch marks the records its bytes belong to, `root` re-hashes only those and feeds the registry to the
  * tree as ready chunks (first level) -- same roots, half the time. */
@@ -128,6 +137,22 @@ void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st);
  * not overlap (they are applied concurrently) */
 int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offsets, const uint64_t* data_off,
                                const uint8_t* data, uint32_t n);
+/* Lists that change length without re-creating the state: `append` adds whole elements at the end of a variable-length list
+ * (add_validator_to_registry, phase0/block_processing.rs:317-349, is five appends: a 121-byte Validator, an 8-byte balance,
+ * two participation bytes, an 8-byte inactivity score; historical_summaries grows once per period), `truncate` keeps the
+ * first new_n_bytes of it (the eth1_data_votes reset).  The bytes behind the list move on the device, the SSZ offsets
+ * of later fields are rewritten, patch offsets refer to the NEW encoding afterwards (ecgpu_resident_state_size). */
+#define ECGPU_STATE_HISTORICAL_ROOTS 0
+#define ECGPU_STATE_ETH1_DATA_VOTES 1
+#define ECGPU_STATE_VALIDATORS 2
+#define ECGPU_STATE_BALANCES 3
+#define ECGPU_STATE_PREVIOUS_EPOCH_PARTICIPATION 4
+#define ECGPU_STATE_CURRENT_EPOCH_PARTICIPATION 5
+#define ECGPU_STATE_INACTIVITY_SCORES 6
+#define ECGPU_STATE_HISTORICAL_SUMMARIES 8
+int ecgpu_resident_state_append(ecgpu_resident_state_t* st, int field, const uint8_t* data, uint64_t n_bytes);
+int ecgpu_resident_state_truncate(ecgpu_resident_state_t* st, int field, uint64_t new_n_bytes);
+uint64_t ecgpu_resident_state_size(const ecgpu_resident_state_t* st);
 int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]);
 /* asynchronous form: root written to device memory on `stream` */
 int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, ecgpu_stream_t stream);
@@ -212,6 +237,13 @@ int ecgpu_fast_aggregate_verify_batch_dev(const uint8_t* d_pks48, const uint32_t
                                           uint32_t n_pks_total, const uint8_t* d_msgs32,
                                           const uint8_t* d_sigs96, uint32_t n, int eth_variant,
                                           uint8_t* d_status_out, ecgpu_stream_t stream);
+
+/* The same batch sharded over `n_devices` GPUs of this process (contiguous tuple ranges): one host thread per
+ * device, every shard writes its statuses into status_out -- the all-gather of the verify booleans is the shared buffer.
+ * devices may repeat (two shards on one GPU). */
+int ecgpu_fast_aggregate_verify_batch_multi(const int* devices, uint32_t n_devices, const uint8_t* pks48, const uint32_t* pk_off,
+                                            const uint8_t* msgs32, const uint8_t* sigs96, uint32_t n, int eth_variant,
+                                            uint8_t* status_out);
 
 /* Validated-key registry.  The reference decompresses and subgroup-checks every public key
  * on every call (`TryFrom<&PublicKey>`, crypto/bls.rs:279-285, reached from :122 for each key gathered out of

@@ -525,3 +525,34 @@ def test_whole_block_signature_batch_at_block_shape(gpu):
     rb.close()
     reg.close()
     batch.close()
+
+
+def test_several_devices_in_one_process(gpu):
+    """SURVEY.md 8e for a host without torch.distributed: the *_multi entries shard a batch / a registry over a device list
+    on host threads of their own (ecgpu_bind_thread).  One GPU here: the list names it several times, which exercises the
+    sharding, the per-thread binding and the result assembly; the statuses / root must equal the single-device call."""
+    from ethereum_consensus_amd import ssz, synthetic as syn
+    n = 700
+    skb = syn.bls_secret_keys(n)
+    msgs = syn.bls_messages(n)
+    pks = bytearray(gpu.sk_to_pk_batch(skb))
+    sigs = bytearray(gpu.sign_batch(skb, [msgs[32 * i:32 * i + 32] for i in range(n)]))
+    msgb = bytearray(msgs)
+    want, _ = syn.bls_inject_faults(pks, msgb, sigs, n, period=16)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        assert gpu.fast_aggregate_verify_batch_multi(devs, bytes(pks), None, bytes(msgb), bytes(sigs)) == bytes(want)
+    # variable K: 5 aggregates over the clean keys of the first 60 tuples
+    clean = gpu.sk_to_pk_batch(skb[:32 * 60])
+    offs = [0, 10, 10, 25, 59, 60]
+    sk_int = [int.from_bytes(skb[32 * i:32 * i + 32], "big") for i in range(60)]
+    m5 = [S(b"multi", c) for c in range(5)]
+    agg = [sum(sk_int[offs[c]:offs[c + 1]]) % B.R or 1 for c in range(5)]
+    sg5 = gpu.sign_batch(b"".join(sk_bytes(a) for a in agg), m5)
+    single = gpu.fast_aggregate_verify_batch(clean, offs, b"".join(m5), sg5)
+    assert single == bytes([0, B.BLST_AGGR_TYPE_MISMATCH, 0, 0, 0])
+    assert gpu.fast_aggregate_verify_batch_multi([0, 0], clean, offs, b"".join(m5), sg5) == single
+    v = syn.validators(5000).tobytes()
+    want_root = ssz.hash_tree_root_validators(v)
+    for devs in ([0], [0, 0], [0, 0, 0, 0, 0]):
+        assert ssz.hash_tree_root_validators_multi(devs, v) == want_root
+    assert ssz.hash_tree_root_validators_multi([0, 0], b"") == ssz.hash_tree_root_validators(b"")

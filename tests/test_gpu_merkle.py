@@ -491,3 +491,62 @@ def test_light_client_branches_of_a_beacon_state(gpu):
     for pos in (22, 23, 20, 11):
         leaf, branch, g, root = ssz.prove_beacon_state_field("deneb", enc, ssz.MAINNET, pos)
         assert root == want_root and g == 32 + pos and ssz.is_valid_merkle_branch(leaf, branch, 5, pos, root)
+
+
+def test_resident_state_lists_change_length(gpu):
+    """add_validator_to_registry (phase0/block_processing.rs:317-349) and the other length changes on a
+    RESIDENT state -- appends (within the buffer's slack and beyond it), a truncation, patches before and after -- against
+    from-scratch roots of the re-serialized state."""
+    import numpy as np
+    from ethereum_consensus_amd import synthetic
+    ssz = gpu
+    f = synthetic.state_fields(100, "minimal", seed=12)
+    enc = synthetic.serialize_state(f)
+    st = ssz.ResidentBeaconStateDeneb(enc, ssz.MINIMAL)
+    assert st.hash_tree_root() == ssz.hash_tree_root_beacon_state_deneb(enc, ssz.MINIMAL) and len(st) == len(enc)
+
+    def grow(k, seed):
+        new = synthetic.validators(k, seed=seed)
+        f["validators"] = np.concatenate([f["validators"], new])
+        f["balances"] = np.concatenate([f["balances"], np.full(k, 32 * 10**9 + seed, dtype="<u8")])
+        for name in ("previous_epoch_participation", "current_epoch_participation"):
+            f[name] = np.concatenate([f[name], np.zeros(k, dtype=np.uint8)])
+        f["inactivity_scores"] = np.concatenate([f["inactivity_scores"], np.zeros(k, dtype="<u8")])
+        return new
+
+    for step, k in enumerate((1, 1, 7)):  # one validator at a time, as a deposit does
+        new = grow(k, 100 + step)
+        for i in range(k):
+            st.add_validator(new[i:i + 1].tobytes(), 32 * 10**9 + 100 + step)
+        enc = synthetic.serialize_state(f)
+        assert len(st) == len(enc)
+        assert st.hash_tree_root() == ssz.hash_tree_root_beacon_state_deneb(enc, ssz.MINIMAL), step
+    # a patch addressed in the NEW encoding: the balance of the last validator
+    n = len(f["validators"])
+    tail = sum(len(x) for x in (f["balances"].tobytes(), f["previous_epoch_participation"].tobytes(), f["current_epoch_participation"].tobytes(),
+                                f["inactivity_scores"].tobytes(), synthetic.serialize_payload_header(f["payload_header"]),
+                                f["historical_summaries"].tobytes()))
+    bal_off = len(enc) - tail
+    f["balances"][n - 1] = 31 * 10**9
+    st.patch([(bal_off + 8 * (n - 1), int(31 * 10**9).to_bytes(8, "little"))])
+    # beyond the slack of the device buffer: 1 500 validators in one append per list
+    new = grow(1500, 7)
+    st.append(st.VALIDATORS, new.tobytes())
+    st.append(st.BALANCES, f["balances"][-1500:].tobytes())
+    st.append(st.PREVIOUS_EPOCH_PARTICIPATION, bytes(1500))
+    st.append(st.CURRENT_EPOCH_PARTICIPATION, bytes(1500))
+    st.append(st.INACTIVITY_SCORES, bytes(8 * 1500))
+    # the eth1_data_votes reset and one more historical summary
+    f["eth1_data_votes"] = []
+    st.truncate(st.ETH1_DATA_VOTES, 0)
+    extra = np.frombuffer(bytes(range(64)), dtype=np.uint8).reshape(1, 64)
+    f["historical_summaries"] = np.concatenate([f["historical_summaries"], extra])
+    st.append(st.HISTORICAL_SUMMARIES, extra.tobytes())
+    enc = synthetic.serialize_state(f)
+    assert len(st) == len(enc)
+    assert st.hash_tree_root() == ssz.hash_tree_root_beacon_state_deneb(enc, ssz.MINIMAL)
+    with pytest.raises(ssz.MerkleizationError):
+        st.append(st.VALIDATORS, bytes(120))  # not a whole record
+    with pytest.raises(ssz.MerkleizationError):
+        st.append(7, bytes(8))                 # the payload header is not a list
+    st.close()
