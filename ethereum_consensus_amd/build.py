@@ -22,6 +22,7 @@ LIB = os.path.join(LIBDIR, "libecgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 VM2_GEN_ARGS = os.environ.get("ECGPU_VM2_GEN_ARGS", "--lanes 16 --window 200").split()
+VM3_GEN_ARGS = os.environ.get("ECGPU_VM3_GEN_ARGS", "--lanes 16 --window 120").split()
 # -pragma-unroll-threshold: the sums of products (bls_fp.h fp_sumprod) are 13 rows x up to 13 x 13 multiply-adds that
 # must be fully unrolled for their column accumulators to stay in registers; the default threshold stops at ~1000.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
@@ -84,7 +85,7 @@ def _run(cmd):
 def generate_vm_programs(verbose: bool = True) -> str:
     """csrc/bls_vm2_prog.h (generated tables) is produced by tools/gen_bls_vm2.py, not committed."""
     out = None
-    for script, header, gen_args in (("gen_bls_vm2.py", "bls_vm2_prog.h", VM2_GEN_ARGS),):
+    for script, header, gen_args in (("gen_bls_vm2.py", "bls_vm2_prog.h", VM2_GEN_ARGS), ("gen_bls_vm3.py", "bls_vm3_prog.h", VM3_GEN_ARGS)):
         gen = os.path.join(ROOT, "tools", script)
         out = os.path.join(CSRC, header)
         stamp = out + ".args"

@@ -30,7 +30,10 @@
 
 namespace ecg {
 
-int init_bls_tables(hipStream_t) { return init_vm2_tables(); }
+int init_bls_tables(hipStream_t) {
+    int rc = init_vm2_tables();
+    return rc ? rc : init_vm3_tables();
+}
 
 // ---- stage kernels ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pk_validate(const u8* pks48, u32 n, A1* pts, u8* st) {
@@ -187,7 +190,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sign(const u8* sks
 static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
-    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + vm2_xfer_bytes(n) + 8192;
+    const size_t xf = vm2_xfer_bytes(n) > vm3_xfer_bytes(n) ? vm2_xfer_bytes(n) : vm3_xfer_bytes(n);
+    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + xf + 8192;
 }
 // Which kernels run the pairing check.  The lane kernel (one lane per tuple, state in VGPRs/AGPRs + private segment)
 // has the best throughput but one tuple's check is a 35 ms dependent chain, so a batch of a few thousand tuples
@@ -197,7 +201,13 @@ static const int g_pairing_mode = [] {
     const char* e = getenv("ECGPU_PAIRING");
     if (e && !strcmp(e, "lane")) return 0;
     if (e && !strcmp(e, "vm2")) return 2;
+    if (e && !strcmp(e, "vm3")) return 4;
     return 3;
+}();
+// auto mode: which lane-group VM small batches use (ECGPU_SMALL_VM=vm2|vm3)
+static const int g_small_vm = [] {
+    const char* e = getenv("ECGPU_SMALL_VM");
+    return (e && !strcmp(e, "vm2")) ? 2 : 3;
 }();
 // Which tower the lane pairing kernels run on: 1 = sums of products (bls_pairing_kernels.hip), 2 = the compact-code tower
 // (bls_pairing_kernels_calls.hip).  ECGPU_TOWER=sums|calls forces one; otherwise the box self-check decides once per
@@ -223,9 +233,13 @@ static int decide_tower() {
 // which kernels ran the pairing check of this thread's last batch: 1 = lane kernel (k_pairing[_calls]), 2 = Fp2 lane groups
 // (bls_vm2.hip; tuples with a point at infinity still go through the lane kernel), 3 = Fp lane groups (bls_vm3.hip)
 static thread_local int t_last_pairing_path = 0;
+// batch size up to which the lane groups run the pairing check in auto mode.  Measured (profiles/r02f_vm3_timing.txt, healthy
+// box): sum-of-products groups 4.1 / 10.5 / 56.7 ms at 2 048 / 8 192 / 65 536 tuples, Fp2 groups 8.1 / 21.3 / 126, lane
+// kernel 27 .. 31 flat -- the groups win below ~28 k tuples.  On a box whose instruction fetch is slow (compact-code build
+// selected: the lane kernel takes 52 ms) the sum-of-products groups, 47 KB of code, win at every size.
 static const u32 g_vm2_max_tuples = [] {
     const char* e = getenv("ECGPU_VM2_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : 12288u;
+    return e ? (u32)strtoul(e, nullptr, 10) : (g_small_vm == 3 ? 24576u : 12288u);
 }();
 
 }  // namespace ecg
@@ -306,17 +320,21 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     }
     {
         ProfScope ps("bls_pairing", s);
-        const bool use_vm = g_pairing_mode == 2 || (g_pairing_mode == 3 && n <= g_vm2_max_tuples);
-        t_last_pairing_path = use_vm ? 2 : 1;
+        const bool slow_box = g_tower.load() == 2 && g_small_vm == 3;  // large-code kernels crawl here: the 47 KB kernel at every size
+        const bool auto_vm = g_pairing_mode == 3 && (n <= g_vm2_max_tuples || slow_box);
+        const bool use_vm3 = g_pairing_mode == 4 || (auto_vm && g_small_vm == 3);
+        const bool use_vm = use_vm3 || g_pairing_mode == 2 || auto_vm;
+        t_last_pairing_path = use_vm3 ? 3 : use_vm ? 2 : 1;
         if (!use_vm) {
             hipLaunchKernelGGL(g_tower.load() == 2 ? k_pairing_calls : k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg,
                                (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96,
                                n, eth_variant, d_status, 0);
         } else {
-            u32* xfer = (u32*)ar.take(vm2_xfer_bytes(n));
+            u32* xfer = (u32*)ar.take(use_vm3 ? vm3_xfer_bytes(n) : vm2_xfer_bytes(n));
             if (!xfer) return ECGPU_ERR_OOM;
-            int rc = vm2_pairing_launch(s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec,
-                                        (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
+            int rc = (use_vm3 ? vm3_pairing_launch : vm2_pairing_launch)(s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
+                                                                         (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n,
+                                                                         eth_variant, d_status, xfer);
             if (rc) return rc;
             // tuples with a point at infinity in the pairing (signature 0xc0.., H(m) = inf): rare, branchy lane kernel
             hipLaunchKernelGGL(g_tower.load() == 2 ? k_pairing_calls : k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg,

@@ -13,4 +13,10 @@ size_t vm2_xfer_bytes(u32 n);
 int vm2_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                        const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer);
 
+// the same interface for the sum-of-products lane groups (bls_vm3.hip)
+int init_vm3_tables();
+size_t vm3_xfer_bytes(u32 n);
+int vm3_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
+                       const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer);
+
 }  // namespace ecg

@@ -397,7 +397,9 @@ def config2_workload(gpu, tmp_path_factory):
 @pytest.mark.parametrize("tower,pairing,n,want_tower,want_path", [
     ("sums", "lane", 65536, 1, "lane"),     # the default large-batch kernel on a healthy box: k_pairing on the sums-of-products tower
     ("calls", "lane", 65536, 2, "lane"),    # the compact-code build chosen on boxes with slow instruction fetch: k_pairing_calls
-    ("sums", "vm2", 8192, 1, "vm2"),        # the Fp2 lane-group path of small batches
+    ("sums", "vm2", 8192, 1, "vm2"),        # the Fp2 lane-group programs (round 1's small-batch path)
+    ("sums", "vm3", 8192, 1, "vm3"),        # the sum-of-products lane groups: the small-batch path
+    ("sums", "vm3", 65536, 1, "vm3"),       # ... and at full size (what a box with slow instruction fetch would run)
 ])
 def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, tower, pairing, n, want_tower, want_path):
     """The whole status vector of SURVEY.md 8(d) config 2 -- every fault class: wrong message, swapped key, signature outside

@@ -343,10 +343,11 @@ def test_fast_aggregate_verify_status_algebra(variant):
         assert got == C.oracle_fav(pks, msg, sig, eth), (len(pks), eth)
 
 
-@pytest.mark.parametrize("entry", ["hs_vm2_pairing"])
+@pytest.mark.parametrize("entry", ["hs_vm2_pairing", "hs_vm3_pairing"])
 def test_lane_group_vm_pairing_programs(entry):
-    """The generated lane-group programs (tools/gen_bls_vm2.py) executed with the kernel's
-    lock-step semantics: e(P, H) e(-g1, S) after the final exponentiation, coefficient by coefficient."""
+    """The generated lane-group programs (tools/gen_bls_vm2.py: Fp2 registers, Karatsuba tower; tools/gen_bls_vm3.py: Fp
+    registers, sums of products with derived outputs) executed with the kernels' lock-step semantics and the kernels' own limb
+    arithmetic: e(P, H) e(-g1, S) after the final exponentiation, coefficient by coefficient."""
     r = random.Random(23)
     L = lib()
     fn = getattr(L, entry)

@@ -38,6 +38,8 @@ G1_Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC74
 LIMIT = 600   # sum over the terms of bound(a) * bound(b), in units of p^2; the Montgomery reduction needs < R / p = 632
 MAXN = 7      # products per sum (descriptor: dst + 7 + 7 register numbers)
 MAXDER = 4    # derived outputs per lane per round
+CLASSES = (4, 7)  # the sums the kernel carries compiled (csrc/bls_vm3.hip): a round of N products runs as the next class up.
+                  # Two bodies keep the hot loop at ~40 KB -- inside the 64 KB instruction cache -- for +5 % multiply-adds
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -607,9 +609,13 @@ def make_program(t, outputs, inputs, lanes, window):
         lead_sum = ops[el[0]]["n"] > 0
         same = [i for i in el if (ops[i]["n"] > 0) == lead_sum]
         ncls = max(ops[i]["n"] for i in same[:slots])
+        if ncls:
+            ncls = min(c for c in CLASSES if c >= ncls)
         take = [i for i in same if ops[i]["n"] <= ncls][:slots]
         # a cheaper class that still holds the same ops?  (all taken ops smaller than the leader's class)
         ncls = max(ops[i]["n"] for i in take)
+        if ncls:
+            ncls = min(c for c in CLASSES if c >= ncls)
         rounds.append((ncls, take))
         ts = set(take)
         ready = [i for i in ready if i not in ts]
