@@ -235,11 +235,11 @@ static int decide_tower() {
 static thread_local int t_last_pairing_path = 0;
 // batch size up to which the lane groups run the pairing check in auto mode.  Measured (profiles/r02f_vm3_timing.txt, healthy
 // box): sum-of-products groups 4.1 / 10.5 / 56.7 ms at 2 048 / 8 192 / 65 536 tuples, Fp2 groups 8.1 / 21.3 / 126, lane
-// kernel 27 .. 31 flat -- the groups win below ~28 k tuples.  On a box whose instruction fetch is slow (compact-code build
+// kernel 27 .. 31 flat -- the groups win up to ~32 k tuples (26.4 ms at 32 768 after the register-file work, profiles/r02g_vm3_timing.txt).  On a box whose instruction fetch is slow (compact-code build
 // selected: the lane kernel takes 52 ms) the sum-of-products groups, 47 KB of code, win at every size.
 static const u32 g_vm2_max_tuples = [] {
     const char* e = getenv("ECGPU_VM2_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : (g_small_vm == 3 ? 24576u : 12288u);
+    return e ? (u32)strtoul(e, nullptr, 10) : (g_small_vm == 3 ? 32768u : 12288u);
 }();
 
 }  // namespace ecg

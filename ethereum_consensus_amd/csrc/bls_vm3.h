@@ -10,8 +10,9 @@
 // stores it to dst, exchanges `own` with its pair partner (lane ^ 1: the other component of the same Fp2 value) and stores
 // up to nder derived registers c_own * own + c_partner * partner + K p -- limbs renormalised, NOT reduced modulo p: they
 // are product operands of later rounds (bounds checked by the generator).  Register 0 is ZERO: unused operand slots read
-// it (0 * 0 adds nothing to a sum) and a store to it is skipped (idle lanes, results nobody reads).  All reads of a round
-// happen before its writes, so a register may be reused by the round that last reads it.
+// it (0 * 0 adds nothing to a sum) and a store to it is skipped (idle lanes, results nobody reads).  Register numbers from
+// ECG_VM3_CONST_BASE up name the program's constants: one copy per workgroup behind the tuples' slices, not one per tuple.
+// All reads of a round happen before its writes, so a register may be reused by the round that last reads it.
 #pragma once
 #include "bls_fp.h"
 
@@ -19,16 +20,23 @@ namespace ecg {
 
 constexpr u32 VM3_REG_DW = 13;  // dwords per Fp register
 constexpr u32 VM3_DESC_DW = 8;  // dwords per lane descriptor
+constexpr u32 VM3_CONST_BASE = 192;
 
-ECG_HD Fp vm3_load(const u32* R, u32 r) {
+// the register file of one tuple: its own slice and the workgroup's constants
+struct Vm3Regs {
+    u32* own;
+    const u32* consts;
+};
+
+ECG_HD Fp vm3_load(const Vm3Regs& R, u32 r) {
     Fp x;
-    const u32* p = R + r * VM3_REG_DW;
+    const u32* p = r >= VM3_CONST_BASE ? R.consts + (r - VM3_CONST_BASE) * VM3_REG_DW : R.own + r * VM3_REG_DW;
 #pragma unroll
     for (int i = 0; i < 13; i++) x.l[i] = p[i];
     return x;
 }
-ECG_HD void vm3_store(u32* R, u32 r, const Fp& x) {
-    u32* p = R + r * VM3_REG_DW;
+ECG_HD void vm3_store(const Vm3Regs& R, u32 r, const Fp& x) {
+    u32* p = R.own + r * VM3_REG_DW;
 #pragma unroll
     for (int i = 0; i < 13; i++) p[i] = x.l[i];
 }
@@ -48,7 +56,7 @@ ECG_HD Fp vm3_derive(const Fp& own, const Fp& par, int c_own, int c_par, u32 k) 
 }
 
 template <int N>
-ECG_HD Fp vm3_sum(const u32* R, const u32* w) {
+ECG_HD Fp vm3_sum(const Vm3Regs& R, const u32* w) {
     Fp a[N], b[N];
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -62,7 +70,7 @@ ECG_HD Fp vm3_sum(const u32* R, const u32* w) {
 // the arithmetic of one lane in one round of class n (wave-uniform): its own result.  Two compiled sums (the generator pads a
 // round of N products to the next class: unused slots multiply ZERO by ZERO): together with the interpreter loop they are the
 // whole hot code, ~40 KB -- inside the 64 KB instruction cache.
-ECG_HD Fp vm3_own(u32 n, const u32* R, const u32* w) {
+ECG_HD Fp vm3_own(u32 n, const Vm3Regs& R, const u32* w) {
     if (n == 0) return vm3_load(R, (w[0] >> 8) & 255);
     if (n <= 4) return vm3_sum<4>(R, w);
     return vm3_sum<7>(R, w);
@@ -70,7 +78,7 @@ ECG_HD Fp vm3_own(u32 n, const u32* R, const u32* w) {
 
 // Sequential (one tuple) execution with the lock-step semantics of the kernel: every lane of a round reads the register
 // file as it was before the round.  Used by tests/hostsim.
-inline void vm3_run_serial(const u32* prog, const u32* hdr, u32 rounds, u32 lanes, u32* R) {
+inline void vm3_run_serial(const u32* prog, const u32* hdr, u32 rounds, u32 lanes, const Vm3Regs& R) {
     Fp own[64];
     for (u32 r = 0; r < rounds; r++) {
         const u32 n = hdr[r] & 255, nder = (hdr[r] >> 8) & 255;

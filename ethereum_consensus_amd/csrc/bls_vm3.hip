@@ -64,6 +64,7 @@ static int upload3(const unsigned int* h, size_t n, const u32** d) {
 int init_vm3_tables() {
     static_assert(ECG_VM3_A_NIN == 10 && ECG_VM3_A_NOUT == 14 && ECG_VM3_C_NIN == 14 && ECG_VM3_C_NOUT == 12, "program interface");
     static_assert(64 % ECG_VM3_LANES == 0 && ECG_VM3_LANES % 2 == 0, "lane groups tile a wave; results travel in lane pairs");
+    static_assert(ECG_VM3_CONST_BASE == VM3_CONST_BASE, "generator and kernel agree on where the constants start");
     VM3_FILL(g_vm3_a, A);
     VM3_FILL(g_vm3_c, C);
     return ECGPU_SUCCESS;
@@ -74,13 +75,13 @@ ECG_D u32 dpp_partner(u32 v) {  // the value of lane ^ 1 (quad_perm [1, 0, 3, 2]
 }
 
 template <int N>
-ECG_D Fp vm3_round_sum(const u32* R, const uint4 w01) {
+ECG_D Fp vm3_round_sum(const Vm3Regs& R, const uint4 w01) {
     const u32 w[4] = {w01.x, w01.y, w01.z, w01.w};
     return vm3_sum<N>(R, w);
 }
 
 // one lane group through a whole program; R = the tuple's register file in LDS
-ECG_D void vm3_run(const Vm3Desc& d, u32* R, u32 slot) {
+ECG_D void vm3_run(const Vm3Desc& d, const Vm3Regs& R, u32 slot) {
     const uint4* pp = (const uint4*)d.prog + (size_t)slot * 2;
     uint4 w01 = pp[0], w23 = pp[1];
     u32 h = d.hdr[0];
@@ -120,10 +121,17 @@ ECG_D void vm3_run(const Vm3Desc& d, u32* R, u32 slot) {
     }
 }
 
-ECG_D void vm3_load_consts(const Vm3Desc& d, u32* R, u32 slot) {
-    for (u32 i = slot; i < VM3_REG_DW; i += VM3_G) R[i] = 0;  // register 0 = ZERO
-    for (u32 c = slot; c < d.nconst; c += VM3_G)
-        for (u32 i = 0; i < VM3_REG_DW; i++) R[d.const_reg[c] * VM3_REG_DW + i] = d.const_val[c * VM3_REG_DW + i];
+// register 0 of every tuple = ZERO; the constants once per workgroup, behind the tuples' slices
+ECG_D Vm3Regs vm3_setup(const Vm3Desc& d, u32* lds, u32 lane) {
+    const u32 slot = lane % VM3_G, tl = lane / VM3_G;
+    u32* own = lds + tl * d.nreg * VM3_REG_DW;
+    u32* consts = lds + VM3_TPW * d.nreg * VM3_REG_DW;
+    for (u32 i = slot; i < VM3_REG_DW; i += VM3_G) own[i] = 0;
+    for (u32 i = lane; i < d.nconst * VM3_REG_DW; i += 64) {
+        const u32 c = i / VM3_REG_DW, k = i % VM3_REG_DW;
+        consts[(d.const_reg[c] - VM3_CONST_BASE) * VM3_REG_DW + k] = d.const_val[i];
+    }
+    return Vm3Regs{own, consts};
 }
 
 // part A: Miller loops of e(agg, H) e(-g1, sig) -> f (12 Fp) and the Fp norm d to invert
@@ -132,8 +140,7 @@ __global__ void __launch_bounds__(64) k_vm3_pair_a(Vm3Desc d, const A1* agg, con
     const u32 lane = threadIdx.x, slot = lane % VM3_G, tl = lane / VM3_G;
     const u32 tuple = blockIdx.x * VM3_TPW + tl;
     const u32 tc = tuple < n ? tuple : n - 1;
-    u32* R = vm3_lds + tl * d.nreg * VM3_REG_DW;
-    vm3_load_consts(d, R, slot);
+    const Vm3Regs R = vm3_setup(d, vm3_lds, lane);
     for (u32 k = slot; k < 10; k += VM3_G) {
         // inputs in the generator's order: PXY = (x, y) of the aggregate key, then HX, HY, SX, SY (c0, c1 each)
         const u32* w = k == 0   ? agg[tc].x.l
@@ -142,14 +149,14 @@ __global__ void __launch_bounds__(64) k_vm3_pair_a(Vm3Desc d, const A1* agg, con
                        : k < 6  ? (k == 4 ? hpts[tc].y.c0.l : hpts[tc].y.c1.l)
                        : k < 8  ? (k == 6 ? sigpts[tc].x.c0.l : sigpts[tc].x.c1.l)
                                 : (k == 8 ? sigpts[tc].y.c0.l : sigpts[tc].y.c1.l);
-        for (u32 i = 0; i < VM3_REG_DW; i++) R[d.in_reg[k] * VM3_REG_DW + i] = w[i];
+        for (u32 i = 0; i < VM3_REG_DW; i++) R.own[d.in_reg[k] * VM3_REG_DW + i] = w[i];
     }
     __syncthreads();
     vm3_run(d, R, slot);
     if (tuple < n)
         for (u32 k = slot; k < 13; k += VM3_G) {
             u32* o = xfer + (size_t)tuple * XFER3_STRIDE + k * VM3_REG_DW;
-            for (u32 i = 0; i < VM3_REG_DW; i++) o[i] = R[d.out_reg[k] * VM3_REG_DW + i];
+            for (u32 i = 0; i < VM3_REG_DW; i++) o[i] = R.own[d.out_reg[k] * VM3_REG_DW + i];
         }
 }
 
@@ -172,11 +179,10 @@ __global__ void __launch_bounds__(64) k_vm3_pair_c(Vm3Desc d, const u32* xfer, c
     const u32 lane = threadIdx.x, slot = lane % VM3_G, tl = lane / VM3_G;
     const u32 tuple = blockIdx.x * VM3_TPW + tl;
     const u32 tc = tuple < n ? tuple : n - 1;
-    u32* R = vm3_lds + tl * d.nreg * VM3_REG_DW;
-    vm3_load_consts(d, R, slot);
+    const Vm3Regs R = vm3_setup(d, vm3_lds, lane);
     for (u32 k = slot; k < 14; k += VM3_G) {
         const u32* w = xfer + (size_t)tc * XFER3_STRIDE + (k < 12 ? k : k + 2) * VM3_REG_DW;
-        for (u32 i = 0; i < VM3_REG_DW; i++) R[d.in_reg[k] * VM3_REG_DW + i] = w[i];
+        for (u32 i = 0; i < VM3_REG_DW; i++) R.own[d.in_reg[k] * VM3_REG_DW + i] = w[i];
     }
     if (slot == 0) not_one[tl] = 0;
     __syncthreads();
@@ -208,7 +214,9 @@ int vm3_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32*
                        const u8* st_dec, const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer) {
     static_assert(sizeof(Fp) == 13 * 4, "register images are read straight from the staged points");
     const dim3 vgrid((n + VM3_TPW - 1) / VM3_TPW);
-    const size_t lds_a = (size_t)VM3_TPW * g_vm3_a.nreg * VM3_REG_DW * 4, lds_c = (size_t)VM3_TPW * g_vm3_c.nreg * VM3_REG_DW * 4;
+    // per workgroup: the tuples' register slices + one copy of the constants
+    const size_t lds_a = ((size_t)VM3_TPW * g_vm3_a.nreg + g_vm3_a.nconst) * VM3_REG_DW * 4,
+                 lds_c = ((size_t)VM3_TPW * g_vm3_c.nreg + g_vm3_c.nconst) * VM3_REG_DW * 4;
     static bool attr_set[MAX_DEVICES] = {};
     if (!attr_set[current_device()]) {
         ECG_HIP_CHECK(hipFuncSetAttribute((const void*)k_vm3_pair_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));

@@ -296,24 +296,25 @@ int hs_vm2_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
 // The sum-of-products lane-group programs (tools/gen_bls_vm3.py) executed with the kernel's lock-step semantics on one tuple:
 // part A, the Fp inversion, part C.  Same interface as hs_vm2_pairing; Fp12 coefficients arrive in w-power order.
 int hs_vm3_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
-    std::vector<u32> RA((size_t)ECG_VM3_A_NREG * 13, 0), RC((size_t)ECG_VM3_C_NREG * 13, 0);
+    std::vector<u32> RA((size_t)ECG_VM3_A_NREG * 13, 0), RC((size_t)ECG_VM3_C_NREG * 13, 0), KA(64 * 13, 0), KC(64 * 13, 0);
     for (int c = 0; c < ECG_VM3_A_NCONST; c++)
-        for (int i = 0; i < 13; i++) RA[(size_t)ECG_VM3_A_CONST_REG[c] * 13 + i] = ECG_VM3_A_CONST_VAL[c * 13 + i];
+        for (int i = 0; i < 13; i++) KA[(size_t)(ECG_VM3_A_CONST_REG[c] - VM3_CONST_BASE) * 13 + i] = ECG_VM3_A_CONST_VAL[c * 13 + i];
     for (int c = 0; c < ECG_VM3_C_NCONST; c++)
-        for (int i = 0; i < 13; i++) RC[(size_t)ECG_VM3_C_CONST_REG[c] * 13 + i] = ECG_VM3_C_CONST_VAL[c * 13 + i];
+        for (int i = 0; i < 13; i++) KC[(size_t)(ECG_VM3_C_CONST_REG[c] - VM3_CONST_BASE) * 13 + i] = ECG_VM3_C_CONST_VAL[c * 13 + i];
+    const Vm3Regs A{RA.data(), KA.data()}, Cr{RC.data(), KC.data()};
     A1 p = in_a1(p_xy, 0);
     A2 h = in_a2(h_xy, 0), sg = in_a2(s_xy, 0);
     const Fp in[10] = {p.x, p.y, h.x.c0, h.x.c1, h.y.c0, h.y.c1, sg.x.c0, sg.x.c1, sg.y.c0, sg.y.c1};
-    for (int k = 0; k < 10; k++) vm3_store(RA.data(), ECG_VM3_A_IN[k], in[k]);
-    vm3_run_serial(ECG_VM3_A_PROG, ECG_VM3_A_HDR, ECG_VM3_A_ROUNDS, ECG_VM3_LANES, RA.data());
-    for (int k = 0; k < 12; k++) vm3_store(RC.data(), ECG_VM3_C_IN[k], vm3_load(RA.data(), ECG_VM3_A_OUT[k]));
-    vm3_store(RC.data(), ECG_VM3_C_IN[12], fp_inv(vm3_load(RA.data(), ECG_VM3_A_OUT[12])));
-    vm3_store(RC.data(), ECG_VM3_C_IN[13], fp_zero());
-    vm3_run_serial(ECG_VM3_C_PROG, ECG_VM3_C_HDR, ECG_VM3_C_ROUNDS, ECG_VM3_LANES, RC.data());
+    for (int k = 0; k < 10; k++) vm3_store(A, ECG_VM3_A_IN[k], in[k]);
+    vm3_run_serial(ECG_VM3_A_PROG, ECG_VM3_A_HDR, ECG_VM3_A_ROUNDS, ECG_VM3_LANES, A);
+    for (int k = 0; k < 12; k++) vm3_store(Cr, ECG_VM3_C_IN[k], vm3_load(A, ECG_VM3_A_OUT[k]));
+    vm3_store(Cr, ECG_VM3_C_IN[12], fp_inv(vm3_load(A, ECG_VM3_A_OUT[12])));
+    vm3_store(Cr, ECG_VM3_C_IN[13], fp_zero());
+    vm3_run_serial(ECG_VM3_C_PROG, ECG_VM3_C_HDR, ECG_VM3_C_ROUNDS, ECG_VM3_LANES, Cr);
     // w-power order g0..g5 = c0.c0, c1.c0, c0.c1, c1.c1, c0.c2, c1.c2
     Fp12 e;
     Fp2* c[6] = {&e.c0.c0, &e.c1.c0, &e.c0.c1, &e.c1.c1, &e.c0.c2, &e.c1.c2};
-    for (int k = 0; k < 6; k++) *c[k] = Fp2{vm3_load(RC.data(), ECG_VM3_C_OUT[2 * k]), vm3_load(RC.data(), ECG_VM3_C_OUT[2 * k + 1])};
+    for (int k = 0; k < 6; k++) *c[k] = Fp2{vm3_load(Cr, ECG_VM3_C_OUT[2 * k]), vm3_load(Cr, ECG_VM3_C_OUT[2 * k + 1])};
     out_fp12(e, out576);
     return fp12_is_one(e) ? 1 : 0;
 }

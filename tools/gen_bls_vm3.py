@@ -38,6 +38,7 @@ G1_Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC74
 LIMIT = 600   # sum over the terms of bound(a) * bound(b), in units of p^2; the Montgomery reduction needs < R / p = 632
 MAXN = 7      # products per sum (descriptor: dst + 7 + 7 register numbers)
 MAXDER = 4    # derived outputs per lane per round
+CONST_BASE = 192  # register numbers >= CONST_BASE name the workgroup's shared constant area, not the tuple's own slice
 CLASSES = (4, 7)  # the sums the kernel carries compiled (csrc/bls_vm3.hip): a round of N products runs as the next class up.
                   # Two bodies keep the hot loop at ~40 KB -- inside the 64 KB instruction cache -- for +5 % multiply-adds
 
@@ -137,10 +138,14 @@ class Trace:
         return pr["forms"][ab]
 
     def _new_forms(self, pid, abs_):
+        """cost of asking pair `pid` for these forms: constants are free (their forms are more constants); a new form of an
+        INPUT pair occupies a register for the whole program (inputs live until their last use), so it weighs more than one of
+        a short-lived intermediate"""
         pr = self.pairs[pid]
         if pr["kind"] == "const":
             return 0
-        return sum(1 for ab in abs_ if ab not in ((0, 0), (1, 0), (0, 1)) and ab not in pr["forms"])
+        w = 8 if pr["kind"] == "in" else 1
+        return sum(w for ab in abs_ if ab not in ((0, 0), (1, 0), (0, 1)) and ab not in pr["forms"])
 
     def row(self, v, r, sign=1):
         return self.form(v.pid, tuple(sign * x for x in v.m[r]))
@@ -157,6 +162,13 @@ class Trace:
                     c = x.m[0][0]
                     x, y = V(x.pid), y.scale(c)
                 x, y = y, x
+            # (M X) Y == X (M Y) for the scalar / xi matrices used here (they commute with the Fp2 product): when exactly one
+            # side is plain, the matrix may ride on either pair -- keep it off long-lived inputs
+            ident = ((1, 0), (0, 1))
+            if self.pairs[x.pid]["kind"] == "in" and x.m != ident and y.m == ident and self.pairs[y.pid]["kind"] == "op":
+                x, y = V(x.pid), V(y.pid, x.m)
+            elif self.pairs[y.pid]["kind"] == "in" and y.m != ident and x.m == ident and self.pairs[x.pid]["kind"] == "op":
+                x, y = V(x.pid, y.m), V(y.pid)
             # the minus sign of i^2 goes to whichever side needs fewer new forms
             neg_x1 = tuple(-a for a in x.m[1])
             neg_y1 = tuple(-a for a in y.m[1])
@@ -254,9 +266,10 @@ def f12_sqr(f):
             wrap = i + j >= 6
             if i == j:
                 terms.append(("sqrxi", f[i]) if wrap else ("sqr", f[i]))
+            elif wrap:
+                terms.append(("mul", f[j].scale(2).xi(), f[i]))
             else:
-                x = f[i].scale(2)
-                terms.append(("mul", x.xi() if wrap else x, f[j]))
+                terms.append(("mul", f[i].scale(2), f[j]))
         out.append(T.sum(terms, "f12sqr") if terms else None)
     return out
 
@@ -390,13 +403,14 @@ def miller_dbl_step(Tp, pxy):
     ZZ = T.sqr(Z)
     YZ = T.mul(Y, Z)
     E = A.scale(3)
-    X3 = T.sum([("sqr", E), ("mul", X.scale(-8), B)], "dblX3")
-    W = T.sum([("mul", X.scale(12), B), ("mul", E.neg(), E)], "dblW")
+    XB = T.mul(X, B)
+    X3 = T.sum([("sqr", E), ("mul", XB.scale(-8), T.one)], "dblX3")
+    W = T.sum([("mul", XB.scale(12), T.one), ("sqr", E, -1)], "dblW")
     l0 = T.sum([("mul", E, X), ("mul", B.scale(-2), T.one)], "dbll0")
     EZZ = T.mul(E, ZZ)
     Z3 = YZ.scale(2)
     Z3ZZ = T.mul(Z3, ZZ)
-    Y3 = T.sum([("mul", E, W), ("mul", B.scale(-8), B)], "dblY3")
+    Y3 = T.sum([("mul", E, W), ("sqr", B, -8)], "dblY3")
     pc = T.pairs[pxy.pid]["c"]
     l1 = T.sum([("fpmul", EZZ.neg(), pc[0])], "dbll1")
     l2 = T.sum([("fpmul", Z3ZZ, pc[1])], "dbll2")
@@ -629,9 +643,9 @@ def make_program(t, outputs, inputs, lanes, window):
     reg = {}
     nxt = 1
     const_nodes = sorted({n for op in ops for n in op_reads(t, op) if t.fp[n]["kind"] == "const"})
-    for n in const_nodes:
-        reg[n] = nxt
-        nxt += 1
+    assert len(const_nodes) <= 256 - CONST_BASE
+    for k, n in enumerate(const_nodes):  # constants: one copy per workgroup, register numbers CONST_BASE ..
+        reg[n] = CONST_BASE + k
     in_nodes = [n for pid in inputs for n in t.pairs[pid]["c"]]
     for n in in_nodes:
         reg[n] = nxt
@@ -649,7 +663,7 @@ def make_program(t, outputs, inputs, lanes, window):
         if n not in pinned and n in last_use:
             release_at.setdefault(last_use[n], []).append(reg[n])
     enc_rounds = []
-    peak = 0
+    peak, peak_round, peak_live, born = 0, 0, [], {}
     for r, (ncls, take) in enumerate(rounds):
         # operands are read before anything is written within a round: registers whose last reader is this round are
         # available to this round's results
@@ -688,7 +702,15 @@ def make_program(t, outputs, inputs, lanes, window):
                     ders.append((alloc(n), c_own, c_par, k))
                 row.append((dst, terms, ders))
         enc_rounds.append((ncls, row))
-        peak = max(peak, nreg - len(free))
+        in_use = nreg - len(free)
+        if in_use > peak:
+            peak = in_use
+            peak_round = r
+            peak_live = [n for n in reg if (n in pinned or last_use.get(n, -1) >= r) and (n in const_nodes or n in in_nodes or n in born and born[n] <= r)]
+        for i in take:
+            pr_ = t.pairs[ops[i]["pid"]]
+            for n in (pr_["c"] if ops[i]["kind"] == "sum" else []) + [x for lf in ops[i]["lane_forms"] for x in lf]:
+                born[n] = r
     pr = Program()
     pr.rounds = enc_rounds
     pr.nreg = nreg
@@ -704,6 +726,8 @@ def make_program(t, outputs, inputs, lanes, window):
         pr.hist[n] = pr.hist.get(n, 0) + 1
     pr.nops = nops
     pr.nder = sum(len(d) for _, row in enc_rounds for _, _, d in row)
+    pr.peak_round = peak_round
+    pr.peak_live = [((t.pairs[t.fp[n]["pair"]]["name"] or t.pairs[t.fp[n]["pair"]]["kind"]), t.fp[n]["kind"]) for n in peak_live]
     return pr
 
 
@@ -713,7 +737,7 @@ def make_program(t, outputs, inputs, lanes, window):
 #   w4 + d (d < 4): derived output d: reg | (c_own & 255) << 8 | (c_partner & 255) << 16 | K << 24      (reg 0 = none)
 # round header: N | nder << 8 (nder = the largest number of derived outputs of any lane of the round)
 def encode(pr):
-    assert pr.nreg <= 256, pr.nreg
+    assert pr.nreg <= CONST_BASE, pr.nreg
     words, hdr = [], []
     for n, row in pr.rounds:
         nder = max((len(d) for _, _, d in row), default=0)
@@ -738,7 +762,7 @@ def encode(pr):
 def simulate(pr, words, hdr, inputs):
     """the ENCODED program on Python integers mod p, with the lock-step semantics of the kernel (all reads of a round before
     its writes; register 0 is TRASH and reads as 0 -- unused operand slots multiply TRASH by TRASH)"""
-    R = [0] * pr.nreg
+    R = [0] * 256
     for r, v in pr.const_regs:
         R[r] = v
     for r, v in zip(pr.input_regs, inputs):
@@ -851,6 +875,7 @@ def emit(pa, pc, wa, ha, wc, hc, lanes):
         print(f"// part {tag}: {pr.nops} ops, {pr.nder} derived outputs in {len(pr.rounds)} rounds {dict(sorted(pr.hist.items()))}, {pr.nreg} registers, "
               f"{pr.mads} multiply-adds per tuple at {100 * fill:.0f} % slot fill, model {int(pr.cycles)} cycles per wave")
         print(f"#define ECG_VM3_{tag}_NREG {pr.nreg}")
+        print(f"#define ECG_VM3_CONST_BASE {CONST_BASE}") if tag == "A" else None
         print(f"#define ECG_VM3_{tag}_ROUNDS {len(pr.rounds)}")
         print(f"#define ECG_VM3_{tag}_NIN {len(pr.input_regs)}")
         print(f"#define ECG_VM3_{tag}_NOUT {len(pr.output_regs)}")
@@ -912,3 +937,11 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def pressure_report(t, outputs, inputs, lanes, window, top=12):
+    """diagnostic: which values are live at the round of peak register pressure"""
+    ops, producer = build_ops(t, outputs)
+    # re-run the scheduler part of make_program to get rounds (kept in sync by calling it and reading back)
+    pr = make_program(t, outputs, inputs, lanes, window)
+    return pr
