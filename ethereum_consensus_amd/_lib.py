@@ -87,6 +87,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_aggregate_verify": (c_int, [u8p, c_u32, u8p, ctypes.c_void_p, c_u32, u8p]),
         "ecgpu_aggregate_sigs": (c_int, [u8p, c_u32, u8p]),
         "ecgpu_aggregate_pks": (c_int, [u8p, c_u32, u8p]),
+        "ecgpu_g1_msm": (c_int, [u8p, u8p, c_u32, c_u32, u8p]),
+        "ecgpu_g2_msm": (c_int, [u8p, u8p, c_u32, c_u32, u8p]),
         "ecgpu_fast_aggregate_verify_batch": (c_int, [u8p, ctypes.c_void_p, u8p, u8p, c_u32, c_int, u8p]),
         "ecgpu_fast_aggregate_verify_batch_dev": (c_int, [u8p, ctypes.c_void_p, c_u32, u8p, u8p, c_u32, c_int, u8p,
                                                           ctypes.c_void_p]),

@@ -338,3 +338,25 @@ def fast_aggregate_verify_batch_multi(devices: Sequence[int], public_keys: bytes
     _lib.check(L.ecgpu_fast_aggregate_verify_batch_multi(devs, len(devices), _buf(public_keys), off, _buf(msgs32), _buf(signatures), n,
                                                          1 if eth else 0, out), "ecgpu_fast_aggregate_verify_batch_multi")
     return out.raw[:n]
+
+
+def g1_multi_scalar_mul(public_keys: Sequence[bytes], scalars: Sequence[int], scalar_bits: int = 255) -> bytes:
+    """sum_i [k_i] P_i over G1 (compressed in, compressed out); points validated like `PublicKey -> blst key`"""
+    L = _lib.load()
+    out = ctypes.create_string_buffer(48)
+    sc = b"".join(int(k).to_bytes(32, "big") for k in scalars)
+    rc = L.ecgpu_g1_msm(_buf(b"".join(_pk(p) for p in public_keys)), _buf(sc), len(public_keys), scalar_bits, out)
+    _lib.check(rc, "ecgpu_g1_msm")
+    _raise_for_aggregate(rc)
+    return out.raw
+
+
+def g2_multi_scalar_mul(signatures: Sequence[bytes], scalars: Sequence[int], scalar_bits: int = 255) -> bytes:
+    """sum_i [k_i] Q_i over G2 (compressed in, compressed out); points decoded and group-checked like `aggregate` does"""
+    L = _lib.load()
+    out = ctypes.create_string_buffer(96)
+    sc = b"".join(int(k).to_bytes(32, "big") for k in scalars)
+    rc = L.ecgpu_g2_msm(_buf(b"".join(_sig(s) for s in signatures)), _buf(sc), len(signatures), scalar_bits, out)
+    _lib.check(rc, "ecgpu_g2_msm")
+    _raise_for_aggregate(rc)
+    return out.raw

@@ -186,6 +186,26 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_sign(const u8* sks
     for (int j = 0; j < 96; j++) sigs96[96 * (size_t)i + j] = b[j];
 }
 
+// ---- multi-scalar multiplication (north_star: "G1/G2 addition and multi-scalar-mult") ----------------------------------------
+// sum_i [k_i] P_i: lane i replaces its decoded point by [k_i] P_i (double-and-add over the low `bits` of the 32-byte
+// big-endian scalar; points whose status is non-zero are left alone: k_sum reports the first of them), then the tree sum of
+// k_sum adds the products.  Per-lane scalar multiples rather than buckets: the consumer is the random-coefficient batch check
+// (64-bit scalars, groups of tens of points), where a bucket method has nothing to amortise.
+template <class F>
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_scalar_mul(Aff<F>* pts, const u8* st, const u8* scalars32, u32 bits, u32 n) {
+    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
+    if (i >= n || (st && st[i]) || pts[i].inf) return;
+    u32 k[8];
+    load_scalar_be32(k, scalars32 + 32 * (size_t)i);
+    for (u32 b = bits; b < 256; b++) k[b >> 5] &= ~(1u << (b & 31));
+    Jac<F> pj, r;
+    Aff<F> a = pts[i];
+    jac_from_aff(pj, a);
+    jac_mul_scalar(r, pj, k, (int)((bits + 31) / 32));
+    jac_to_aff(a, r);
+    pts[i] = a;
+}
+
 // ---- host drivers ----------------------------------------------------------------------------
 static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
@@ -608,6 +628,70 @@ int ecgpu_aggregate_pks(const uint8_t* pks48, uint32_t n, uint8_t* out48) {
     ECG_HIP_CHECK(hipStreamSynchronize(k.s));
     if (h[48]) return (int)h[48];
     for (int i = 0; i < 48; i++) out48[i] = h[i];
+    return ECGPU_SUCCESS;
+}
+
+// sum_i [k_i] P_i over G1: points through key_validate like every public key (a bad one -> its BLST_ERROR), 48-byte result
+int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uint32_t scalar_bits, uint8_t* out48) {
+    if (n == 0) return ECGPU_EMPTY_AGGREGATE;
+    if (!pks48 || !scalars32 || !out48 || scalar_bits == 0 || scalar_bits > 256) return ECGPU_ERR_BAD_ARG;
+    CallCtx k;
+    int rc = begin_call(k, nullptr, (size_t)n * (48 + 32 + sizeof(A1) + 1) + sizeof(A1) + 8192);
+    if (rc) return rc;
+    u8 *d_pks, *d_sc;
+    if ((rc = h2d(k, d_pks, pks48, (size_t)n * 48))) return rc;
+    if ((rc = h2d(k, d_sc, scalars32, (size_t)n * 32))) return rc;
+    A1* pts = (A1*)k.ar->take((size_t)n * sizeof(A1));
+    u8* st = k.ar->take(n);
+    A1* sum = (A1*)k.ar->take(sizeof(A1));
+    u8* d_out = k.ar->take(48 + 1);
+    if (!pts || !st || !sum || !d_out) return ECGPU_ERR_OOM;
+    hipLaunchKernelGGL(k_pk_validate, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_pks, n, pts, st);
+    {
+        ProfScope ps("bls_scalar_mul_g1", k.s);
+        hipLaunchKernelGGL(k_scalar_mul<Fp>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st, (const u8*)d_sc, scalar_bits, n);
+    }
+    launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48);
+    hipLaunchKernelGGL(k_compress_g1, dim3(1), dim3(64), 0, k.s, (const A1*)sum, d_out);
+    ECG_HIP_CHECK(hipGetLastError());
+    u8 h[49];
+    ECG_HIP_CHECK(hipMemcpyAsync(h, d_out, 49, hipMemcpyDeviceToHost, k.s));
+    ECG_HIP_CHECK(hipStreamSynchronize(k.s));
+    if (h[48]) return (int)h[48];
+    for (int i = 0; i < 48; i++) out48[i] = h[i];
+    return ECGPU_SUCCESS;
+}
+
+// sum_i [k_i] Q_i over G2: points decoded and group-checked like crypto::aggregate does (crypto/bls.rs:79-93), 96-byte result
+int ecgpu_g2_msm(const uint8_t* sigs96, const uint8_t* scalars32, uint32_t n, uint32_t scalar_bits, uint8_t* out96) {
+    if (n == 0) return ECGPU_EMPTY_AGGREGATE;
+    if (!sigs96 || !scalars32 || !out96 || scalar_bits == 0 || scalar_bits > 256) return ECGPU_ERR_BAD_ARG;
+    CallCtx k;
+    int rc = begin_call(k, nullptr, (size_t)n * (96 + 32 + sizeof(A2) + 2) + sizeof(A2) + 8192);
+    if (rc) return rc;
+    u8 *d_sigs, *d_sc;
+    if ((rc = h2d(k, d_sigs, sigs96, (size_t)n * 96))) return rc;
+    if ((rc = h2d(k, d_sc, scalars32, (size_t)n * 32))) return rc;
+    A2* pts = (A2*)k.ar->take((size_t)n * sizeof(A2));
+    u8* st_dec = k.ar->take(n);
+    u8* st_grp = k.ar->take(n);
+    A2* sum = (A2*)k.ar->take(sizeof(A2));
+    u8* d_out = k.ar->take(96 + 1);
+    if (!pts || !st_dec || !st_grp || !sum || !d_out) return ECGPU_ERR_OOM;
+    hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_sigs, n, pts, st_dec, st_grp);
+    hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(64), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
+    {
+        ProfScope ps("bls_scalar_mul_g2", k.s);
+        hipLaunchKernelGGL(k_scalar_mul<Fp2>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st_dec, (const u8*)d_sc, scalar_bits, n);
+    }
+    launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr);
+    hipLaunchKernelGGL(k_compress_g2, dim3(1), dim3(64), 0, k.s, (const A2*)sum, d_out);
+    ECG_HIP_CHECK(hipGetLastError());
+    u8 h[97];
+    ECG_HIP_CHECK(hipMemcpyAsync(h, d_out, 97, hipMemcpyDeviceToHost, k.s));
+    ECG_HIP_CHECK(hipStreamSynchronize(k.s));
+    if (h[96]) return (int)h[96];
+    for (int i = 0; i < 96; i++) out96[i] = h[i];
     return ECGPU_SUCCESS;
 }
 

@@ -225,6 +225,14 @@ int ecgpu_aggregate_verify(const uint8_t* pks48, uint32_t n_pks, const uint8_t* 
 int ecgpu_aggregate_sigs(const uint8_t* sigs96, uint32_t n, uint8_t out[96]);
 int ecgpu_aggregate_pks(const uint8_t* pks48, uint32_t n, uint8_t out[48]);
 
+/* Multi-scalar multiplication sum_i [k_i] P_i over G1 / G2 (the north_star's "G1/G2 addition and multi-scalar-mult"; what a
+ * random-coefficient batch check -- blst's verify_multiple_aggregate_signatures -- is made of).  Points arrive compressed and
+ * are validated like the reference validates them (G1: key_validate, crypto/bls.rs:279-285; G2: from_bytes + the group
+ * check of aggregate, :86-90): a bad point returns its BLST_ERROR.  Scalars: 32 big-endian bytes each, of which the low
+ * `scalar_bits` (1..256) are used -- 64 for batch-check coefficients.  n == 0 -> ECGPU_EMPTY_AGGREGATE. */
+int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uint32_t scalar_bits, uint8_t out48[48]);
+int ecgpu_g2_msm(const uint8_t* sigs96, const uint8_t* scalars32, uint32_t n, uint32_t scalar_bits, uint8_t out96[96]);
+
 /* Batch entry (one call per block / per epoch instead of one call per signature):
  * n independent fast_aggregate_verify over 32-byte messages (every in-crate caller signs a
  * 32-byte signing root, signing.rs:14-22).  Tuple i uses public keys pk_off[i]..pk_off[i+1] of

@@ -558,3 +558,39 @@ def test_several_devices_in_one_process(gpu):
     for devs in ([0], [0, 0], [0, 0, 0, 0, 0]):
         assert ssz.hash_tree_root_validators_multi(devs, v) == want_root
     assert ssz.hash_tree_root_validators_multi([0, 0], b"") == ssz.hash_tree_root_validators(b"")
+
+
+def test_multi_scalar_multiplication(gpu):
+    """north_star "G1/G2 ... multi-scalar-mult": sum_i [k_i] P_i against the oracle's group law (oracle/bls12_381.py g1_mul /
+    g2_mul / adds) for 64-bit and 255-bit scalars, with repeated points, a zero scalar, the point at infinity among the
+    inputs, and the error of a point outside the group."""
+    from ethereum_consensus_amd import bls as M
+    from ethereum_consensus_amd import synthetic as syn
+    r = random.Random(99)
+    n = 37
+    sks = [r.randrange(1, B.R) for _ in range(n)]
+    pks = [B.sk_to_pk(s) for s in sks[:8]] + [gpu.sk_to_pk_batch(sk_bytes(s)) for s in sks[8:]]
+    pks[5] = pks[4]
+    sks[5] = sks[4]
+    H = B.hash_to_g2(b"msm")
+    sigs = [B.g2_compress(B.g2_mul(H, s)) for s in sks[:12]] + [B.INFINITY_SIGNATURE]
+    for bits in (64, 255):
+        ks = [r.randrange(1 << bits) % B.R for _ in range(n)]
+        ks[3] = 0
+        # G1: sum k_i * (sk_i G) = (sum k_i sk_i) G
+        want = B.g1_compress(B.g1_mul(B.G1, sum(k * s for k, s in zip(ks, sks)) % B.R))
+        assert M.g1_multi_scalar_mul(pks, ks, bits) == want, bits
+        # G2, infinity among the points
+        k2 = ks[:13]
+        want2 = B.g2_compress(B.g2_mul(H, sum(k * s for k, s in zip(k2[:12], sks[:12])) % B.R))
+        assert M.g2_multi_scalar_mul(sigs, k2, bits) == want2, bits
+    # scalar_bits masks the high part of the 32-byte scalars
+    big = [(1 << 200) + 5, 7]
+    assert M.g1_multi_scalar_mul(pks[:2], big, 64) == M.g1_multi_scalar_mul(pks[:2], [5, 7], 64)
+    with pytest.raises(M.BLSTError) as e:
+        M.g1_multi_scalar_mul([pks[0], syn.off_subgroup_public_key(0)], [1, 2], 64)
+    assert e.value.code == 3
+    with pytest.raises(M.BLSTError):
+        M.g2_multi_scalar_mul([sigs[0], syn.off_subgroup_signature(0)], [1, 2], 64)
+    with pytest.raises(M.EmptyAggregate):
+        M.g1_multi_scalar_mul([], [])
