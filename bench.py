@@ -165,6 +165,17 @@ BLS_MULTS_PER_SIG = sum(m * 351 + s * 273 + x for m, s, x in BLS_OPS.values())
 BLS_BYTES_PER_SIG = 48 + 32 + 96 + 1  # K = 1 tuple in, status byte out
 
 
+def vm3_multiplies_per_tuple() -> int:
+    """useful multiply instructions of one pairing check on the sum-of-products lane groups, as counted by the generator
+    (tools/gen_bls_vm3.py writes them into the program header)"""
+    import re
+    try:
+        text = open(os.path.join(ROOT, "ethereum_consensus_amd", "csrc", "bls_vm3_prog.h")).read()
+        return sum(int(x) for x in re.findall(r"#define ECG_VM3_[AC]_MADS (\d+)", text))
+    except OSError:
+        return 0
+
+
 def S(tag: bytes, i: int) -> bytes:
     import hashlib
     return hashlib.sha256(b"ecgpu/v1/" + tag + b"/" + i.to_bytes(4, "little")).digest()
@@ -258,8 +269,12 @@ def run_bls(args, L, torch, dist, rank, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     build = int(L.ecgpu_bls_tower())
-    ops = BLS_OPS_BY_BUILD.get(build, BLS_OPS)
+    ops = dict(BLS_OPS_BY_BUILD.get(build, BLS_OPS))
     pairing_kernel = PAIRING_KERNEL_BY_BUILD.get(build, "k_pairing")
+    path = int(L.ecgpu_bls_last_pairing_path())
+    if path == 3:  # the sum-of-products lane groups ran the pairing check (ECGPU_PAIRING=vm3, or a box with slow instruction fetch)
+        pairing_kernel = "k_vm3_pair_a + k_vm3_pair_c"
+        ops["bls_pairing"] = (0, 0, vm3_multiplies_per_tuple())
     mults_per_sig = sum(m * 351 + s_ * 273 + x for m, s_, x in ops.values())
     stages = {}
     for tag in ops:
@@ -275,7 +290,12 @@ def run_bls(args, L, torch, dist, rank, world):
     alg_bytes = BLS_BYTES_PER_SIG * n
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     mul_ops = {k: (m * 351 + s_ * 273 + x) * n for k, (m, s_, x) in ops.items()}
-    traffic = pmc_traffic(pairing_kernel)  # None unless a PMC pass of THIS kernel build is committed under profiles/
+    # None unless a PMC pass of THIS kernel build is committed under profiles/
+    if path == 3:
+        ta, tc = pmc_traffic("k_vm3_pair_a"), pmc_traffic("k_vm3_pair_c")
+        traffic = None if not (ta and tc) else {"bytes_per_launch": ta["bytes_per_launch"] + tc["bytes_per_launch"], "parts": [ta, tc]}
+    else:
+        traffic = pmc_traffic(pairing_kernel)
     m_cpu = min(n, 16384)
     return dict(
         host_sample=(bytes(h_pk[:48 * m_cpu]), bytes(msgs[:32 * m_cpu]), bytes(h_sig[:96 * m_cpu]), bytes(want_bytes[:m_cpu])),
@@ -287,7 +307,7 @@ def run_bls(args, L, torch, dist, rank, world):
                 "tuples": n, "semantics": "reference: every key decompressed + subgroup-checked, every signature "
                                           "decompressed + subgroup-checked, every message hashed to G2, per-tuple pairing check",
                 "sharding": "one independent batch per GPU; all-gather of the status bytes every step"},
-        roofline={"bound": "hbm", "kernel": pairing_kernel, "kernel_build": {1: "sums of products", 2: "compact-code tower"}.get(build, "?"),
+        roofline={"bound": "hbm", "kernel": pairing_kernel, "kernel_build": "sum-of-products lane groups (vm3)" if path == 3 else {1: "sums of products", 2: "compact-code tower"}.get(build, "?"),
                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"), "traffic_detail": traffic,
                   "algorithmic_bytes_per_launch": alg_bytes,
@@ -606,6 +626,57 @@ def run_slots(args, L, torch, dist, rank, world, n_sync=512):
                "applied_patch_sets": applied, "hash64_of_last_root": hashes_per_root})
 
 
+def run_block(args, L, torch, n_val=1 << 16):
+    """Whole-block batching: every verification of ONE block -- 128 attestations x ~400 keys
+    (phase0/block_processing.rs:752-761), the sync aggregate over ~95 % of 512 keys (altair/block_processing.rs:226-234), 16
+    single-key operations (proposer, randao, exits ...) -- pushed into the collector (ecgpu_batch_*) and verified in one pass;
+    host memory in, statuses out (the shape the Rust caller has).  Timed with raw keys (reference semantics: every key
+    decompressed + checked) and through a validated-key registry.  Secondary line."""
+    from ethereum_consensus_amd import bls
+    sk = bls_inputs(n_val, 0)[0]
+    sks = [int.from_bytes(sk[32 * i:32 * i + 32], "big") for i in range(n_val)]
+    reg_keys = bls.sk_to_pk_batch(sk)
+    key = lambda i: reg_keys[48 * i:48 * i + 48]
+    members = [[(c * 509 + j * 7) % n_val for j in range(400)] for c in range(128)]
+    sync = [i for i in range(512) if i % 20 != 3]
+    single = list(range(1000, 1016))
+    lists = members + [sync] + [[i] for i in single]
+    msgs = [S(b"blk", c) for c in range(len(lists))]
+    agg = [sum(sks[i] for i in l) % R_ORDER for l in lists]
+    sigs = bls.sign_batch(b"".join(a.to_bytes(32, "big") for a in agg), msgs)
+    eth = [0] * 128 + [1] + [0] * 16
+    sig = lambda t: sigs[96 * t:96 * t + 96]
+    msgs[7] = S(b"blk", 9999)  # one attestation over the wrong message
+    want = [5 if t == 7 else 0 for t in range(len(lists))]
+    reg = bls.ValidatorKeyRegistry(n_val)
+    reg.set(0, reg_keys)
+    out = {}
+    for name, registry in (("reference_semantics", None), ("validated_key_registry", reg)):
+        b = bls.SignatureBatch(registry)
+        best = None
+        for rep in range(4):
+            t0 = time.perf_counter()
+            for t, l in enumerate(lists):
+                if registry is None:
+                    b.fast_aggregate_verify([key(i) for i in l], msgs[t], sig(t), eth=bool(eth[t]))
+                else:
+                    b.fast_aggregate_verify_indexed(l, msgs[t], sig(t), eth=bool(eth[t]))
+            t1 = time.perf_counter()
+            got = list(b.flush())
+            t2 = time.perf_counter()
+            if rep:  # the first pass warms the arenas
+                best = (t2 - t1, t1 - t0) if best is None or t2 - t1 < best[0] else best
+            assert got == want, (name, got[:10])
+        b.close()
+        out[name] = {"block_verify_ms": best[0] * 1e3, "push_ms_python": best[1] * 1e3}
+    reg.close()
+    n_sigs = sum(len(l) for l in lists)
+    return {"verifications": len(lists), "signatures": n_sigs, **out,
+            "note": "flush() of one block's verifications (host buffers in, statuses out); the scalar entry is ~20 ms of dependent latency "
+                    "EACH, so the same block through 145 scalar calls costs ~3 s; push_ms_python is ctypes marshalling, not the library",
+            "check": {"statuses_match_construction": True}}
+
+
 def _prof(L, tag):
     ms = ctypes.c_double(0)
     nl = ctypes.c_uint64(0)
@@ -669,6 +740,7 @@ def main():
         line = finish(r_bls)
         if world == 1 and not args.no_aggregates:
             line["aggregates_k2048"] = run_bls_aggregate(args, L, torch, dist, rank, world)
+            line["block"] = run_block(args, L, torch)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_bls(r_bls["host_sample"])
     if workload in ("merkle", "both"):

@@ -356,10 +356,8 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
                                                                          (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n,
                                                                          eth_variant, d_status, xfer);
             if (rc) return rc;
-            // tuples with a point at infinity in the pairing (signature 0xc0.., H(m) = inf): rare, branchy lane kernel
-            hipLaunchKernelGGL(g_tower.load() == 2 ? k_pairing_calls : k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg,
-                               (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96,
-                               n, eth_variant, d_status, 1);
+            // (tuples whose pairing involves a point at infinity are decided in the lane groups' status step: such a pair
+            // contributes 1, and a single non-degenerate pair cannot be 1)
         }
     }
     ECG_HIP_CHECK(hipGetLastError());

@@ -158,8 +158,12 @@ __global__ void __launch_bounds__(64) k_vm2_pair_c(Vm2Desc d, const u32* xfer, c
         const bool agg_inf = agg[tuple].inf != 0;
         u8 st = combine_fav_status(k, eth_variant != 0, sig_inf_bytes, st_pk[tuple], st_dec[tuple], st_grp[tuple], agg_inf, 0xff);
         if (st == 0xff) {
-            if (sigpts[tuple].inf || hpts[tuple].inf)
-                st = VM_NEEDS_LANE_PATH;
+            // A pair with a point at infinity contributes 1 to the product, and e(P, Q) != 1 for non-zero P in G1, Q in G2
+            // (the pairing is non-degenerate on the order-r subgroups; the key was validated, H(m) is cofactor-cleared, the
+            // signature passed its group check): the infinity cases are decided without evaluating anything.
+            const bool s_inf = sigpts[tuple].inf != 0, h_inf = hpts[tuple].inf != 0;
+            if (s_inf || h_inf)
+                st = (s_inf && h_inf) ? ECGPU_SUCCESS : ECGPU_VERIFY_FAIL;
             else
                 st = not_one[tl] ? ECGPU_VERIFY_FAIL : ECGPU_SUCCESS;
         }
