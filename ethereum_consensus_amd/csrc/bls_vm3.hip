@@ -63,7 +63,7 @@ static int upload3(const unsigned int* h, size_t n, const u32** d) {
 
 int init_vm3_tables() {
     static_assert(ECG_VM3_A_NIN == 10 && ECG_VM3_A_NOUT == 14 && ECG_VM3_C_NIN == 14 && ECG_VM3_C_NOUT == 12, "program interface");
-    static_assert(64 % ECG_VM3_LANES == 0 && ECG_VM3_LANES % 2 == 0, "lane groups tile a wave; results travel in lane pairs");
+    static_assert(ECG_VM3_LANES <= 64 && ECG_VM3_LANES % 2 == 0, "results travel in lane pairs; lanes beyond TPW groups of a wave idle");
     static_assert(ECG_VM3_CONST_BASE == VM3_CONST_BASE, "generator and kernel agree on where the constants start");
     VM3_FILL(g_vm3_a, A);
     VM3_FILL(g_vm3_c, C);
@@ -81,13 +81,17 @@ ECG_D Fp vm3_round_sum(const Vm3Regs& R, const uint4 w01) {
 }
 
 // one lane group through a whole program; R = the tuple's register file in LDS
-ECG_D void vm3_run(const Vm3Desc& d, const Vm3Regs& R, u32 slot) {
+ECG_D void vm3_run(const Vm3Desc& d, const Vm3Regs& R, u32 slot, bool idle = false) {
+    // `idle`: a lane beyond the last whole group of the wave (64 is not a multiple of every group size): it runs the rounds
+    // with all-zero descriptors -- operands ZERO, no stores
     const uint4* pp = (const uint4*)d.prog + (size_t)slot * 2;
-    uint4 w01 = pp[0], w23 = pp[1];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 w01 = idle ? zero4 : pp[0], w23 = idle ? zero4 : pp[1];
     u32 h = d.hdr[0];
     for (u32 r = 0; r < d.rounds; r++) {
         const u32 rn = (r + 1 < d.rounds) ? r + 1 : r;
-        const uint4 n01 = pp[(size_t)rn * VM3_G * 2], n23 = pp[(size_t)rn * VM3_G * 2 + 1];  // next round's descriptor, in flight
+        uint4 n01 = pp[(size_t)rn * VM3_G * 2], n23 = pp[(size_t)rn * VM3_G * 2 + 1];  // next round's descriptor, in flight
+        if (idle) n01 = n23 = zero4;
         const u32 hn = d.hdr[rn];
         const u32 hu = (u32)__builtin_amdgcn_readfirstlane((int)h);
         const u32 n = hu & 255, nder = (hu >> 8) & 255;
@@ -123,7 +127,7 @@ ECG_D void vm3_run(const Vm3Desc& d, const Vm3Regs& R, u32 slot) {
 
 // register 0 of every tuple = ZERO; the constants once per workgroup, behind the tuples' slices
 ECG_D Vm3Regs vm3_setup(const Vm3Desc& d, u32* lds, u32 lane) {
-    const u32 slot = lane % VM3_G, tl = lane / VM3_G;
+    const u32 slot = lane % VM3_G, tl = lane / VM3_G < VM3_TPW ? lane / VM3_G : VM3_TPW - 1;  // idle lanes look at the last slice
     u32* own = lds + tl * d.nreg * VM3_REG_DW;
     u32* consts = lds + VM3_TPW * d.nreg * VM3_REG_DW;
     for (u32 i = slot; i < VM3_REG_DW; i += VM3_G) own[i] = 0;
@@ -138,10 +142,11 @@ ECG_D Vm3Regs vm3_setup(const Vm3Desc& d, u32* lds, u32 lane) {
 __global__ void __launch_bounds__(64) k_vm3_pair_a(Vm3Desc d, const A1* agg, const A2* hpts, const A2* sigpts, u32 n, u32* xfer) {
     extern __shared__ u32 vm3_lds[];
     const u32 lane = threadIdx.x, slot = lane % VM3_G, tl = lane / VM3_G;
-    const u32 tuple = blockIdx.x * VM3_TPW + tl;
+    const bool idle = tl >= VM3_TPW;
+    const u32 tuple = idle ? n : blockIdx.x * VM3_TPW + tl;
     const u32 tc = tuple < n ? tuple : n - 1;
     const Vm3Regs R = vm3_setup(d, vm3_lds, lane);
-    for (u32 k = slot; k < 10; k += VM3_G) {
+    for (u32 k = slot; k < 10 && !idle; k += VM3_G) {
         // inputs in the generator's order: PXY = (x, y) of the aggregate key, then HX, HY, SX, SY (c0, c1 each)
         const u32* w = k == 0   ? agg[tc].x.l
                        : k == 1 ? agg[tc].y.l
@@ -152,7 +157,7 @@ __global__ void __launch_bounds__(64) k_vm3_pair_a(Vm3Desc d, const A1* agg, con
         for (u32 i = 0; i < VM3_REG_DW; i++) R.own[d.in_reg[k] * VM3_REG_DW + i] = w[i];
     }
     __syncthreads();
-    vm3_run(d, R, slot);
+    vm3_run(d, R, slot, idle);
     if (tuple < n)
         for (u32 k = slot; k < 13; k += VM3_G) {
             u32* o = xfer + (size_t)tuple * XFER3_STRIDE + k * VM3_REG_DW;
@@ -177,17 +182,18 @@ __global__ void __launch_bounds__(64) k_vm3_pair_c(Vm3Desc d, const u32* xfer, c
     extern __shared__ u32 vm3_lds[];
     __shared__ u32 not_one[VM3_TPW];
     const u32 lane = threadIdx.x, slot = lane % VM3_G, tl = lane / VM3_G;
-    const u32 tuple = blockIdx.x * VM3_TPW + tl;
+    const bool idle = tl >= VM3_TPW;
+    const u32 tuple = idle ? n : blockIdx.x * VM3_TPW + tl;
     const u32 tc = tuple < n ? tuple : n - 1;
     const Vm3Regs R = vm3_setup(d, vm3_lds, lane);
-    for (u32 k = slot; k < 14; k += VM3_G) {
+    for (u32 k = slot; k < 14 && !idle; k += VM3_G) {
         const u32* w = xfer + (size_t)tc * XFER3_STRIDE + (k < 12 ? k : k + 2) * VM3_REG_DW;
         for (u32 i = 0; i < VM3_REG_DW; i++) R.own[d.in_reg[k] * VM3_REG_DW + i] = w[i];
     }
-    if (slot == 0) not_one[tl] = 0;
+    if (slot == 0 && !idle) not_one[tl] = 0;
     __syncthreads();
-    vm3_run(d, R, slot);
-    for (u32 k = slot; k < 12; k += VM3_G) {
+    vm3_run(d, R, slot, idle);
+    for (u32 k = slot; k < 12 && !idle; k += VM3_G) {
         const Fp v = vm3_load(R, d.out_reg[k]);
         const bool ok = k == 0 ? fp_eq(v, fp_one()) : fp_is_zero(v);
         if (!ok) not_one[tl] = 1;
