@@ -101,8 +101,12 @@ pub fn hash<D: AsRef<[u8]>>(data: D) -> Bytes32 {
     out
 }
 
-/// crypto/bls.rs:64-77
+/// crypto/bls.rs:64-77.  With a collector installed on this thread (`with_collector`) the verification is recorded and
+/// `Ok(())` returned; its verdict is in `SignatureBatch::flush()`.
 pub fn verify_signature(public_key: &PublicKeyBytes, msg: &[u8], signature: &SignatureBytes) -> Result<(), Error> {
+    if let Some(r) = deferred(|b| b.verify_signature(public_key, msg, signature)) {
+        return r;
+    }
     verify_status_to_result(unsafe { sys::ecgpu_verify(public_key.as_ptr(), msg.as_ptr(), msg.len(), signature.as_ptr()) })
 }
 
@@ -141,6 +145,9 @@ pub fn aggregate_verify(public_keys: &[PublicKeyBytes], msgs: &[&[u8]], signatur
 
 /// crypto/bls.rs:114-132
 pub fn fast_aggregate_verify(public_keys: &[&PublicKeyBytes], msg: &[u8], signature: &SignatureBytes) -> Result<(), Error> {
+    if let Some(r) = deferred(|b| b.fast_aggregate_verify(public_keys, msg, signature)) {
+        return r;
+    }
     let pks = concat48(public_keys);
     verify_status_to_result(unsafe {
         sys::ecgpu_fast_aggregate_verify(pks.as_ptr(), public_keys.len() as u32, msg.as_ptr(), msg.len(), signature.as_ptr(), 0)
@@ -163,6 +170,9 @@ pub fn eth_aggregate_public_keys(public_keys: &[PublicKeyBytes]) -> Result<Publi
 
 /// crypto/bls.rs:150-160 (the `public_keys.is_empty() && signature.is_infinity()` rule is inside the backend: eth_variant = 1)
 pub fn eth_fast_aggregate_verify(public_keys: &[&PublicKeyBytes], message: &[u8], signature: &SignatureBytes) -> Result<(), Error> {
+    if let Some(r) = deferred(|b| b.eth_fast_aggregate_verify(public_keys, message, signature)) {
+        return r;
+    }
     let pks = concat48(public_keys);
     verify_status_to_result(unsafe {
         sys::ecgpu_fast_aggregate_verify(pks.as_ptr(), public_keys.len() as u32, message.as_ptr(), message.len(),
@@ -183,12 +193,27 @@ unsafe impl Sync for SignatureBatch {}
 
 impl SignatureBatch {
     pub fn new() -> Self {
+        Self::create(std::ptr::null())
+    }
+    /// a batch whose `*_indexed` pushes name their keys by validator index in `registry` (which must outlive the batch)
+    pub fn with_registry(registry: &ValidatorKeyRegistry) -> Self {
+        Self::create(registry.raw)
+    }
+    fn create(reg: *const sys::ecgpu_registry_t) -> Self {
         let mut raw = std::ptr::null_mut();
-        let rc = unsafe { sys::ecgpu_batch_create(std::ptr::null(), &mut raw) };
+        let rc = unsafe { sys::ecgpu_batch_create(reg, &mut raw) };
         if rc != 0 {
             backend_fault(rc);
         }
         Self { raw }
+    }
+    /// `fast_aggregate_verify` / `eth_fast_aggregate_verify` over the registry's keys at `indices` (phase0/helpers.rs:123-140
+    /// gathers exactly these keys out of `state.validators`)
+    pub fn fast_aggregate_verify_indexed(&self, indices: &[u32], msg: &[u8], signature: &SignatureBytes, eth_variant: bool) -> usize {
+        Self::pushed(unsafe {
+            sys::ecgpu_batch_push_indexed(self.raw, indices.as_ptr(), indices.len() as u32, msg.as_ptr(), msg.len(), signature.as_ptr(),
+                                          eth_variant as c_int)
+        })
     }
     fn pushed(rc: i64) -> usize {
         if rc < 0 {
@@ -237,6 +262,171 @@ impl Default for SignatureBatch {
 impl Drop for SignatureBatch {
     fn drop(&mut self) {
         unsafe { sys::ecgpu_batch_destroy(self.raw) }
+    }
+}
+
+// ---- the collector: whole-block batching without touching a caller ---------------------------------------------------------
+thread_local! {
+    static COLLECTOR: std::cell::Cell<*const SignatureBatch> = std::cell::Cell::new(std::ptr::null());
+}
+
+/// `Some(Ok(()))` after recording the verification in the thread's collector, `None` when none is installed
+fn deferred(push: impl FnOnce(&SignatureBatch) -> usize) -> Option<Result<(), Error>> {
+    let b = COLLECTOR.with(|c| c.get());
+    if b.is_null() {
+        return None;
+    }
+    push(unsafe { &*b });
+    Some(Ok(()))
+}
+
+/// Runs `f` with `batch` installed as this thread's collector: `verify_signature`, `fast_aggregate_verify` and
+/// `eth_fast_aggregate_verify` called inside `f` (through crypto/bls.rs with `--features gpu`) record their arguments, return
+/// `Ok(())`, and are verified together by `batch.flush()`.  The intended `f` is one `process_block`
+/// (phase0/state_transition.rs:48-62 and the same function of the later forks):
+///
+/// ```ignore
+/// let batch = SignatureBatch::new();
+/// let outcome = with_collector(&batch, || process_block(state, block, context));
+/// match batch.flush().into_iter().position(|r| r.is_err()) {
+///     Some(_) => Err(Error::InvalidSignature.into()),   // a signature pushed BEFORE `outcome`'s error (if any) was raised
+///     None => outcome,
+/// }
+/// ```
+///
+/// Validity of the block is decided exactly as by the reference (every recorded check must pass, and the tickets are in
+/// program order, so the first failing ticket is the reference's first failing call).  Two things the caller owns:
+/// * a call site whose RESULT STEERS CONTROL FLOW must not be deferred -- there is one: `process_deposit` skips a deposit
+///   with an invalid signature instead of failing (phase0/block_processing.rs:389); wrap that call in `immediate`
+///   (rust/patches/ethereum-consensus-gpu-feature.patch does);
+/// * the reference wraps a failed check in a call-site specific error (`InvalidOperation::…`); a deferred failure surfaces as
+///   the bare `Error::InvalidSignature`.  A host that reports the exact variant re-runs the (invalid, hence rare) block on
+///   its pre-state without a collector.
+pub fn with_collector<R>(batch: &SignatureBatch, f: impl FnOnce() -> R) -> R {
+    struct Restore(*const SignatureBatch);
+    impl Drop for Restore {
+        fn drop(&mut self) {
+            COLLECTOR.with(|c| c.set(self.0));
+        }
+    }
+    let _restore = Restore(COLLECTOR.with(|c| c.replace(batch as *const SignatureBatch)));
+    f()
+}
+
+/// Runs `f` with no collector installed (verifications inside it happen now and return their verdict)
+pub fn immediate<R>(f: impl FnOnce() -> R) -> R {
+    struct Restore(*const SignatureBatch);
+    impl Drop for Restore {
+        fn drop(&mut self) {
+            COLLECTOR.with(|c| c.set(self.0));
+        }
+    }
+    let _restore = Restore(COLLECTOR.with(|c| c.replace(std::ptr::null())));
+    f()
+}
+
+/// What `PublicKey -> blst key` (crypto/bls.rs:279-285) yields for every validator index, kept in HBM: the affine point or the
+/// BLST_ERROR.  `set` converts; the `*_indexed` calls gather by index instead of decompressing and subgroup-checking every key of
+/// every committee on every call.  Results are those of the by-value calls over the same keys.
+pub struct ValidatorKeyRegistry {
+    raw: *mut sys::ecgpu_registry_t,
+}
+unsafe impl Send for ValidatorKeyRegistry {}
+
+impl ValidatorKeyRegistry {
+    pub fn new(capacity: usize) -> Self {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { sys::ecgpu_registry_create(capacity as u64, &mut raw) };
+        if rc != 0 {
+            backend_fault(rc);
+        }
+        Self { raw }
+    }
+    /// genesis / state load: all keys; `add_validator_to_registry` (phase0/block_processing.rs:317-349): one key at `first_index`
+    pub fn set(&mut self, first_index: usize, keys: &[PublicKeyBytes]) {
+        let rc = unsafe { sys::ecgpu_registry_set(self.raw, first_index as u64, keys.as_ptr() as *const u8, keys.len() as u64) };
+        if rc != 0 {
+            backend_fault(rc);
+        }
+    }
+    /// one `fast_aggregate_verify` per (indices, message, signature); 32-byte messages (signing roots)
+    pub fn fast_aggregate_verify_batch(&self, indices: &[&[u32]], msgs: &[Bytes32], signatures: &[SignatureBytes], eth_variant: bool)
+        -> Vec<Result<(), Error>> {
+        assert!(indices.len() == msgs.len() && msgs.len() == signatures.len());
+        let mut flat = Vec::new();
+        let mut off = vec![0u32];
+        for l in indices {
+            flat.extend_from_slice(l);
+            off.push(flat.len() as u32);
+        }
+        let n = msgs.len();
+        let mut st = vec![0u8; n.max(1)];
+        let rc = unsafe {
+            sys::ecgpu_fast_aggregate_verify_indexed_batch(self.raw, flat.as_ptr(), off.as_ptr(), msgs.as_ptr() as *const u8,
+                                                           signatures.as_ptr() as *const u8, n as u32, eth_variant as c_int,
+                                                           st.as_mut_ptr())
+        };
+        if rc != 0 {
+            backend_fault(rc);
+        }
+        st[..n].iter().map(|&s| verify_status_to_result(s as c_int)).collect()
+    }
+}
+impl Drop for ValidatorKeyRegistry {
+    fn drop(&mut self) {
+        unsafe { sys::ecgpu_registry_destroy(self.raw) }
+    }
+}
+
+/// Batches held in arrays (a caller that already collected its tuples) and several GPUs under one process.
+pub mod batch {
+    use super::{backend_fault, sys, verify_status_to_result, Bytes32, Error, PublicKeyBytes, SignatureBytes};
+    use std::os::raw::c_int;
+
+    /// binds the calling thread to `device`: every later call of this thread runs there (streams, tables and scratch are per
+    /// (thread, device))
+    pub fn bind_thread(device: i32) {
+        let rc = unsafe { sys::ecgpu_bind_thread(device) };
+        if rc != 0 {
+            backend_fault(rc);
+        }
+    }
+
+    fn flatten(keys: &[&[PublicKeyBytes]]) -> (Vec<u8>, Vec<u32>) {
+        let mut flat = Vec::new();
+        let mut off = vec![0u32];
+        for l in keys {
+            for k in l.iter() {
+                flat.extend_from_slice(&k[..]);
+            }
+            off.push((flat.len() / 48) as u32);
+        }
+        (flat, off)
+    }
+
+    /// `results[i] == fast_aggregate_verify(keys[i], msgs[i], signatures[i])`, on the thread's device, or — `devices`
+    /// non-empty — split over those devices by worker threads inside the library (no collective: the statuses come back
+    /// through host memory)
+    pub fn fast_aggregate_verify_batch(keys: &[&[PublicKeyBytes]], msgs: &[Bytes32], signatures: &[SignatureBytes], eth_variant: bool,
+                                       devices: &[i32]) -> Vec<Result<(), Error>> {
+        assert!(keys.len() == msgs.len() && msgs.len() == signatures.len());
+        let (flat, off) = flatten(keys);
+        let n = msgs.len();
+        let mut st = vec![0u8; n.max(1)];
+        let rc = unsafe {
+            if devices.is_empty() {
+                sys::ecgpu_fast_aggregate_verify_batch(flat.as_ptr(), off.as_ptr(), msgs.as_ptr() as *const u8,
+                                                       signatures.as_ptr() as *const u8, n as u32, eth_variant as c_int, st.as_mut_ptr())
+            } else {
+                sys::ecgpu_fast_aggregate_verify_batch_multi(devices.as_ptr(), devices.len() as u32, flat.as_ptr(), off.as_ptr(),
+                                                             msgs.as_ptr() as *const u8, signatures.as_ptr() as *const u8, n as u32,
+                                                             eth_variant as c_int, st.as_mut_ptr())
+            }
+        };
+        if rc != 0 {
+            backend_fault(rc);
+        }
+        st[..n].iter().map(|&s| verify_status_to_result(s as c_int)).collect()
     }
 }
 
@@ -290,6 +480,168 @@ pub mod merkle {
         };
         finish(rc, root, 0)
     }
+    /// `List<Validator, LIMIT>::hash_tree_root` split over `devices` (aligned power-of-two subtrees, one worker thread per
+    /// device, the top of the tree on devices[0])
+    pub fn validators_root_multi(devices: &[i32], ssz121: &[u8], limit: usize) -> Result<Bytes32, MerkleizationError> {
+        let mut root = [0u8; 32];
+        let rc = unsafe {
+            sys::ecgpu_htr_validators_multi(devices.as_ptr(), devices.len() as u32, ssz121.as_ptr(), (ssz121.len() / 121) as u64,
+                                            limit as u64, root.as_mut_ptr())
+        };
+        finish(rc, root, limit)
+    }
+
+    /// one step of a proof path: a container field / vector or list element by position, or a list's length node
+    /// (ssz_rs `PathElement::{Field, Index, Length}`; field names resolve to positions on the Rust side)
+    #[derive(Clone, Copy, Debug, PartialEq, Eq)]
+    pub enum PathElement {
+        Index(usize),
+        Length,
+    }
+    fn raw_path(path: &[PathElement]) -> Vec<u64> {
+        path.iter().map(|e| match e { PathElement::Index(i) => *i as u64, PathElement::Length => u64::MAX }).collect()
+    }
+    /// ssz_rs `get_generalized_index` (deneb/beacon_block.rs:139-154 pins 221 for `blob_kzg_commitments[0]` of a block body)
+    pub fn generalized_index(types: &[sys::ecgpu_ssz_type], fields: &[u32], root_type: u32, path: &[PathElement])
+        -> Result<usize, MerkleizationError> {
+        let p = raw_path(path);
+        let mut g = 0u64;
+        let rc = unsafe {
+            sys::ecgpu_ssz_generalized_index(types.as_ptr(), types.len() as u32, fields.as_ptr(), fields.len() as u32, root_type,
+                                             p.as_ptr(), p.len() as u32, &mut g)
+        };
+        match rc {
+            0 => Ok(g as usize),
+            -3 => Err(MerkleizationError::InvalidEncoding),
+            rc => backend_fault(rc),
+        }
+    }
+    /// ssz_rs `Prove::prove(path)` over a serialization: (leaf, branch bottom-up, generalized index, root of the object)
+    /// -- what `deneb/blob_sidecar.rs:70-132` checks with `is_valid_merkle_branch`
+    pub struct Proof {
+        pub leaf: Bytes32,
+        pub branch: Vec<Bytes32>,
+        pub index: usize,
+        pub witness: Bytes32,
+    }
+    pub fn prove(types: &[sys::ecgpu_ssz_type], fields: &[u32], root_type: u32, ssz: &[u8], path: &[PathElement])
+        -> Result<Proof, MerkleizationError> {
+        const MAX_DEPTH: usize = 64;
+        let p = raw_path(path);
+        let (mut leaf, mut root) = ([0u8; 32], [0u8; 32]);
+        let mut branch = vec![0u8; 32 * MAX_DEPTH];
+        let (mut depth, mut g) = (0u32, 0u64);
+        let rc = unsafe {
+            sys::ecgpu_ssz_prove(types.as_ptr(), types.len() as u32, fields.as_ptr(), fields.len() as u32, root_type, ssz.as_ptr(),
+                                 ssz.len() as u64, p.as_ptr(), p.len() as u32, leaf.as_mut_ptr(), branch.as_mut_ptr(),
+                                 MAX_DEPTH as u32, &mut depth, &mut g, root.as_mut_ptr())
+        };
+        match rc {
+            0 => Ok(Proof {
+                leaf,
+                branch: branch[..32 * depth as usize].chunks_exact(32).map(|c| c.try_into().unwrap()).collect(),
+                index: g as usize,
+                witness: root,
+            }),
+            -3 => Err(MerkleizationError::InvalidEncoding),
+            rc => backend_fault(rc),
+        }
+    }
+    /// roots of the fields of a `BeaconState` (fork 0..=4) and the state root: the leaves of the light-client branches
+    /// (altair/light_client.rs: finalized root, current / next sync committee) -- `merkle_proof` over them gives the branch
+    pub fn beacon_state_field_roots(fork: i32, preset: i32, ssz: &[u8]) -> Result<(Vec<Bytes32>, Bytes32), MerkleizationError> {
+        let mut roots = vec![0u8; 32 * 32];
+        let (mut n, mut root) = (0u32, [0u8; 32]);
+        let rc = unsafe {
+            sys::ecgpu_beacon_state_field_roots(fork, ssz.as_ptr(), ssz.len() as u64, preset, roots.as_mut_ptr(), 32, &mut n,
+                                                root.as_mut_ptr())
+        };
+        match rc {
+            0 => Ok((roots[..32 * n as usize].chunks_exact(32).map(|c| c.try_into().unwrap()).collect(), root)),
+            -3 => Err(MerkleizationError::InvalidEncoding),
+            rc => backend_fault(rc),
+        }
+    }
+    /// the branch of chunk `index` in the tree over `chunks` padded to `limit_chunks` leaves (0: next power of two)
+    pub fn merkle_proof(chunks: &[Bytes32], limit_chunks: usize, index: usize) -> Vec<Bytes32> {
+        let width = if limit_chunks != 0 { limit_chunks } else { chunks.len().max(1) }.next_power_of_two();
+        let depth = width.trailing_zeros() as usize;
+        let mut branch = vec![0u8; 32 * depth.max(1)];
+        let rc = unsafe {
+            sys::ecgpu_merkle_proof(chunks.as_ptr() as *const u8, chunks.len() as u64, limit_chunks as u64, index as u64,
+                                    branch.as_mut_ptr())
+        };
+        if rc != 0 {
+            backend_fault(rc);
+        }
+        branch[..32 * depth].chunks_exact(32).map(|c| c.try_into().unwrap()).collect()
+    }
+
+    /// A `BeaconState` kept in HBM between slots: the serialization is uploaded once; `patch` overwrites the
+    /// byte ranges `process_slot` / `process_block` changed, `append` / `truncate` change the length of a list field, and
+    /// `root` re-hashes only what the changes touched in the validator registry.
+    pub struct ResidentState {
+        raw: *mut sys::ecgpu_resident_state_t,
+    }
+    unsafe impl Send for ResidentState {}
+    impl ResidentState {
+        pub fn new(fork: i32, preset: i32, ssz: &[u8]) -> Result<Self, MerkleizationError> {
+            let mut raw = std::ptr::null_mut();
+            match unsafe { sys::ecgpu_resident_state_create_fork(fork, preset, ssz.as_ptr(), ssz.len() as u64, &mut raw) } {
+                0 => Ok(Self { raw }),
+                -3 => Err(MerkleizationError::InvalidEncoding),
+                rc => backend_fault(rc),
+            }
+        }
+        /// `patches`: (byte offset in the serialization, new bytes)
+        pub fn patch(&mut self, patches: &[(u64, &[u8])]) -> Result<(), MerkleizationError> {
+            let mut offsets = Vec::with_capacity(patches.len());
+            let mut data_off = vec![0u64];
+            let mut data = Vec::new();
+            for (o, d) in patches {
+                offsets.push(*o);
+                data.extend_from_slice(d);
+                data_off.push(data.len() as u64);
+            }
+            match unsafe {
+                sys::ecgpu_resident_state_patch(self.raw, offsets.as_ptr(), data_off.as_ptr(), data.as_ptr(), patches.len() as u32)
+            } {
+                0 => Ok(()),
+                -3 => Err(MerkleizationError::InvalidEncoding),
+                rc => backend_fault(rc),
+            }
+        }
+        /// appends whole elements to list field `field` (`sys::ECGPU_STATE_*`): a 121-byte validator record, an 8-byte balance ...
+        pub fn append(&mut self, field: i32, elements: &[u8]) -> Result<(), MerkleizationError> {
+            match unsafe { sys::ecgpu_resident_state_append(self.raw, field, elements.as_ptr(), elements.len() as u64) } {
+                0 => Ok(()),
+                -3 => Err(MerkleizationError::InvalidEncoding),
+                rc => backend_fault(rc),
+            }
+        }
+        pub fn truncate(&mut self, field: i32, new_n_bytes: u64) -> Result<(), MerkleizationError> {
+            match unsafe { sys::ecgpu_resident_state_truncate(self.raw, field, new_n_bytes) } {
+                0 => Ok(()),
+                -3 => Err(MerkleizationError::InvalidEncoding),
+                rc => backend_fault(rc),
+            }
+        }
+        /// size of the serialization now
+        pub fn size(&self) -> u64 {
+            unsafe { sys::ecgpu_resident_state_size(self.raw) }
+        }
+        pub fn root(&mut self) -> Result<Bytes32, MerkleizationError> {
+            let mut root = [0u8; 32];
+            let rc = unsafe { sys::ecgpu_resident_state_root(self.raw, root.as_mut_ptr()) };
+            finish(rc, root, 0)
+        }
+    }
+    impl Drop for ResidentState {
+        fn drop(&mut self) {
+            unsafe { sys::ecgpu_resident_state_destroy(self.raw) }
+        }
+    }
+
     /// ssz_rs `is_valid_merkle_branch` (phase0/block_processing.rs:433, deneb/blob_sidecar.rs:62)
     pub fn is_valid_merkle_branch(leaf: &Bytes32, branch: &[Bytes32], depth: usize, index: usize, root: &Bytes32) -> bool {
         if branch.len() < depth || depth > 64 {

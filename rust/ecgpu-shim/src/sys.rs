@@ -1,10 +1,28 @@
-//! One declaration per entry point of include/ecgpu.h that the shim uses (same order as the header).
+//! One declaration per host-pointer entry point of include/ecgpu.h (same order as the header).  Not declared: the `_dev`
+//! variants (device pointers + a HIP stream: for hosts that own HBM buffers, i.e. not a Rust beacon node today), the key /
+//! signature generators of the test harness (`ecgpu_sk_to_pk_batch`, `ecgpu_sign_batch`) and the profiling hooks.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
 pub const ECGPU_SUCCESS: c_int = 0;
 pub const ECGPU_IN_VERIFY: c_int = 0x40;
 pub const ECGPU_EMPTY_AGGREGATE: c_int = -100;
+pub const ECGPU_ERR_INVALID: c_int = -3;
+// fork ids of the BeaconState entry points ({phase0,altair,bellatrix,capella,deneb}/beacon_state.rs)
+pub const ECGPU_FORK_PHASE0: c_int = 0;
+pub const ECGPU_FORK_ALTAIR: c_int = 1;
+pub const ECGPU_FORK_BELLATRIX: c_int = 2;
+pub const ECGPU_FORK_CAPELLA: c_int = 3;
+pub const ECGPU_FORK_DENEB: c_int = 4;
+// variable-length fields of a resident state (ecgpu_resident_state_append / _truncate)
+pub const ECGPU_STATE_HISTORICAL_ROOTS: c_int = 0;
+pub const ECGPU_STATE_ETH1_DATA_VOTES: c_int = 1;
+pub const ECGPU_STATE_VALIDATORS: c_int = 2;
+pub const ECGPU_STATE_BALANCES: c_int = 3;
+pub const ECGPU_STATE_PREVIOUS_EPOCH_PARTICIPATION: c_int = 4;
+pub const ECGPU_STATE_CURRENT_EPOCH_PARTICIPATION: c_int = 5;
+pub const ECGPU_STATE_INACTIVITY_SCORES: c_int = 6;
+pub const ECGPU_STATE_HISTORICAL_SUMMARIES: c_int = 8;
 
 #[repr(C)]
 pub struct ecgpu_registry_t {
@@ -33,6 +51,11 @@ extern "C" {
     pub fn ecgpu_init(device: c_int) -> c_int;
     pub fn ecgpu_device_count() -> c_int;
     pub fn ecgpu_last_error() -> *const c_char;
+    pub fn ecgpu_version() -> *const c_char;
+    pub fn ecgpu_bind_thread(device: c_int) -> c_int;
+    pub fn ecgpu_selfcheck_ifetch(ms_small_loop: *mut f64, ms_large_loop: *mut f64) -> c_int;
+    pub fn ecgpu_bls_tower() -> c_int;
+    pub fn ecgpu_bls_last_pairing_path() -> c_int;
 
     pub fn ecgpu_sha256(data: *const u8, len: usize, out: *mut u8) -> c_int;
     pub fn ecgpu_merkleize(data: *const u8, n_bytes: u64, limit_chunks: u64, mix_in_len: c_int, len: u64, root: *mut u8) -> c_int;
@@ -49,6 +72,24 @@ extern "C" {
     pub fn ecgpu_resident_state_patch(st: *mut ecgpu_resident_state_t, offsets: *const u64, data_off: *const u64, data: *const u8,
                                       n: u32) -> c_int;
     pub fn ecgpu_resident_state_root(st: *mut ecgpu_resident_state_t, root: *mut u8) -> c_int;
+    pub fn ecgpu_sha256_batch(data: *const u8, len: usize, n: u64, out: *mut u8) -> c_int;
+    pub fn ecgpu_validators_subtree_root(ssz121: *const u8, n: u64, width: u64, root: *mut u8) -> c_int;
+    pub fn ecgpu_merkleize_subtree_roots(sub_roots: *const u8, n_sub: u32, width: u64, limit: u64, mix_in_len: c_int, len: u64,
+                                         root: *mut u8) -> c_int;
+    pub fn ecgpu_htr_validators_multi(devices: *const c_int, n_devices: u32, ssz121: *const u8, n: u64, limit: u64,
+                                      root: *mut u8) -> c_int;
+    pub fn ecgpu_beacon_state_fixed_size(fork: c_int, preset: c_int) -> u64;
+    pub fn ecgpu_resident_state_append(st: *mut ecgpu_resident_state_t, field: c_int, data: *const u8, n_bytes: u64) -> c_int;
+    pub fn ecgpu_resident_state_truncate(st: *mut ecgpu_resident_state_t, field: c_int, new_n_bytes: u64) -> c_int;
+    pub fn ecgpu_resident_state_size(st: *const ecgpu_resident_state_t) -> u64;
+    pub fn ecgpu_ssz_generalized_index(types: *const ecgpu_ssz_type, n_types: u32, fields: *const u32, n_field_refs: u32,
+                                       root_type: u32, path: *const u64, path_len: u32, gindex: *mut u64) -> c_int;
+    pub fn ecgpu_ssz_prove(types: *const ecgpu_ssz_type, n_types: u32, fields: *const u32, n_field_refs: u32, root_type: u32,
+                           ssz: *const u8, n_bytes: u64, path: *const u64, path_len: u32, leaf: *mut u8, branch: *mut u8,
+                           max_depth: u32, depth: *mut u32, gindex: *mut u64, root: *mut u8) -> c_int;
+    pub fn ecgpu_merkle_proof(chunks: *const u8, n_chunks: u64, limit_chunks: u64, index: u64, branch: *mut u8) -> c_int;
+    pub fn ecgpu_beacon_state_field_roots(fork: c_int, ssz: *const u8, n_bytes: u64, preset: c_int, roots: *mut u8, capacity: u32,
+                                          n_fields: *mut u32, root: *mut u8) -> c_int;
     pub fn ecgpu_compute_shuffled_indices(indices: *const u64, n: u64, seed: *const u8, rounds: u32, out: *mut u64) -> c_int;
 
     pub fn ecgpu_verify(pk: *const u8, msg: *const u8, msg_len: usize, sig: *const u8) -> c_int;
@@ -60,6 +101,12 @@ extern "C" {
     pub fn ecgpu_aggregate_pks(pks48: *const u8, n: u32, out: *mut u8) -> c_int;
     pub fn ecgpu_fast_aggregate_verify_batch(pks48: *const u8, pk_off: *const u32, msgs32: *const u8, sigs96: *const u8, n: u32,
                                              eth_variant: c_int, status_out: *mut u8) -> c_int;
+
+    pub fn ecgpu_fast_aggregate_verify_batch_multi(devices: *const c_int, n_devices: u32, pks48: *const u8, pk_off: *const u32,
+                                                   msgs32: *const u8, sigs96: *const u8, n: u32, eth_variant: c_int,
+                                                   status_out: *mut u8) -> c_int;
+    pub fn ecgpu_g1_msm(pks48: *const u8, scalars32: *const u8, n: u32, scalar_bits: u32, out48: *mut u8) -> c_int;
+    pub fn ecgpu_g2_msm(sigs96: *const u8, scalars32: *const u8, n: u32, scalar_bits: u32, out96: *mut u8) -> c_int;
 
     pub fn ecgpu_registry_create(capacity: u64, out: *mut *mut ecgpu_registry_t) -> c_int;
     pub fn ecgpu_registry_destroy(reg: *mut ecgpu_registry_t);
