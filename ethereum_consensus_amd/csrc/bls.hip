@@ -36,13 +36,21 @@ int init_bls_tables(hipStream_t) {
 }
 
 // ---- stage kernels ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pk_validate(const u8* pks48, u32 n, A1* pts, u8* st) {
-    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    A1 p;
-    u8 s = stage_pk_validate(p, pks48 + 48 * (size_t)i);
-    pts[i] = p;
-    st[i] = s;
+static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
+// waves per SIMD the key stage leaves room for: with more than one wave per SIMD of keys to validate, two half-file waves
+// issue more than one full-file wave (a lone wave issues once per ~5 cycles whatever it runs, profiles/r02p_issue_rates.txt)
+static const int g_pk_waves = [] {
+    const char* e = getenv("ECGPU_PK_WAVES");
+    return e ? atoi(e) : 0;
+}();
+static int pk_waves_for(u32 n_keys) { return g_pk_waves ? g_pk_waves : (n_keys > 65536u ? 2 : 1); }
+static void launch_pk_validate(hipStream_t s, const u8* pks48, u32 n, A1* pts, u8* st) {
+    switch (pk_waves_for(n)) {
+    case 2: hipLaunchKernelGGL(k_pk_validate_w2, grid_for(n), dim3(BLS_BLOCK), 0, s, pks48, n, pts, st); break;
+    case 3: hipLaunchKernelGGL(k_pk_validate_w3, grid_for(n), dim3(BLS_BLOCK), 0, s, pks48, n, pts, st); break;
+    case 4: hipLaunchKernelGGL(k_pk_validate_w4, grid_for(n), dim3(BLS_BLOCK), 0, s, pks48, n, pts, st); break;
+    default: hipLaunchKernelGGL(k_pk_validate_w1, grid_for(n), dim3(BLS_BLOCK), 0, s, pks48, n, pts, st);
+    }
 }
 
 // sum of affine points lo..hi per tuple; first non-zero status (lowest index) wins.
@@ -207,7 +215,6 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_scalar_mul(Aff<F>*
 }
 
 // ---- host drivers ----------------------------------------------------------------------------
-static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
     const size_t xf = vm2_xfer_bytes(n) > vm3_xfer_bytes(n) ? vm2_xfer_bytes(n) : vm3_xfer_bytes(n);
@@ -296,7 +303,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     // With a registry there is no key validation to hide behind: the signature stage stays on the caller's stream
     // and only the (three times longer) message stage goes to the auxiliary one.  Big K = 1 batches gain nothing from it:
     // two one-wave-per-SIMD kernels side by side take as long as one after the other (65 536 tuples: 13.6 ms together,
-    // 3.2 + 9.9 apart, profiles/r01s4_*).
+    // 3.2 + 9.9 apart, profiles/r01s4_*; round 2: the full-size kernels cannot share a SIMD's registers at all, and the
+    // half-register-file builds side by side are SLOWER -- key 3.0 + signature 5.1 + message 15.4 ms against 1.85 + 2.95 + 8.8,
+    // two megabyte-sized instruction streams through one instruction cache: profiles/r02l_stage_overlap.txt).
     const bool key_heavy = d_pk_off && !reg && n_pks >= 4ull * n;
     const bool fork = d_pk_off && (reg || key_heavy) && n <= 16384;
     hipStream_t s2 = s, s3 = s;  // message stage / signature stage
@@ -306,29 +315,54 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         s2 = ax.st[2];  // st[0] / st[1] carry the small fields of a state root the same thread may have in flight
         ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
         ECG_HIP_CHECK(hipStreamWaitEvent(s2, ax.fork, 0));
+        ECG_HIP_CHECK(hipEventRecord(ax.reached[2], s2));
         if (key_heavy) {
             // the two stages are independent of each other as well: a stream each (a lone aggregate is all latency:
             // 3.6 ms + 9.7 ms one after the other, 9.7 ms side by side)
             s3 = ax.st[1];
             ECG_HIP_CHECK(hipStreamWaitEvent(s3, ax.fork, 0));
+            ECG_HIP_CHECK(hipEventRecord(ax.reached[1], s3));
         }
     }
-    if (n_pks && !reg) {
-        ProfScope ps("bls_pk_validate", s);
-        hipLaunchKernelGGL(k_pk_validate, grid_for(n_pks), dim3(BLS_BLOCK), 0, s, d_pks48, n_pks, pts, st);
-    }
-    if (d_pk_off) {
-        ProfScope ps("bls_pk_aggregate", s);
-        launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
-    }
-    {
-        hipStream_t s_sig = s3;
-        ProfScope ps("bls_sig", s_sig);
-        hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s_sig, d_sigs96, n, sigpts, st_dec, st_grp);
-    }
-    {
+    static const char* g2_env = getenv("ECGPU_G2_WAVES");  // experiment: the half-register-file builds of the side stages
+    const bool g2_w2 = g2_env && atoi(g2_env) >= 2;
+    auto run_keys = [&] {
+        if (n_pks && !reg) {
+            ProfScope ps("bls_pk_validate", s);
+            launch_pk_validate(s, d_pks48, n_pks, pts, st);
+        }
+        if (d_pk_off) {
+            ProfScope ps("bls_pk_aggregate", s);
+            launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
+        }
+    };
+    auto run_sig = [&] {
+        ProfScope ps("bls_sig", s3);
+        hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : g2_w2 ? k_sig_w2 : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts, st_dec, st_grp);
+    };
+    auto run_h2c = [&] {
         ProfScope ps("bls_h2c", s2);
-        hipLaunchKernelGGL(g_tower.load() == 2 ? k_h2c_calls : k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
+        hipLaunchKernelGGL(g_tower.load() == 2 ? k_h2c_calls : g2_w2 ? k_h2c_w2 : k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
+    };
+    if (fork) {
+        // The few long waves of the side stages must be ON their SIMDs before the key stage floods the chip: a G2 wave needs
+        // most of a SIMD's register file, and with two key waves per SIMD retiring at different times a latecomer never finds
+        // one empty (256 x 2 048 keys: 29.2 ms, against 22.0 with the one-wave key stage, profiles/r02k_pk_waves.txt).  Launch
+        // order alone does not do it -- the side streams first sit out a cross-queue wait on `fork` while the caller's stream
+        // runs on -- so the key stage waits until the side streams have PASSED that wait (`reached`): their kernels are next
+        // in their queues, the key stage is one more cross-queue signal away.
+        run_h2c();
+        if (s3 != s) run_sig();
+        if (key_heavy) {
+            ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.reached[2], 0));
+            ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.reached[1], 0));
+        }
+        run_keys();
+        if (s3 == s) run_sig();
+    } else {
+        run_keys();
+        run_sig();
+        run_h2c();
     }
     if (fork) {
         ECG_HIP_CHECK(hipEventRecord(ax.done[2], s2));
@@ -464,7 +498,7 @@ int ecgpu_registry_set_dev(ecgpu_registry_t* reg, uint64_t first_index, const ui
     if (!n) return ECGPU_SUCCESS;
     hipStream_t s = tctx()->stream_or_own(stream);
     ProfScope ps("bls_pk_validate", s);
-    hipLaunchKernelGGL(k_pk_validate, grid_for((u32)n), dim3(BLS_BLOCK), 0, s, d_pks48, (u32)n, reg->pts + first_index, reg->st + first_index);
+    launch_pk_validate(s, d_pks48, (u32)n, reg->pts + first_index, reg->st + first_index);
     ECG_HIP_CHECK(hipGetLastError());
     return ECGPU_SUCCESS;
 }
@@ -561,7 +595,7 @@ int ecgpu_aggregate_verify(const uint8_t* pks48, uint32_t n_pks, const uint8_t* 
     Fp12* fs = (Fp12*)k.ar->take((size_t)(npair + 1) * sizeof(Fp12));
     u8* d_status = k.ar->take(1);
     if (!pts || !st || !hpts || !sigpt || !st_dec || !st_grp || !fs || !d_status) return ECGPU_ERR_OOM;
-    if (np) hipLaunchKernelGGL(k_pk_validate, grid_for(np), dim3(BLS_BLOCK), 0, k.s, d_pks, np, pts, st);
+    if (np) launch_pk_validate(k.s, d_pks, np, pts, st);
     hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(1), dim3(BLS_BLOCK), 0, k.s, d_sig, 1u, sigpt, st_dec, st_grp);
     if (npair) {
         hipLaunchKernelGGL(g_tower.load() == 2 ? k_h2c_calls : k_h2c, grid_for(nm), dim3(BLS_BLOCK), 0, k.s, d_msgs, (const u64*)d_moff, nm, hpts);
@@ -617,7 +651,7 @@ int ecgpu_aggregate_pks(const uint8_t* pks48, uint32_t n, uint8_t* out48) {
     A1* sum = (A1*)k.ar->take(sizeof(A1));
     u8* d_out = k.ar->take(48 + 1);
     if (!pts || !st || !sum || !d_out) return ECGPU_ERR_OOM;
-    hipLaunchKernelGGL(k_pk_validate, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_pks, n, pts, st);
+    launch_pk_validate(k.s, d_pks, n, pts, st);
     launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48);
     hipLaunchKernelGGL(k_compress_g1, dim3(1), dim3(64), 0, k.s, (const A1*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
@@ -644,7 +678,7 @@ int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uin
     A1* sum = (A1*)k.ar->take(sizeof(A1));
     u8* d_out = k.ar->take(48 + 1);
     if (!pts || !st || !sum || !d_out) return ECGPU_ERR_OOM;
-    hipLaunchKernelGGL(k_pk_validate, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_pks, n, pts, st);
+    launch_pk_validate(k.s, d_pks, n, pts, st);
     {
         ProfScope ps("bls_scalar_mul_g1", k.s);
         hipLaunchKernelGGL(k_scalar_mul<Fp>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st, (const u8*)d_sc, scalar_bits, n);

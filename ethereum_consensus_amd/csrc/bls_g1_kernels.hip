@@ -1,0 +1,28 @@
+// The G1 stage kernel of the BLS batch pipeline (bls.hip launches it):
+//   k_pk_validate   lane = public key   48 B -> affine G1 (decompress: Fp sqrt; reject infinity; subgroup check)
+// (PublicKey::try_from of /root/reference/ethereum-consensus/src/crypto/bls.rs:279-285, once per key of every call.)
+// G1 work is Fp-only -- no tower values -- so it fits a half, a third or a quarter of a SIMD's register file, and committee
+// batches bring 8+ waves per SIMD of keys.  The register budget of the callees follows the kernel's launch bounds only when the
+// kernel is alone in its translation unit, so every occupancy target is a unit of its own: bls_g1_kernels_w{2,3,4}.hip
+// compile this file again with ECG_G1_WAVES set; bls.hip picks by batch size.
+#include "bls_kernels.h"
+
+#ifndef ECG_G1_WAVES
+#define ECG_G1_WAVES 1
+#endif
+#define ECG_G1_CAT2(a, b) a##b
+#define ECG_G1_CAT(a, b) ECG_G1_CAT2(a, b)
+#define ECG_G1_KN(name) ECG_G1_CAT(name##_w, ECG_G1_WAVES)
+
+namespace ecg {
+
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_G1_WAVES) ECG_G1_KN(k_pk_validate)(const u8* pks48, u32 n, A1* pts, u8* st) {
+    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    A1 p;
+    u8 s = stage_pk_validate(p, pks48 + 48 * (size_t)i);
+    pts[i] = p;
+    st[i] = s;
+}
+
+}  // namespace ecg

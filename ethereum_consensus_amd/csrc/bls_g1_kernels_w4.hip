@@ -1,0 +1,3 @@
+// k_pk_validate once more, with room for 4 waves per SIMD (see bls_g1_kernels.hip).
+#define ECG_G1_WAVES 4
+#include "bls_g1_kernels.hip"

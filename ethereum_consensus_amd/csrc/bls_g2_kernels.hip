@@ -9,10 +9,18 @@
 #ifndef ECG_KN
 #define ECG_KN(name) name
 #endif
+// The half-register-file build exists to share a SIMD with a wave of the key stage (bls.hip: committee batches): its few long
+// waves are the dependent chain of the batch, the key waves beside them are throughput work -- the chain asks for issue priority.
+#if ECG_BLS_WAVES >= 2
+#define ECG_G2_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define ECG_G2_PRIO() ((void)0)
+#endif
 
 namespace ecg {
 
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig)(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp) {
+    ECG_G2_PRIO();
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
     A2 p;
@@ -25,6 +33,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig)(const 
 
 // msg_off == nullptr: message i = msgs + 32 i (32 bytes)
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c)(const u8* msgs, const u64* msg_off, u32 n, A2* hpts) {
+    ECG_G2_PRIO();
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
     const u8* m = msg_off ? msgs + msg_off[i] : msgs + 32 * (size_t)i;

@@ -93,11 +93,16 @@ __device__ __forceinline__ void run_tree_job(const TreeJob& job, u8* buf, const 
     }
 }
 
+// Jobs and tiles are dependent chains of hash64 on a few waves (11 levels in a tile, ~30 in a finishing job); the passes are
+// throughput work on every SIMD.  A chain wave that takes turns with three pass waves is three times slower while the pass
+// does not notice a few chain waves, so the chain kernels ask for issue priority (s_setprio) and the passes do not.
 __global__ void __launch_bounds__(JOB_BLOCK) k_tree_jobs(const TreeJob* jobs, u8* buf, const ZeroTable* zt) {
+    __builtin_amdgcn_s_setprio(3);
     TreeJob job = jobs[blockIdx.x];
     run_tree_job(job, buf, zt);
 }
 __global__ void __launch_bounds__(JOB_BLOCK) k_tree_job1(TreeJob job, u8* buf, const ZeroTable* zt) {
+    __builtin_amdgcn_s_setprio(3);
     run_tree_job(job, buf, zt);
 }
 
@@ -145,9 +150,13 @@ __global__ void __launch_bounds__(TILE_LANES) k_tree_tiles(const TileDesc* descs
     for (u32 i = 1; i < n_desc; i++)
         if (blockIdx.x >= descs[i].first_wg) f = i;
     const TileDesc d = descs[f];
+    __builtin_amdgcn_s_setprio(3);  // see k_tree_jobs
     run_tile(d, zt);
 }
-__global__ void __launch_bounds__(TILE_LANES) k_tree_tiles1(TileDesc d, const ZeroTable* zt) { run_tile(d, zt); }
+__global__ void __launch_bounds__(TILE_LANES) k_tree_tiles1(TileDesc d, const ZeroTable* zt) {
+    __builtin_amdgcn_s_setprio(3);  // see k_tree_jobs
+    run_tile(d, zt);
+}
 
 __global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u32 n, u8* dst) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;

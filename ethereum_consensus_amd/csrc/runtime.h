@@ -48,7 +48,7 @@ struct PinnedBuf {
 constexpr int N_AUX_STREAMS = 3;
 struct AuxStreams {
     hipStream_t st[N_AUX_STREAMS] = {};
-    hipEvent_t fork = nullptr, done[N_AUX_STREAMS] = {};
+    hipEvent_t fork = nullptr, done[N_AUX_STREAMS] = {}, reached[N_AUX_STREAMS] = {};  // reached[i]: st[i] has passed its wait on fork
     bool ready = false;
     int init();
 };

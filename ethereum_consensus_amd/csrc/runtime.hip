@@ -111,6 +111,7 @@ int AuxStreams::init() {
     for (int i = 0; i < N_AUX_STREAMS; i++) {
         ECG_HIP_CHECK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
         ECG_HIP_CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        ECG_HIP_CHECK(hipEventCreateWithFlags(&reached[i], hipEventDisableTiming));
     }
     ready = true;
     return ECGPU_SUCCESS;

@@ -12,6 +12,8 @@
 #include "merkle_driver.h"
 #include "state_plan.h"
 
+#include <cstdlib>
+
 namespace ecg {
 
 // d_vroots != nullptr (resident state): the 32-byte hash_tree_root of every validator record is cached there and kept
@@ -77,8 +79,12 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         // chip-filling validator pass for its whole duration (measured 0.63 -> 0.79 ms); they start when that pass
         // has been issued and overlap with the validator tree's own latency-bound tail instead.
         const BigField& b = plan.bigs[biggest];
+        // (the other fields from the START of the pass, now that their chain kernels carry issue priority: 1.02 against 1.05 ms,
+        // inside the run-to-run spread -- profiles/r02n_committee_and_priority.txt; kept in the middle)
+        static const bool aux_early = getenv("ECGPU_STATE_AUX_EARLY") != nullptr;
+        if (aux_early) ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
         rc = merkleize_device(s, b.kind, fptr[biggest], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk,
-                              wss[biggest], &hc, nullptr, nullptr, false, ax.fork);
+                              wss[biggest], &hc, nullptr, nullptr, false, aux_early ? nullptr : ax.fork);
         if (rc) return rc;
     }
     for (int i = 0; i < 2; i++) ECG_HIP_CHECK(hipStreamWaitEvent(ax.st[i], ax.fork, 0));

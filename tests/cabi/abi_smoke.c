@@ -45,6 +45,24 @@ int main(int argc, char** argv) {
     memcpy(sigs, sig, 96), memcpy(sigs + 96, sig, 96);
     if (ecgpu_fast_aggregate_verify_batch(pks, NULL, msgs, sigs, 2, 0, st) != ECGPU_SUCCESS) return 14;
     if (st[0] != ECGPU_VERIFY_FAIL || st[1] != ECGPU_VERIFY_FAIL) return 15; /* wrong 32-byte messages */
+    /* whole-block collector: two deferred verifications, one pass, the scalar entries' statuses in push order */
+    ecgpu_batch_t* b = NULL;
+    if (ecgpu_batch_create(NULL, &b) != ECGPU_SUCCESS || !b) return 16;
+    if (ecgpu_batch_push(b, pk, 1, (const unsigned char*)msg, strlen(msg), sig, 0) != 0) return 17;
+    if (ecgpu_batch_push(b, pk, 1, (const unsigned char*)"forged", 6, sig, 0) != 1) return 18;
+    if (ecgpu_batch_len(b) != 2 || ecgpu_batch_flush(b, st, 2) != ECGPU_SUCCESS) return 19;
+    if (st[0] != ECGPU_SUCCESS || st[1] != ECGPU_VERIFY_FAIL || ecgpu_batch_len(b) != 0) return 20;
+    ecgpu_batch_destroy(b);
+    /* the same batch split over a device list from one process (both entries name device 0 here) */
+    int devs[2] = {0, 0};
+    if (ecgpu_fast_aggregate_verify_batch_multi(devs, 2, pks, NULL, msgs, sigs, 2, 0, st) != ECGPU_SUCCESS) return 21;
+    if (st[0] != ECGPU_VERIFY_FAIL || st[1] != ECGPU_VERIFY_FAIL) return 22;
+    /* a Merkle branch of a 4-chunk tree, checked by the library's own is_valid_merkle_branch */
+    unsigned char chunks[128], branch[64], r4[32];
+    for (int i = 0; i < 128; i++) chunks[i] = (unsigned char)(i * 7 + 1);
+    if (ecgpu_merkleize(chunks, 128, 4, 0, 0, r4) != ECGPU_SUCCESS) return 23;
+    if (ecgpu_merkle_proof(chunks, 4, 4, 2, branch) != ECGPU_SUCCESS) return 24;
+    if (ecgpu_is_valid_merkle_branch(chunks + 64, branch, 2, 2, r4) != ECGPU_SUCCESS) return 25;
     printf("C caller ok: %s\n", ecgpu_version());
     return 0;
 }
