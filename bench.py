@@ -155,9 +155,9 @@ R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 # of N products with one reduction 169 N + 182, see csrc/bls_fp.h.  The census used is the one of the build that RAN
 # (ecgpu_bls_tower(): 1 = sums of products, 2 = compact-code tower over out-of-line Fp products; the key stage is shared).
 BLS_OPS_BY_BUILD = {
-    1: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (218, 756, 522626), "bls_h2c": (768, 2655, 1197430),
-        "bls_pairing": (651, 382, 7239674)},
-    2: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (1476, 756, 0), "bls_h2c": (3718, 2655, 0), "bls_pairing": (19643, 382, 0)},
+    1: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (218, 756, 522626), "bls_h2c": (555, 1871, 1205350),
+        "bls_pairing": (548, 2, 7243634)},
+    2: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (1476, 756, 0), "bls_h2c": (3505, 1871, 7920), "bls_pairing": (19540, 2, 3960)},
 }
 BLS_OPS = BLS_OPS_BY_BUILD[1]
 PAIRING_KERNEL_BY_BUILD = {1: "k_pairing", 2: "k_pairing_calls"}

@@ -38,7 +38,9 @@ int init_bls_tables(hipStream_t) {
 // ---- stage kernels ---------------------------------------------------------------------------
 static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 // waves per SIMD the key stage leaves room for: with more than one wave per SIMD of keys to validate, two half-file waves
-// issue more than one full-file wave (a lone wave issues once per ~5 cycles whatever it runs, profiles/r02p_issue_rates.txt)
+// issue more than one full-file wave (a lone wave issues once per ~5 cycles whatever it runs, profiles/r02p_issue_rates.txt).
+// Measured with room for 1 / 2 / 3 / 4 waves: 4.2 M keys 127 / 108 / 109 / 120 ms, 65 536 keys 1.84 / 1.84 / 1.98 / 2.34 ms
+// (profiles/r02k_pk_waves.txt) -- the smaller budgets pay in scratch traffic what they win in issue slots.
 static const int g_pk_waves = [] {
     const char* e = getenv("ECGPU_PK_WAVES");
     return e ? atoi(e) : 0;
@@ -47,8 +49,6 @@ static int pk_waves_for(u32 n_keys) { return g_pk_waves ? g_pk_waves : (n_keys >
 static void launch_pk_validate(hipStream_t s, const u8* pks48, u32 n, A1* pts, u8* st) {
     switch (pk_waves_for(n)) {
     case 2: hipLaunchKernelGGL(k_pk_validate_w2, grid_for(n), dim3(BLS_BLOCK), 0, s, pks48, n, pts, st); break;
-    case 3: hipLaunchKernelGGL(k_pk_validate_w3, grid_for(n), dim3(BLS_BLOCK), 0, s, pks48, n, pts, st); break;
-    case 4: hipLaunchKernelGGL(k_pk_validate_w4, grid_for(n), dim3(BLS_BLOCK), 0, s, pks48, n, pts, st); break;
     default: hipLaunchKernelGGL(k_pk_validate_w1, grid_for(n), dim3(BLS_BLOCK), 0, s, pks48, n, pts, st);
     }
 }
@@ -216,9 +216,15 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_scalar_mul(Aff<F>*
 
 // ---- host drivers ----------------------------------------------------------------------------
 
+// message stage on two lanes per message up to this many tuples (twice as many lanes still fit one wave per SIMD)
+static const u32 g_h2c_split_max = [] {
+    const char* e = getenv("ECGPU_H2C_SPLIT_MAX");
+    return e ? (u32)strtoul(e, nullptr, 10) : 32768u;
+}();
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
     const size_t xf = vm2_xfer_bytes(n) > vm3_xfer_bytes(n) ? vm2_xfer_bytes(n) : vm3_xfer_bytes(n);
-    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + xf + 8192;
+    const size_t maps = n <= g_h2c_split_max ? (size_t)2 * n * sizeof(J2) + 256 : 0;
+    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + xf + maps + 8192;
 }
 // Which kernels run the pairing check.  The lane kernel (one lane per tuple, state in VGPRs/AGPRs + private segment)
 // has the best throughput but one tuple's check is a 35 ms dependent chain, so a batch of a few thousand tuples
@@ -298,6 +304,13 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         if (!agg || !st_pk) return ECGPU_ERR_OOM;
     }
     if (!pts || !st || !sigpts || !hpts || !st_dec || !st_grp) return ECGPU_ERR_OOM;
+    // (not under a committee batch's key stage: the second launch of the pair would find every SIMD taken by key waves and
+    // wait for the stage to drain -- 256 x 2 048 keys: 25.3 ms against 21.2, profiles/r02p2_h2c_two_lanes.txt)
+    J2* h2c_maps = nullptr;
+    if (n <= g_h2c_split_max && !(d_pk_off && !reg && n_pks >= 4ull * n)) {
+        h2c_maps = (J2*)ar.take((size_t)2 * n * sizeof(J2));
+        if (!h2c_maps) return ECGPU_ERR_OOM;
+    }
     // Key-heavy batches (committees): the signature and message stages do not depend on the keys, so they run on an
     // auxiliary stream underneath the key validation + aggregation and join before the pairing check.
     // With a registry there is no key validation to hide behind: the signature stage stays on the caller's stream
@@ -324,8 +337,6 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             ECG_HIP_CHECK(hipEventRecord(ax.reached[1], s3));
         }
     }
-    static const char* g2_env = getenv("ECGPU_G2_WAVES");  // experiment: the half-register-file builds of the side stages
-    const bool g2_w2 = g2_env && atoi(g2_env) >= 2;
     auto run_keys = [&] {
         if (n_pks && !reg) {
             ProfScope ps("bls_pk_validate", s);
@@ -338,11 +349,17 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     };
     auto run_sig = [&] {
         ProfScope ps("bls_sig", s3);
-        hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : g2_w2 ? k_sig_w2 : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts, st_dec, st_grp);
+        hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts, st_dec, st_grp);
     };
     auto run_h2c = [&] {
         ProfScope ps("bls_h2c", s2);
-        hipLaunchKernelGGL(g_tower.load() == 2 ? k_h2c_calls : g2_w2 ? k_h2c_w2 : k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
+        const bool calls = g_tower.load() == 2;
+        if (h2c_maps) {  // two lanes per message while that still leaves SIMDs idle
+            hipLaunchKernelGGL(calls ? k_h2c_map_calls : k_h2c_map, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, h2c_maps);
+            hipLaunchKernelGGL(calls ? k_h2c_finish_calls : k_h2c_finish, grid_for(n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
+        } else {
+            hipLaunchKernelGGL(calls ? k_h2c_calls : k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
+        }
     };
     if (fork) {
         // The few long waves of the side stages must be ON their SIMDs before the key stage floods the chip: a G2 wave needs

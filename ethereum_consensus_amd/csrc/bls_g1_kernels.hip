@@ -3,8 +3,8 @@
 // (PublicKey::try_from of /root/reference/ethereum-consensus/src/crypto/bls.rs:279-285, once per key of every call.)
 // G1 work is Fp-only -- no tower values -- so it fits a half, a third or a quarter of a SIMD's register file, and committee
 // batches bring 8+ waves per SIMD of keys.  The register budget of the callees follows the kernel's launch bounds only when the
-// kernel is alone in its translation unit, so every occupancy target is a unit of its own: bls_g1_kernels_w{2,3,4}.hip
-// compile this file again with ECG_G1_WAVES set; bls.hip picks by batch size.
+// kernel is alone in its translation unit, so every occupancy target is a unit of its own: bls_g1_kernels_w2.hip
+// compiles this file again with ECG_G1_WAVES = 2; bls.hip picks by batch size.
 #include "bls_kernels.h"
 
 #ifndef ECG_G1_WAVES

@@ -9,18 +9,10 @@
 #ifndef ECG_KN
 #define ECG_KN(name) name
 #endif
-// The half-register-file build exists to share a SIMD with a wave of the key stage (bls.hip: committee batches): its few long
-// waves are the dependent chain of the batch, the key waves beside them are throughput work -- the chain asks for issue priority.
-#if ECG_BLS_WAVES >= 2
-#define ECG_G2_PRIO() __builtin_amdgcn_s_setprio(3)
-#else
-#define ECG_G2_PRIO() ((void)0)
-#endif
 
 namespace ecg {
 
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig)(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp) {
-    ECG_G2_PRIO();
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
     A2 p;
@@ -33,13 +25,33 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig)(const 
 
 // msg_off == nullptr: message i = msgs + 32 i (32 bytes)
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c)(const u8* msgs, const u64* msg_off, u32 n, A2* hpts) {
-    ECG_G2_PRIO();
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
     const u8* m = msg_off ? msgs + msg_off[i] : msgs + 32 * (size_t)i;
     size_t len = msg_off ? (size_t)(msg_off[i + 1] - msg_off[i]) : 32;
     A2 h;
     hash_to_g2(h, m, len);
+    hpts[i] = h;
+}
+
+// The message stage on two lanes per message: lane 2i + j runs map j of message i (hash_to_g2_map), then one lane per message
+// finishes (sum of the two points, cofactor clearing, affine).  For batches that leave SIMDs idle anyway.
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c_map)(const u8* msgs, const u64* msg_off, u32 n, J2* maps) {
+    u32 t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+    if (t >= 2 * n) return;
+    const u32 i = t >> 1;
+    const u8* m = msg_off ? msgs + msg_off[i] : msgs + 32 * (size_t)i;
+    size_t len = msg_off ? (size_t)(msg_off[i + 1] - msg_off[i]) : 32;
+    J2 q;
+    hash_to_g2_map(q, m, len, (int)(t & 1));
+    maps[t] = q;
+}
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c_finish)(const J2* maps, u32 n, A2* hpts) {
+    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const J2 q0 = maps[2 * i], q1 = maps[2 * i + 1];
+    A2 h;
+    hash_to_g2_finish(h, q0, q1);
     hpts[i] = h;
 }
 

@@ -15,17 +15,17 @@ constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches 
 // the branchy lane kernel decides
 constexpr u8 VM_NEEDS_LANE_PATH = 0xFE;
 
-// bls_g1_kernels.hip / bls_g1_kernels_w{2,3,4}.hip: the key stage with room for 1 .. 4 waves per SIMD
+// bls_g1_kernels.hip / bls_g1_kernels_w2.hip: the key stage with room for one / two waves per SIMD
 __global__ void k_pk_validate_w1(const u8* pks48, u32 n, A1* pts, u8* st);
 __global__ void k_pk_validate_w2(const u8* pks48, u32 n, A1* pts, u8* st);
-__global__ void k_pk_validate_w3(const u8* pks48, u32 n, A1* pts, u8* st);
-__global__ void k_pk_validate_w4(const u8* pks48, u32 n, A1* pts, u8* st);
 
 // bls_g2_kernels.hip / bls_g2_kernels_calls.hip
 __global__ void k_sig(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
 __global__ void k_h2c(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
-__global__ void k_sig_w2(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
-__global__ void k_h2c_w2(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
+__global__ void k_h2c_map(const u8* msgs, const u64* msg_off, u32 n, J2* maps);
+__global__ void k_h2c_finish(const J2* maps, u32 n, A2* hpts);
+__global__ void k_h2c_map_calls(const u8* msgs, const u64* msg_off, u32 n, J2* maps);
+__global__ void k_h2c_finish_calls(const J2* maps, u32 n, A2* hpts);
 __global__ void k_sig_calls(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
 __global__ void k_h2c_calls(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
 

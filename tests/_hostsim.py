@@ -23,6 +23,7 @@ def lib():
         _lib.hs_sha256.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         _lib.hs_xmd.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
         _lib.hs_hash_to_g2.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.hs_hash_to_g2_split.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
         _lib.hs_fast_aggregate_verify.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64,
                                                   ctypes.c_char_p, ctypes.c_int]
     return _lib

@@ -199,6 +199,16 @@ void hs_g2_mul(const u8* xy, const u8* k32be, u8* out, int* inf) {
     *inf = (int)r.inf;
 }
 void hs_xmd(const u8* msg, u64 len, u8* out256) { xmd_expand_256(out256, msg, (size_t)len); }
+// split != 0: the two-lanes-per-message form of the small-batch message stage (hash_to_g2_map x 2, hash_to_g2_finish)
+void hs_hash_to_g2_split(const u8* msg, u64 len, u8* xy, int* inf) {
+    J2 q0, q1;
+    hash_to_g2_map(q0, msg, (size_t)len, 0);
+    hash_to_g2_map(q1, msg, (size_t)len, 1);
+    A2 h;
+    hash_to_g2_finish(h, q0, q1);
+    out_a2(h, xy);
+    *inf = (int)h.inf;
+}
 void hs_hash_to_g2(const u8* msg, u64 len, u8* xy, int* inf) {
     A2 h;
     hash_to_g2(h, msg, (size_t)len);

@@ -61,8 +61,9 @@ def test_fp_arithmetic_and_lazy_range():
         assert fp_op(7, a)[0] == int(a > (P - 1) // 2)
         assert fp_op(9, a)[0] == int(a == 0)
         assert fp_op(10, a, b)[0] == int(a == b)
-    for a in vals[:40]:
+    for a in vals + [r.randrange(1 << k) for k in (1, 29, 30, 31, 60, 200, 379) for _ in range(8)]:  # division-steps inversion
         assert fp_op(4, a)[1] == pow(a, P - 2, P)
+    for a in vals[:40]:
         rc, v = fp_op(5, a)
         sq = a == 0 or pow(a, (P - 1) // 2, P) == 1
         assert rc == int(sq)
@@ -263,6 +264,9 @@ def test_expand_message_and_hash_to_g2():
         inf = ctypes.c_int(0)
         L.hs_hash_to_g2(msg, len(msg), xy, ctypes.byref(inf))
         assert un2(xy.raw) == B.hash_to_g2(msg)
+        xy2 = ctypes.create_string_buffer(192)  # the two-lanes-per-message form of small batches
+        L.hs_hash_to_g2_split(msg, len(msg), xy2, ctypes.byref(inf))
+        assert xy2.raw == xy.raw
     # crypto/bls.rs:530-544 test_can_sign through the lane programs: [sk] H(msg) compressed
     xy = ctypes.create_string_buffer(192)
     inf = ctypes.c_int(0)
