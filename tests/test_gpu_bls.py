@@ -242,6 +242,101 @@ def test_committee_aggregates_config4_shape(gpu):
     gpu.fast_aggregate_verify(keys, bytes(msgb[:32]), sigs[:96])
 
 
+def test_committee_aggregates_config4_full_size(gpu):
+    """BASELINE.json configs[3], one GPU's share at FULL size: 256 committees x 2 048 keys (524 288 key validations per call)
+    out of a 65 536-validator registry, through the reference-semantics entry and through the validated-key registry.  One
+    committee in sixteen is corrupted, cycling through: a member that did not sign, a wrong message, a key outside G1 in the
+    middle of the list, an infinity key near the end, a cleared compression flag on the first key.  Statuses are known by
+    construction; the C++ restatement re-verifies every corrupted committee and six clean ones, the Python oracle one."""
+    from ethereum_consensus_amd import bls as M
+    from oracle import cbls
+    n_reg, n_comm, k = 65536, 256, 2048
+    sks = [1 + int.from_bytes(S(b"c4sk", i), "big") % (B.R - 1) for i in range(n_reg)]
+    reg = gpu.sk_to_pk_batch(b"".join(sk_bytes(s) for s in sks))
+    r = random.Random(404)
+    off_g1 = B.g1_compress(C.rand_g1_curve_point(r))
+    members = [[(509 * c + 31 * j) % n_reg for j in range(k)] for c in range(n_comm)]
+    msgs = [S(b"c4att", c) for c in range(n_comm)]
+    sigs = gpu.sign_batch(b"".join(sk_bytes(sum(sks[i] for i in m) % B.R) for m in members), msgs)
+    msgb = bytearray(b"".join(msgs))
+    pk_buf, want = bytearray(), bytearray(n_comm)
+    for c in range(n_comm):
+        keys = [reg[48 * i:48 * i + 48] for i in members[c]]
+        if c % 16 == 3:
+            kind = (c // 16) % 5
+            if kind == 0:    # one member replaced by a key that did not sign
+                keys[k // 2] = reg[48 * ((members[c][0] + 1) % n_reg):48 * ((members[c][0] + 1) % n_reg) + 48]
+                want[c] = B.BLST_VERIFY_FAIL
+            elif kind == 1:  # wrong message
+                msgb[32 * c + 7] ^= 0x10
+                want[c] = B.BLST_VERIFY_FAIL
+            elif kind == 2:  # key outside G1: its conversion error wins over everything after it
+                keys[k // 3] = off_g1
+                want[c] = B.BLST_POINT_NOT_IN_GROUP
+            elif kind == 3:  # infinity key near the end
+                keys[k - 5] = B.INFINITY_PUBLIC_KEY
+                want[c] = B.BLST_PK_IS_INFINITY
+            else:            # compression flag cleared on the first key
+                keys[0] = bytes([keys[0][0] & 0x7F]) + keys[0][1:]
+                want[c] = B.BLST_BAD_ENCODING
+        pk_buf += b"".join(keys)
+    offs = list(range(0, n_comm * k + 1, k))
+    got = gpu.fast_aggregate_verify_batch(bytes(pk_buf), offs, bytes(msgb), sigs)
+    assert got == bytes(want)
+    check = [c for c in range(n_comm) if want[c]] + [0, 1, 100, 200, 254, 255]
+    for c in check:
+        keys = [bytes(pk_buf[48 * i:48 * i + 48]) for i in range(offs[c], offs[c + 1])]
+        assert cbls.fast_aggregate_verify(keys, bytes(msgb[32 * c:32 * c + 32]), sigs[96 * c:96 * c + 96]) == got[c], c
+    c = 19  # a wrong-message committee through the Python oracle as well (2 048 big-int key validations)
+    keys = [bytes(pk_buf[48 * i:48 * i + 48]) for i in range(offs[c], offs[c + 1])]
+    assert B.fast_aggregate_verify(keys, bytes(msgb[32 * c:32 * c + 32]), sigs[96 * c:96 * c + 96]) == got[c]
+    # the same committees by validator index; the registry holds what each key's conversion yields, so a committee whose
+    # corrupted key is not a registry member is expressed through a registry slot set to that key
+    registry = M.ValidatorKeyRegistry(n_reg + 8)
+    registry.set(0, reg)
+    registry.set(n_reg, off_g1 + B.INFINITY_PUBLIC_KEY)
+    idx_lists = []
+    for c in range(n_comm):
+        idx = list(members[c])
+        if c % 16 == 3:
+            kind = (c // 16) % 5
+            if kind == 0:
+                idx[k // 2] = (members[c][0] + 1) % n_reg
+            elif kind == 2:
+                idx[k // 3] = n_reg
+            elif kind == 3:
+                idx[k - 5] = n_reg + 1
+            elif kind == 4:
+                continue  # an undecodable key has no registry form of its own; covered by the by-value call
+        idx_lists.append((c, idx))
+    flat = [i for _, idx in idx_lists for i in idx]
+    got_idx = registry.fast_aggregate_verify_batch(flat, list(range(0, len(flat) + 1, k)), b"".join(bytes(msgb[32 * c:32 * c + 32]) for c, _ in idx_lists),
+                                                   b"".join(sigs[96 * c:96 * c + 96] for c, _ in idx_lists))
+    assert bytes(got_idx) == bytes(want[c] for c, _ in idx_lists)
+
+
+def test_bench_workloads_at_full_size(gpu):
+    """BASELINE.json configs[3] and configs[4] at the sizes bench.py quotes: the whole epoch (32 slots x 64 committees x 2 048
+    keys on one GPU) and 64 consecutive slots (sync-committee aggregate + root of the resident 2^20-validator state after the
+    slot's patches), driven through the same code the bench lines come from; each run checks its statuses against construction
+    and the last root against a from-scratch root of the patched encoding."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for workload, extra in (("epoch", ["--steps", "1", "--warmup", "1"]), ("slots", [])):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--no-cpu-baseline"] + extra, cwd=root,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["check"]["statuses_match_construction"] is True, line["check"]
+        if workload == "slots":
+            assert line["check"]["last_root_equals_from_scratch_root"] is True and line["config"]["slots"] >= 64, line
+        else:
+            assert line["config"]["aggregates"] * line["config"]["keys_per_aggregate"] == 32 * 64 * 2048, line["config"]
+
+
 def test_slot_pipeline_config5_shape(gpu):
     """BASELINE.json configs[4] shape: per slot one eth_fast_aggregate_verify over the participating keys of a 512-key
     sync committee (Bitvector<512> at ~95 %, altair/block_processing.rs:216-236) and one state root after mutating
@@ -400,6 +495,8 @@ def config2_workload(gpu, tmp_path_factory):
     ("sums", "vm2", 8192, 1, "vm2"),        # the Fp2 lane-group programs (round 1's small-batch path)
     ("sums", "vm3", 8192, 1, "vm3"),        # the sum-of-products lane groups: the small-batch path
     ("sums", "vm3", 65536, 1, "vm3"),       # ... and at full size (what a box with slow instruction fetch would run)
+    ("sums", "auto", 4096, 1, "vm3"),       # a small batch as dispatched by default: two-lane message stage + lane groups
+    ("calls", "auto", 4096, 2, "vm3"),      # ... and on the compact-code build (k_h2c_map_calls / k_h2c_finish_calls, k_sig_calls)
 ])
 def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, tower, pairing, n, want_tower, want_path):
     """The whole status vector of SURVEY.md 8(d) config 2 -- every fault class: wrong message, swapped key, signature outside
