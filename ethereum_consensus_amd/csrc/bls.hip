@@ -399,7 +399,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         if (!use_vm) {
             hipLaunchKernelGGL(g_tower.load() == 2 ? k_pairing_calls : k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg,
                                (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96,
-                               n, eth_variant, d_status, 0);
+                               n, eth_variant, d_status);
         } else {
             u32* xfer = (u32*)ar.take(use_vm3 ? vm3_xfer_bytes(n) : vm2_xfer_bytes(n));
             if (!xfer) return ECGPU_ERR_OOM;

@@ -18,10 +18,9 @@ namespace ecg {
 // k_of: number of keys of tuple i = pk_off ? pk_off[i+1]-pk_off[i] : 1.
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_pairing)(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts,
                                                         const A2* sigpts, const u8* st_dec, const u8* st_grp, const u8* sigs96,
-                                                        u32 n, int eth_variant, u8* status_out, int only_marked) {
+                                                        u32 n, int eth_variant, u8* status_out) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
-    if (only_marked && status_out[i] != VM_NEEDS_LANE_PATH) return;
     const u32 k = pk_off ? pk_off[i + 1] - pk_off[i] : 1;
     const bool sig_inf_bytes = sig_is_infinity_bytes(sigs96 + 96 * (size_t)i);
     const bool agg_inf = agg[i].inf != 0;
