@@ -272,6 +272,7 @@ ECG_HD void jac_to_aff(Aff<F>& r, const Jac<F>& p) {
 // [|x|] P, |x| = 0xd201000000010000 (MSB-first double-and-add: 63 doublings, 5 additions)
 template <class F>
 ECG_HD_NOINLINE void jac_mul_xabs(Jac<F>& r, const Jac<F>& p) {
+#if defined(ECG_TOWER_CALLS)
     const Jac<F> base = ecg_priv_load(p);
     Jac<F> acc = base;
     for (int b = 62; b >= 0; b--) {
@@ -279,6 +280,23 @@ ECG_HD_NOINLINE void jac_mul_xabs(Jac<F>& r, const Jac<F>& p) {
         if ((blsc::X_ABS >> b) & 1) jac_add(acc, acc, base);
     }
     ecg_priv_store(r, acc);
+#else
+    // The running point stays in registers across the 63 doublings (inlined: an out-of-line doubling reloads its operand with
+    // 21 separate waits on the private segment, a fifth of its time on a lone wave); the base point is needed five times and
+    // lives in memory -- 78 more live dwords under the doubling would come back as spills (cf. fp12_cyc_pow_x).
+    Jac<F> base_mem;
+    Jac<F> acc = ecg_priv_load(p);
+    ecg_priv_store(base_mem, acc);
+    for (int b = 62; b >= 0; b--) {
+        jac_dbl_inl(acc, acc);
+        if ((blsc::X_ABS >> b) & 1) {
+            Jac<F> t = acc;
+            jac_add(t, t, base_mem);
+            acc = t;
+        }
+    }
+    ecg_priv_store(r, acc);
+#endif
 }
 
 // [k] P for a scalar of `nwords` 32-bit LE words (test-vector generation: sk -> pk, signing)

@@ -118,13 +118,17 @@ ECG_HD_NOINLINE void miller_loop(Fp12& f, MillerPair* pairs, int n) {
 
 // a^x for a in the cyclotomic subgroup (x < 0: conjugate)
 ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
-    const Fp12 base = ecg_priv_load(a);
-    Fp12 acc = base;  // a register-resident value: the squaring is inlined, the five products work on a copy
+    // The running value is register-resident (the squaring is inlined, the five products work on a copy); the BASE is not: it
+    // is needed five times in 63 iterations, and 156 more live dwords under the squaring cost 64 reloads per iteration.  `a`
+    // may alias `r` (written only at the end); it is copied once so that the callee of the product never sees `r`'s storage.
+    Fp12 base_mem;
+    Fp12 acc = ecg_priv_load(a);
+    ecg_priv_store(base_mem, acc);
     for (int b = 62; b >= 0; b--) {
         fp12_cyclotomic_sqr_inl(acc, acc);
         if ((blsc::X_ABS >> b) & 1) {
-            Fp12 t = acc, u = base;
-            fp12_mul(t, t, u);
+            Fp12 t = acc;
+            fp12_mul(t, t, base_mem);
             acc = t;
         }
     }
