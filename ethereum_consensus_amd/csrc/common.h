@@ -67,8 +67,10 @@ ECG_D T ecg_priv_load(const T& x) {
     u32* q = (u32*)&r;
 #pragma unroll
     for (unsigned i = 0; i < sizeof(T) / 4; i++) q[i] = p[i];
-    // (materialising every dword here, so that the wave parks once per object instead of once per first use, was measured and
-    // does not pay: 44.5 against 43.8 ms per 65 536 tuples, profiles/r02u_staggered_start.txt)
+    // (materialising every dword here with an asm barrier, so that the wave parks once per object instead of once per first
+    // use, was measured and does not pay: 44.5 against 43.8 ms per 65 536 tuples, profiles/r02u_staggered_start.txt)
+    // (a scheduling barrier after the loads of small objects, which keeps them together ahead of their uses, halves the static
+    // wait count of an out-of-line doubling and changes nothing measurable: 41.6 ms either way)
     return r;
 }
 template <class T>
