@@ -80,8 +80,10 @@ __global__ void __launch_bounds__(BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts,
             continue;
         }
         if (!pts[j].inf) {
+            // inlined: the running sum stays in registers (the out-of-line form moves it through the private segment with
+            // ~30 separately awaited accesses per call, and this loop + the tree below are one dependent chain per aggregate)
             F x = pts[j].x, y = pts[j].y;
-            jac_add_aff(acc, acc, x, y);
+            jac_add_aff_inl(acc, acc, x, y);
         }
     }
     sh[tid] = acc;
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts,
     for (u32 stride = BLOCK / 2; stride > 0; stride >>= 1) {
         if (tid < stride) {
             Jac<F> o = sh[tid + stride];
-            jac_add(acc, acc, o);
+            jac_add_inl(acc, acc, o);
             sh[tid] = acc;
         }
         __syncthreads();
