@@ -22,7 +22,7 @@ LIB = os.path.join(LIBDIR, "libecgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 VM2_GEN_ARGS = os.environ.get("ECGPU_VM2_GEN_ARGS", "--lanes 16 --window 200").split()
-VM3_GEN_ARGS = os.environ.get("ECGPU_VM3_GEN_ARGS", "--lanes 16 --window 60").split()
+VM3_GEN_ARGS = os.environ.get("ECGPU_VM3_GEN_ARGS", "--lanes 16 --lanes-c 12 --window 60").split()
 # -pragma-unroll-threshold: the sums of products (bls_fp.h fp_sumprod) are 13 rows x up to 13 x 13 multiply-adds that
 # must be fully unrolled for their column accumulators to stay in registers; the default threshold stops at ~1000.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

@@ -1,7 +1,7 @@
 // The "sum-of-products VM": lane-group execution of straight-line programs over an LDS-resident Fp register file
 // (tools/gen_bls_vm3.py has the why, the programs and the encoding).
 //
-// A tuple (one pairing check) is owned by ECG_VM3_LANES consecutive lanes of a wave.  A program is a sequence of rounds;
+// A tuple (one pairing check) is owned by ECG_VM3_<part>_LANES consecutive lanes of a wave (16 in the Miller loops, 12 in the final exponentiation).  A program is a sequence of rounds;
 // round r has one header word (N | nder << 8) and gives lane slot k the 8-dword descriptor prog[(r * LANES + k) * 8 ..]:
 //     w0: dst | a0 << 8 | a1 << 16 | a2 << 24     w1: a3 | a4 << 8 | a5 << 16 | a6 << 24
 //     w2: b0 | b1 << 8 | b2 << 16 | b3 << 24      w3: b4 | b5 << 8 | b6 << 16

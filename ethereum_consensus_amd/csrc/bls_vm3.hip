@@ -1,4 +1,4 @@
-// Lane-group ("sum-of-products VM") pairing kernels for gfx950: ECG_VM3_LANES lanes share one pairing check; the tower
+// Lane-group ("sum-of-products VM") pairing kernels for gfx950: 16 (Miller loops) / 12 (final exponentiation) lanes share one pairing check; the tower
 // arithmetic is a generated straight-line program over an LDS-resident Fp register file in which every operation is a
 // sum of products with one Montgomery reduction and every linear step rides along as a derived output of its producer
 // (tools/gen_bls_vm3.py, csrc/bls_vm3.h).  This is the e(pk, H(m)) == e(g1, sig) check of
@@ -20,8 +20,10 @@
 
 namespace ecg {
 
-constexpr int VM3_G = ECG_VM3_LANES;
-constexpr int VM3_TPW = 64 / VM3_G;     // tuples per wave (= per workgroup)
+// lanes per tuple, per part: the Miller loops keep 8 lane pairs busy, the final exponentiation is Fp12 arithmetic (6 pairs), so
+// part C runs 12-lane groups, five tuples to a wave (tools/gen_bls_vm3.py --lanes-c; 23.9 -> 22.3 ms per 65 536 tuples)
+constexpr int VM3_G_A = ECG_VM3_A_LANES, VM3_G_C = ECG_VM3_C_LANES;
+constexpr int VM3_TPW_A = 64 / VM3_G_A, VM3_TPW_C = 64 / VM3_G_C;  // tuples per wave (= per workgroup)
 constexpr u32 XFER3_REGS = 16;          // per tuple: f (12 Fp, w-power order), d, -, 1/d, -
 constexpr u32 XFER3_STRIDE = XFER3_REGS * VM3_REG_DW;
 
@@ -48,7 +50,7 @@ static int upload3(const unsigned int* h, size_t n, const u32** d) {
 #define VM3_FILL(D, T)                                                                                                       \
     do {                                                                                                                     \
         int rc_;                                                                                                             \
-        if ((rc_ = upload3(ECG_VM3_##T##_PROG, (size_t)ECG_VM3_##T##_ROUNDS * ECG_VM3_LANES * VM3_DESC_DW, &D.prog))) return rc_; \
+        if ((rc_ = upload3(ECG_VM3_##T##_PROG, (size_t)ECG_VM3_##T##_ROUNDS * ECG_VM3_##T##_LANES * VM3_DESC_DW, &D.prog))) return rc_; \
         if ((rc_ = upload3(ECG_VM3_##T##_HDR, ECG_VM3_##T##_ROUNDS, &D.hdr))) return rc_;                                    \
         if ((rc_ = upload3(ECG_VM3_##T##_CONST_REG, ECG_VM3_##T##_NCONST, &D.const_reg))) return rc_;                        \
         if ((rc_ = upload3(ECG_VM3_##T##_CONST_VAL, (size_t)ECG_VM3_##T##_NCONST * 13, &D.const_val))) return rc_;           \
@@ -63,7 +65,7 @@ static int upload3(const unsigned int* h, size_t n, const u32** d) {
 
 int init_vm3_tables() {
     static_assert(ECG_VM3_A_NIN == 10 && ECG_VM3_A_NOUT == 14 && ECG_VM3_C_NIN == 14 && ECG_VM3_C_NOUT == 12, "program interface");
-    static_assert(ECG_VM3_LANES <= 64 && ECG_VM3_LANES % 2 == 0, "results travel in lane pairs; lanes beyond TPW groups of a wave idle");
+    static_assert(VM3_G_A <= 64 && VM3_G_A % 2 == 0 && VM3_G_C <= 64 && VM3_G_C % 2 == 0, "results travel in lane pairs; lanes beyond TPW groups of a wave idle");
     static_assert(ECG_VM3_CONST_BASE == VM3_CONST_BASE, "generator and kernel agree on where the constants start");
     VM3_FILL(g_vm3_a, A);
     VM3_FILL(g_vm3_c, C);
@@ -80,7 +82,8 @@ ECG_D Fp vm3_round_sum(const Vm3Regs& R, const uint4 w01) {
     return vm3_sum<N>(R, w);
 }
 
-// one lane group through a whole program; R = the tuple's register file in LDS
+// one lane group (VM3_G lanes) through a whole program; R = the tuple's register file in LDS
+template <int VM3_G>
 ECG_D void vm3_run(const Vm3Desc& d, const Vm3Regs& R, u32 slot, bool idle = false) {
     // `idle`: a lane beyond the last whole group of the wave (64 is not a multiple of every group size): it runs the rounds
     // with all-zero descriptors -- operands ZERO, no stores
@@ -126,7 +129,9 @@ ECG_D void vm3_run(const Vm3Desc& d, const Vm3Regs& R, u32 slot, bool idle = fal
 }
 
 // register 0 of every tuple = ZERO; the constants once per workgroup, behind the tuples' slices
+template <int VM3_G>
 ECG_D Vm3Regs vm3_setup(const Vm3Desc& d, u32* lds, u32 lane) {
+    constexpr int VM3_TPW = 64 / VM3_G;
     const u32 slot = lane % VM3_G, tl = lane / VM3_G < VM3_TPW ? lane / VM3_G : VM3_TPW - 1;  // idle lanes look at the last slice
     u32* own = lds + tl * d.nreg * VM3_REG_DW;
     u32* consts = lds + VM3_TPW * d.nreg * VM3_REG_DW;
@@ -141,11 +146,12 @@ ECG_D Vm3Regs vm3_setup(const Vm3Desc& d, u32* lds, u32 lane) {
 // part A: Miller loops of e(agg, H) e(-g1, sig) -> f (12 Fp) and the Fp norm d to invert
 __global__ void __launch_bounds__(64) k_vm3_pair_a(Vm3Desc d, const A1* agg, const A2* hpts, const A2* sigpts, u32 n, u32* xfer) {
     extern __shared__ u32 vm3_lds[];
+    constexpr int VM3_G = VM3_G_A, VM3_TPW = VM3_TPW_A;
     const u32 lane = threadIdx.x, slot = lane % VM3_G, tl = lane / VM3_G;
     const bool idle = tl >= VM3_TPW;
     const u32 tuple = idle ? n : blockIdx.x * VM3_TPW + tl;
     const u32 tc = tuple < n ? tuple : n - 1;
-    const Vm3Regs R = vm3_setup(d, vm3_lds, lane);
+    const Vm3Regs R = vm3_setup<VM3_G>(d, vm3_lds, lane);
     for (u32 k = slot; k < 10 && !idle; k += VM3_G) {
         // inputs in the generator's order: PXY = (x, y) of the aggregate key, then HX, HY, SX, SY (c0, c1 each)
         const u32* w = k == 0   ? agg[tc].x.l
@@ -157,7 +163,7 @@ __global__ void __launch_bounds__(64) k_vm3_pair_a(Vm3Desc d, const A1* agg, con
         for (u32 i = 0; i < VM3_REG_DW; i++) R.own[d.in_reg[k] * VM3_REG_DW + i] = w[i];
     }
     __syncthreads();
-    vm3_run(d, R, slot, idle);
+    vm3_run<VM3_G>(d, R, slot, idle);
     if (tuple < n)
         for (u32 k = slot; k < 13; k += VM3_G) {
             u32* o = xfer + (size_t)tuple * XFER3_STRIDE + k * VM3_REG_DW;
@@ -180,19 +186,20 @@ __global__ void __launch_bounds__(64) k_vm3_pair_c(Vm3Desc d, const u32* xfer, c
                                                    const A2* hpts, const A2* sigpts, const u8* st_dec, const u8* st_grp, const u8* sigs96,
                                                    u32 n, int eth_variant, u8* status_out) {
     extern __shared__ u32 vm3_lds[];
+    constexpr int VM3_G = VM3_G_C, VM3_TPW = VM3_TPW_C;
     __shared__ u32 not_one[VM3_TPW];
     const u32 lane = threadIdx.x, slot = lane % VM3_G, tl = lane / VM3_G;
     const bool idle = tl >= VM3_TPW;
     const u32 tuple = idle ? n : blockIdx.x * VM3_TPW + tl;
     const u32 tc = tuple < n ? tuple : n - 1;
-    const Vm3Regs R = vm3_setup(d, vm3_lds, lane);
+    const Vm3Regs R = vm3_setup<VM3_G>(d, vm3_lds, lane);
     for (u32 k = slot; k < 14 && !idle; k += VM3_G) {
         const u32* w = xfer + (size_t)tc * XFER3_STRIDE + (k < 12 ? k : k + 2) * VM3_REG_DW;
         for (u32 i = 0; i < VM3_REG_DW; i++) R.own[d.in_reg[k] * VM3_REG_DW + i] = w[i];
     }
     if (slot == 0 && !idle) not_one[tl] = 0;
     __syncthreads();
-    vm3_run(d, R, slot, idle);
+    vm3_run<VM3_G>(d, R, slot, idle);
     for (u32 k = slot; k < 12 && !idle; k += VM3_G) {
         const Fp v = vm3_load(R, d.out_reg[k]);
         const bool ok = k == 0 ? fp_eq(v, fp_one()) : fp_is_zero(v);
@@ -223,10 +230,10 @@ size_t vm3_xfer_bytes(u32 n) { return (size_t)n * XFER3_STRIDE * 4 + 256; }
 int vm3_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts,
                        const u8* st_dec, const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer) {
     static_assert(sizeof(Fp) == 13 * 4, "register images are read straight from the staged points");
-    const dim3 vgrid((n + VM3_TPW - 1) / VM3_TPW);
+    const dim3 vgrid_a((n + VM3_TPW_A - 1) / VM3_TPW_A), vgrid_c((n + VM3_TPW_C - 1) / VM3_TPW_C);
     // per workgroup: the tuples' register slices + one copy of the constants
-    const size_t lds_a = ((size_t)VM3_TPW * g_vm3_a.nreg + g_vm3_a.nconst) * VM3_REG_DW * 4,
-                 lds_c = ((size_t)VM3_TPW * g_vm3_c.nreg + g_vm3_c.nconst) * VM3_REG_DW * 4;
+    const size_t lds_a = ((size_t)VM3_TPW_A * g_vm3_a.nreg + g_vm3_a.nconst) * VM3_REG_DW * 4,
+                 lds_c = ((size_t)VM3_TPW_C * g_vm3_c.nreg + g_vm3_c.nconst) * VM3_REG_DW * 4;
     static bool attr_set[MAX_DEVICES] = {};
     if (!attr_set[current_device()]) {
         ECG_HIP_CHECK(hipFuncSetAttribute((const void*)k_vm3_pair_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
@@ -235,7 +242,7 @@ int vm3_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32*
     }
     {
         ProfScope pa("bls_vm3_a", s);
-        hipLaunchKernelGGL(k_vm3_pair_a, vgrid, dim3(64), lds_a, s, g_vm3_a, agg, hpts, sigpts, n, xfer);
+        hipLaunchKernelGGL(k_vm3_pair_a, vgrid_a, dim3(64), lds_a, s, g_vm3_a, agg, hpts, sigpts, n, xfer);
     }
     {
         ProfScope pi("bls_vm3_inv", s);
@@ -243,7 +250,7 @@ int vm3_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32*
     }
     {
         ProfScope pc("bls_vm3_c", s);
-        hipLaunchKernelGGL(k_vm3_pair_c, vgrid, dim3(64), lds_c, s, g_vm3_c, (const u32*)xfer, agg, st_pk, pk_off, hpts, sigpts, st_dec,
+        hipLaunchKernelGGL(k_vm3_pair_c, vgrid_c, dim3(64), lds_c, s, g_vm3_c, (const u32*)xfer, agg, st_pk, pk_off, hpts, sigpts, st_dec,
                            st_grp, sigs96, n, eth_variant, d_status);
     }
     ECG_HIP_CHECK(hipGetLastError());

@@ -316,11 +316,11 @@ int hs_vm3_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
     A2 h = in_a2(h_xy, 0), sg = in_a2(s_xy, 0);
     const Fp in[10] = {p.x, p.y, h.x.c0, h.x.c1, h.y.c0, h.y.c1, sg.x.c0, sg.x.c1, sg.y.c0, sg.y.c1};
     for (int k = 0; k < 10; k++) vm3_store(A, ECG_VM3_A_IN[k], in[k]);
-    vm3_run_serial(ECG_VM3_A_PROG, ECG_VM3_A_HDR, ECG_VM3_A_ROUNDS, ECG_VM3_LANES, A);
+    vm3_run_serial(ECG_VM3_A_PROG, ECG_VM3_A_HDR, ECG_VM3_A_ROUNDS, ECG_VM3_A_LANES, A);
     for (int k = 0; k < 12; k++) vm3_store(Cr, ECG_VM3_C_IN[k], vm3_load(A, ECG_VM3_A_OUT[k]));
     vm3_store(Cr, ECG_VM3_C_IN[12], fp_inv(vm3_load(A, ECG_VM3_A_OUT[12])));
     vm3_store(Cr, ECG_VM3_C_IN[13], fp_zero());
-    vm3_run_serial(ECG_VM3_C_PROG, ECG_VM3_C_HDR, ECG_VM3_C_ROUNDS, ECG_VM3_LANES, Cr);
+    vm3_run_serial(ECG_VM3_C_PROG, ECG_VM3_C_HDR, ECG_VM3_C_ROUNDS, ECG_VM3_C_LANES, Cr);
     // w-power order g0..g5 = c0.c0, c1.c0, c0.c1, c1.c1, c0.c2, c1.c2
     Fp12 e;
     Fp2* c[6] = {&e.c0.c0, &e.c1.c0, &e.c0.c1, &e.c1.c1, &e.c0.c2, &e.c1.c2};

@@ -858,7 +858,7 @@ def mont_limbs(v):
     return [(m >> (30 * i)) & 0x3FFFFFFF for i in range(13)]
 
 
-def emit(pa, pc, wa, ha, wc, hc, lanes):
+def emit(pa, pc, wa, ha, wc, hc):
     def arr(name, vals, per=8, ty="unsigned int"):
         out = [f"static const {ty} {name}[{max(1, len(vals))}] = {{"]
         for i in range(0, len(vals), per):
@@ -867,13 +867,13 @@ def emit(pa, pc, wa, ha, wc, hc, lanes):
         return "\n".join(out)
 
     print("// GENERATED by tools/gen_bls_vm3.py -- do not edit.  Sum-of-products lane-group programs of the BLS pairing check.")
-    print("// One round = one header word (N | nder << 8) + ECG_VM3_LANES descriptors of 8 dwords (tools/gen_bls_vm3.py encode()).")
+    print("// One round = one header word (N | nder << 8) + ECG_VM3_<part>_LANES descriptors of 8 dwords (tools/gen_bls_vm3.py encode()).")
     print("#pragma once")
-    print(f"#define ECG_VM3_LANES {lanes}")
     for tag, pr, w, h in (("A", pa, wa, ha), ("C", pc, wc, hc)):
         fill = pr.mads / max(1, pr.slot_mads)
         print(f"// part {tag}: {pr.nops} ops, {pr.nder} derived outputs in {len(pr.rounds)} rounds {dict(sorted(pr.hist.items()))}, {pr.nreg} registers, "
               f"{pr.mads} multiply-adds per tuple at {100 * fill:.0f} % slot fill, model {int(pr.cycles)} cycles per wave")
+        print(f"#define ECG_VM3_{tag}_LANES {pr.lanes}")
         print(f"#define ECG_VM3_{tag}_NREG {pr.nreg}")
         print(f"#define ECG_VM3_CONST_BASE {CONST_BASE}") if tag == "A" else None
         print(f"#define ECG_VM3_{tag}_ROUNDS {len(pr.rounds)}")
@@ -892,7 +892,8 @@ def emit(pa, pc, wa, ha, wc, hc, lanes):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--lanes", type=int, default=16)
+    ap.add_argument("--lanes", type=int, default=16, help="lanes per tuple in part A (the Miller loops)")
+    ap.add_argument("--lanes-c", type=int, default=0, help="lanes per tuple in part C (the final exponentiation); 0 = as part A")
     ap.add_argument("--window", type=int, default=400)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--stats", action="store_true")
@@ -901,16 +902,15 @@ def main():
     ta, outs_a, ins_a = trace_part_a()
     pa = make_program(ta, outs_a, ins_a, args.lanes, args.window)
     tc, outs_c, ins_c = trace_part_c()
-    pc = make_program(tc, outs_c, ins_c, args.lanes, args.window)
+    pc = make_program(tc, outs_c, ins_c, args.lanes_c or args.lanes, args.window)
     wa, ha = encode(pa)
     wc, hc = encode(pc)
     if args.stats or args.check:
-        tpw = 64 // args.lanes
         for tag, pr in (("A", pa), ("C", pc)):
             sys.stderr.write(f"part {tag}: {pr.nops} ops, {pr.nder} derived, rounds {len(pr.rounds)} {dict(sorted(pr.hist.items()))}, nreg {pr.nreg}, "
                              f"mads/tuple {pr.mads}, slot fill {100 * pr.mads / max(1, pr.slot_mads):.0f} %, model {int(pr.cycles)} cycles\n")
-        tot = pa.cycles + pc.cycles
-        sys.stderr.write(f"model: {int(tot)} cycles per wave of {tpw} tuples -> {tot * 65536 / tpw / 2048 / 2.4e9 * 1e3 * 2:.1f} ms per 65536 tuples "
+        tot = pa.cycles / (64 // pa.lanes) + pc.cycles / (64 // pc.lanes)
+        sys.stderr.write(f"model: {int(tot)} cycles of SIMD time per tuple -> {tot * 65536 / 2048 / 2.4e9 * 1e3 * 2:.1f} ms per 65536 tuples "
                          f"(1024 SIMDs, two waves each taking the modelled cycles of SIMD time, 2.4 GHz)\n")
     if args.check:
         rnd = random.Random(1)
@@ -932,7 +932,7 @@ def main():
         sys.stderr.write("check ok\n")
         return
     if not args.stats:
-        emit(pa, pc, wa, ha, wc, hc, args.lanes)
+        emit(pa, pc, wa, ha, wc, hc)
 
 
 if __name__ == "__main__":
