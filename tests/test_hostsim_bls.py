@@ -385,3 +385,16 @@ def test_no_column_overflow_anywhere_in_the_suite():
     assert L.hs_fast_aggregate_verify(bytes(pk), 1, bytes(C.CAN_SIGN_MSG), len(C.CAN_SIGN_MSG), bytes(C.CAN_SIGN_SIG), 0) == 0
     assert L.hs_column_overflows() == 0
 
+
+def test_two_lane_message_stage_on_the_compact_build():
+    """hash_to_g2_map x 2 + hash_to_g2_finish (k_h2c_map_calls / k_h2c_finish_calls on a slow-fetch box) == hash_to_g2 == oracle,
+    on the compact-code tower as well"""
+    r = random.Random(21)
+    L = lib_variant("calls")
+    L.hs_hash_to_g2.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    L.hs_hash_to_g2_split.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    for msg in [b"", C.CAN_SIGN_MSG] + [r.randbytes(32) for _ in range(6)]:
+        xy, xy2, inf = ctypes.create_string_buffer(192), ctypes.create_string_buffer(192), ctypes.c_int(0)
+        L.hs_hash_to_g2(msg, len(msg), xy, ctypes.byref(inf))
+        L.hs_hash_to_g2_split(msg, len(msg), xy2, ctypes.byref(inf))
+        assert xy.raw == xy2.raw and un2(xy.raw) == B.hash_to_g2(msg)
