@@ -88,13 +88,13 @@ ECG_D void vm3_run(const Vm3Desc& d, const Vm3Regs& R, u32 slot, bool idle = fal
     // `idle`: a lane beyond the last whole group of the wave (64 is not a multiple of every group size): it runs the rounds
     // with all-zero descriptors -- operands ZERO, no stores
     const uint4* pp = (const uint4*)d.prog + (size_t)slot * 2;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    uint4 w01 = idle ? zero4 : pp[0], w23 = idle ? zero4 : pp[1];
+    uint4 w01 = pp[0], w23 = pp[1];  // (loaded unconditionally, then blanked: a select between the two SOURCES becomes a flat load)
+    if (idle) w01 = w23 = make_uint4(0, 0, 0, 0);
     u32 h = d.hdr[0];
     for (u32 r = 0; r < d.rounds; r++) {
         const u32 rn = (r + 1 < d.rounds) ? r + 1 : r;
         uint4 n01 = pp[(size_t)rn * VM3_G * 2], n23 = pp[(size_t)rn * VM3_G * 2 + 1];  // next round's descriptor, in flight
-        if (idle) n01 = n23 = zero4;
+        if (idle) n01 = n23 = make_uint4(0, 0, 0, 0);
         const u32 hn = d.hdr[rn];
         const u32 hu = (u32)__builtin_amdgcn_readfirstlane((int)h);
         const u32 n = hu & 255, nder = (hu >> 8) & 255;
