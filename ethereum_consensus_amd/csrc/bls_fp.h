@@ -218,63 +218,90 @@ ECG_HD Fp fp_mul_body(const Fp& a, const Fp& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
 // nothing but memory and scalar instructions may be scheduled across (operand loads should still be issued early)
 #define ECG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x3f4)
-// T[k] += a[k] * b for 7 / 6 consecutive columns, written as the instructions themselves.  Two reasons: from
+// T[k] (+)= a[k] * b for the 13 columns of a row, written as the instructions themselves.  Two reasons: from
 // `(u64)a * b` LLVM keeps every operand limb that has more than one use as a zero-extended 64-bit register PAIR (the
 // extension is CSE'd and then allocated), which doubles the operand registers of a sum of products and spills it to the
 // private segment; and one statement per multiply-add gets an s_nop between every two of them (the hazard recogniser's
-// conservative rule for back-to-back inline asm), which costs a full issue slot each at one wave per SIMD.  The carry-out
-// of v_mad_u64_u32 goes to vcc and is never used (columns have 4 bits of headroom).
-ECG_D void ecg_mad7(u64* T, const u32* a, u32 b) {
-    asm("v_mad_u64_u32 %0, vcc, %7, %14, %0\n\tv_mad_u64_u32 %1, vcc, %8, %14, %1\n\tv_mad_u64_u32 %2, vcc, %9, %14, %2\n\t"
-        "v_mad_u64_u32 %3, vcc, %10, %14, %3\n\tv_mad_u64_u32 %4, vcc, %11, %14, %4\n\tv_mad_u64_u32 %5, vcc, %12, %14, %5\n\t"
-        "v_mad_u64_u32 %6, vcc, %13, %14, %6"
-        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6])
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(b)
-        : "vcc");
-}
-ECG_D void ecg_mad6(u64* T, const u32* a, u32 b) {
-    asm("v_mad_u64_u32 %0, vcc, %6, %12, %0\n\tv_mad_u64_u32 %1, vcc, %7, %12, %1\n\tv_mad_u64_u32 %2, vcc, %8, %12, %2\n\t"
-        "v_mad_u64_u32 %3, vcc, %9, %12, %3\n\tv_mad_u64_u32 %4, vcc, %10, %12, %4\n\tv_mad_u64_u32 %5, vcc, %11, %12, %5"
-        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5])
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b)
-        : "vcc");
+// conservative rule for back-to-back inline asm), which costs a full issue slot each at one wave per SIMD -- hence ONE
+// statement per row (27 operands; round 2 had two, 7 + 6 columns).  The carry-out of v_mad_u64_u32 goes to vcc and is never
+// used (columns have 4 bits of headroom).
+// FRESH = first column of the row that has not been written yet (13: none).  A column's first multiply-add takes the
+// constant 0 as its addend instead of a register pair somebody had to clear: the 27 v_mov_b64 per sum of products that the
+// zero-initialised accumulators cost in round 2 (4-5 % of the instructions of a sum of 2 or 3 products) are gone.
+#define ECG_MAD_ACC(k, a) "v_mad_u64_u32 %" #k ", vcc, %" #a ", %26, %" #k "\n\t"
+#define ECG_MAD_NEW(k, a) "v_mad_u64_u32 %" #k ", vcc, %" #a ", %26, 0\n\t"
+#define ECG_ROW_IN(a, b) \
+    "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(b)
+template <int FRESH>
+ECG_D void ecg_mad_row(u64* T, const u32* a, u32 b) {
+    static_assert(FRESH == 13 || FRESH == 12 || FRESH == 0, "a row starts a sum (0), opens one new column (12) or none (13)");
+    if constexpr (FRESH == 13) {
+        asm(ECG_MAD_ACC(0, 13) ECG_MAD_ACC(1, 14) ECG_MAD_ACC(2, 15) ECG_MAD_ACC(3, 16) ECG_MAD_ACC(4, 17) ECG_MAD_ACC(5, 18) ECG_MAD_ACC(6, 19)
+                ECG_MAD_ACC(7, 20) ECG_MAD_ACC(8, 21) ECG_MAD_ACC(9, 22) ECG_MAD_ACC(10, 23) ECG_MAD_ACC(11, 24) "v_mad_u64_u32 %12, vcc, %25, %26, %12"
+            : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]), "+v"(T[8]), "+v"(T[9]), "+v"(T[10]),
+              "+v"(T[11]), "+v"(T[12])
+            : ECG_ROW_IN(a, b)
+            : "vcc");
+    } else if constexpr (FRESH == 12) {
+        asm(ECG_MAD_ACC(0, 13) ECG_MAD_ACC(1, 14) ECG_MAD_ACC(2, 15) ECG_MAD_ACC(3, 16) ECG_MAD_ACC(4, 17) ECG_MAD_ACC(5, 18) ECG_MAD_ACC(6, 19)
+                ECG_MAD_ACC(7, 20) ECG_MAD_ACC(8, 21) ECG_MAD_ACC(9, 22) ECG_MAD_ACC(10, 23) ECG_MAD_ACC(11, 24) "v_mad_u64_u32 %12, vcc, %25, %26, 0"
+            : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]), "+v"(T[8]), "+v"(T[9]), "+v"(T[10]),
+              "+v"(T[11]), "=&v"(T[12])
+            : ECG_ROW_IN(a, b)
+            : "vcc");
+    } else {
+        asm(ECG_MAD_NEW(0, 13) ECG_MAD_NEW(1, 14) ECG_MAD_NEW(2, 15) ECG_MAD_NEW(3, 16) ECG_MAD_NEW(4, 17) ECG_MAD_NEW(5, 18) ECG_MAD_NEW(6, 19)
+                ECG_MAD_NEW(7, 20) ECG_MAD_NEW(8, 21) ECG_MAD_NEW(9, 22) ECG_MAD_NEW(10, 23) ECG_MAD_NEW(11, 24) "v_mad_u64_u32 %12, vcc, %25, %26, 0"
+            : "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(T[6]), "=&v"(T[7]), "=&v"(T[8]), "=&v"(T[9]),
+              "=&v"(T[10]), "=&v"(T[11]), "=&v"(T[12])
+            : ECG_ROW_IN(a, b)
+            : "vcc");
+    }
 }
 // the same with the limbs of p (compile-time constants, kept in scalar registers: one per instruction is allowed)
-ECG_D void ecg_mad7_p(u64* T, u32 m) {
-    asm("v_mad_u64_u32 %0, vcc, %14, %7, %0\n\tv_mad_u64_u32 %1, vcc, %14, %8, %1\n\tv_mad_u64_u32 %2, vcc, %14, %9, %2\n\t"
-        "v_mad_u64_u32 %3, vcc, %14, %10, %3\n\tv_mad_u64_u32 %4, vcc, %14, %11, %4\n\tv_mad_u64_u32 %5, vcc, %14, %12, %5\n\t"
-        "v_mad_u64_u32 %6, vcc, %14, %13, %6"
-        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6])
-        : "s"(blsc::P[0]), "s"(blsc::P[1]), "s"(blsc::P[2]), "s"(blsc::P[3]), "s"(blsc::P[4]), "s"(blsc::P[5]), "s"(blsc::P[6]), "v"(m)
-        : "vcc");
-}
-ECG_D void ecg_mad6_p(u64* T, u32 m) {
-    asm("v_mad_u64_u32 %0, vcc, %12, %6, %0\n\tv_mad_u64_u32 %1, vcc, %12, %7, %1\n\tv_mad_u64_u32 %2, vcc, %12, %8, %2\n\t"
-        "v_mad_u64_u32 %3, vcc, %12, %9, %3\n\tv_mad_u64_u32 %4, vcc, %12, %10, %4\n\tv_mad_u64_u32 %5, vcc, %12, %11, %5"
-        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5])
-        : "s"(blsc::P[7]), "s"(blsc::P[8]), "s"(blsc::P[9]), "s"(blsc::P[10]), "s"(blsc::P[11]), "s"(blsc::P[12]), "v"(m)
-        : "vcc");
-}
-// T[0..12] += a[0..12] * b
-ECG_D void ecg_mad_row(u64* T, const u32* a, u32 b) {
-    ecg_mad7(T, a, b);
-    ecg_mad6(T + 7, a + 7, b);
-}
 ECG_D void ecg_mad_row_p(u64* T, u32 m) {
-    ecg_mad7_p(T, m);
-    ecg_mad6_p(T + 7, m);
+    asm(ECG_MAD_ACC(0, 13) ECG_MAD_ACC(1, 14) ECG_MAD_ACC(2, 15) ECG_MAD_ACC(3, 16) ECG_MAD_ACC(4, 17) ECG_MAD_ACC(5, 18) ECG_MAD_ACC(6, 19)
+            ECG_MAD_ACC(7, 20) ECG_MAD_ACC(8, 21) ECG_MAD_ACC(9, 22) ECG_MAD_ACC(10, 23) ECG_MAD_ACC(11, 24) "v_mad_u64_u32 %12, vcc, %25, %26, %12"
+        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]), "+v"(T[8]), "+v"(T[9]), "+v"(T[10]),
+          "+v"(T[11]), "+v"(T[12])
+        : "s"(blsc::P[0]), "s"(blsc::P[1]), "s"(blsc::P[2]), "s"(blsc::P[3]), "s"(blsc::P[4]), "s"(blsc::P[5]), "s"(blsc::P[6]), "s"(blsc::P[7]),
+          "s"(blsc::P[8]), "s"(blsc::P[9]), "s"(blsc::P[10]), "s"(blsc::P[11]), "s"(blsc::P[12]), "v"(m)
+        : "vcc");
+}
+// Carry-save step between two columns: next += 4 * (col >> 32), col &= 2^32 - 1 (2^32 = 4 * 2^30).  The high DWORD of the
+// column is a register of its own, so moving it is ONE multiply-add (by the constant 4) plus clearing it -- instead of a
+// 64-bit shift, a 64-bit addition, a mask and the clear (round 2: 4 instructions per column, a quarter of the non-multiply
+// instructions of the tower).  The low dword keeps up to 32 bits instead of 30: 2^32 + 2^34 is still nothing against the
+// 2^64 - 15 * 2^60 of headroom.  FRESH: `next` has not been written yet.
+template <bool FRESH>
+ECG_D void ecg_col_pass_hi(u64& next, u64& col) {
+    const u32 hi = (u32)(col >> 32);
+    if constexpr (FRESH)
+        asm("v_mad_u64_u32 %0, vcc, %1, 4, 0" : "=v"(next) : "v"(hi) : "vcc");
+    else
+        asm("v_mad_u64_u32 %0, vcc, %1, 4, %0" : "+v"(next) : "v"(hi) : "vcc");
+    col = (u64)(u32)col;
 }
 #else
 #define ECG_SCHED_FENCE() ((void)0)
 // host lane simulator (CPU test-suite): the same column arithmetic, with every accumulation checked for 64-bit overflow
 extern unsigned long long g_ecg_column_overflows;
+template <int FRESH>
 ECG_HD void ecg_mad_row(u64* T, const u32* a, u32 b) {
-    for (int j = 0; j < 13; j++)
+    for (int j = 0; j < 13; j++) {
+        if (j >= FRESH) T[j] = 0;
         if (__builtin_add_overflow(T[j], (u64)a[j] * b, &T[j])) g_ecg_column_overflows++;
+    }
 }
 ECG_HD void ecg_mad_row_p(u64* T, u32 m) {
     for (int j = 0; j < 13; j++)
         if (__builtin_add_overflow(T[j], (u64)m * blsc::P[j], &T[j])) g_ecg_column_overflows++;
+}
+template <bool FRESH>
+ECG_HD void ecg_col_pass_hi(u64& next, u64& col) {
+    if (FRESH) next = 0;
+    if (__builtin_add_overflow(next, (col >> 32) << 2, &next)) g_ecg_column_overflows++;
+    col &= 0xffffffffull;
 }
 #endif
 // k * p in normalized limbs, evaluated at compile time: the offsets of the lazy subtractions below.
@@ -327,6 +354,27 @@ ECG_HD Fp fp_sub_lazy_k(const Fp& a, const Fp& b) {
 // loses to schoolbook with the signs folded into operands (4 half-products + 2 reductions, no linear operation on a
 // result).  169 N + 169 multiply-adds + 13 quotient digits; the 64-bit columns absorb 15 products of 30-bit limbs, so
 // they are renormalized every floor(15 / (N + 1)) rows.
+template <int N, int I>
+ECG_HD void fp_sumprod_row(u64* T, const Fp (&a)[N], const Fp (&b)[N]) {
+    constexpr int ROWS = 15 / (N + 1);
+    // column I + 12 is new to row I unless the carry-save pass after row I - 1 has just opened it
+    constexpr bool after_pass = I > 0 && I % ROWS == 0;
+    constexpr int FRESH = I == 0 ? 0 : (after_pass ? 13 : 12);
+    ecg_mad_row<FRESH>(T + I, a[0].l, b[0].l[I]);
+#pragma unroll
+    for (int k = 1; k < N; k++) ecg_mad_row<13>(T + I, a[k].l, b[k].l[I]);
+    const u32 m = ((u32)T[I] * blsc::N0) & FP_MASK;
+    ecg_mad_row_p(T + I, m);
+    T[I + 1] += T[I] >> 30;  // T[I] == 0 mod 2^30 now
+    if constexpr ((I + 1) % ROWS == 0 && I + 1 < FP_N) {
+        // carry-save pass over the 12 live columns, top down (each step reads a high dword no earlier step has touched);
+        // it opens column I + 13
+        ecg_col_pass_hi<true>(T[I + 13], T[I + 12]);
+#pragma unroll
+        for (int c = I + 11; c >= I + 1; c--) ecg_col_pass_hi<false>(T[c + 1], T[c]);
+    }
+    if constexpr (I + 1 < FP_N) fp_sumprod_row<N, I + 1>(T, a, b);
+}
 template <int N>
 ECG_HD Fp fp_sumprod(const Fp (&a)[N], const Fp (&b)[N]) {
     constexpr int ROWS = 15 / (N + 1);
@@ -334,26 +382,8 @@ ECG_HD Fp fp_sumprod(const Fp (&a)[N], const Fp (&b)[N]) {
     ECG_COUNT_MAD(169 * N + 182);
     ECG_SCHED_FENCE();  // one sum at a time: interleaving independent sums multiplies the live column accumulators
     u64 T[27];
-#pragma unroll
-    for (int i = 0; i < 27; i++) T[i] = 0;
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) {
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            const u32 bi = b[k].l[i];
-            ecg_mad_row(T + i, a[k].l, bi);
-        }
-        const u32 m = ((u32)T[i] * blsc::N0) & FP_MASK;
-        ecg_mad_row_p(T + i, m);
-        T[i + 1] += T[i] >> 30;  // T[i] == 0 mod 2^30 now
-        if ((i + 1) % ROWS == 0 && i + 1 < FP_N) {
-#pragma unroll
-            for (int c = i + 1; c <= i + 12; c++) {
-                T[c + 1] += T[c] >> 30;
-                T[c] &= FP_MASK;
-            }
-        }
-    }
+    fp_sumprod_row<N, 0>(T, a, b);
+    T[25] = 0;
     Fp r;
 #pragma unroll
     for (int c = 13; c < 25; c++) {

@@ -13,10 +13,79 @@
 
 namespace ecg {
 
+// ---- lane slots: twelve Fp values per lane in LDS ---------------------------------------------------------------------------
+// The pairing lane kernels run ONE wave per SIMD (the whole 512-entry register file per lane), so a CU holds 256 lanes and
+// its 160 KB of LDS give each of them 640 bytes: twelve field elements (624 B).  Round 2 kept the running points of the
+// Miller loop and the operands of the out-of-line Fp12 routines in the private segment: 515 MB of frames for 65 536 lanes,
+// which no cache holds, so every reload was a trip to HBM that a lone wave waits out (19.8 GB of traffic per launch, 20 % of
+// the wave's cycles parked on s_waitcnt).  The slots hold, in turn, the two running points of the Miller loop (2 x 6 Fp) and
+// one Fp12 operand of the final exponentiation.  Loads are volatile:
+// the point of the slots is that a value is re-read where it is used instead of staying live (and spilling).
+constexpr int LANE_SLOTS = 12;
+#if defined(__HIP_DEVICE_COMPILE__)
+// limb j of slot s at dword [13 s + j][lane]: every address is lane * 4 + constant (ONE address register for the whole kernel),
+// every access a ds_read_b32 / ds_write_b32 of 64 consecutive dwords (conflict-free).  Dword accesses on purpose: a
+// ds_read_b128 delivers, and a ds_write_b128 demands, a 128-bit register TUPLE, the register coalescer then keeps the limbs
+// that pass through one in tuples for their whole life, and a tuple can only be spilled and reloaded whole -- the first
+// version of the slots had four limbs of the Miller accumulator reloaded from the private segment in front of over a hundred
+// single-limb uses per line product.  (13 LDS instructions per field element instead of 4: +0.5 % instructions.)
+static __shared__ u32 g_lane_slots[13 * LANE_SLOTS * 64];
+// explicit LDS pointer: a volatile access through a generic pointer compiles to flat_load / flat_store
+typedef __attribute__((address_space(3))) volatile u32* lane_slot_ptr;
+ECG_D Fp slot_load(int s) {
+    const lane_slot_ptr p = (lane_slot_ptr)&g_lane_slots[13 * s * 64 + (threadIdx.x & 63)];
+    Fp r;
+#pragma unroll
+    for (int j = 0; j < 13; j++) r.l[j] = p[64 * j];
+    return r;
+}
+ECG_D void slot_store(int s, const Fp& a) {
+    const lane_slot_ptr p = (lane_slot_ptr)&g_lane_slots[13 * s * 64 + (threadIdx.x & 63)];
+#pragma unroll
+    for (int j = 0; j < 13; j++) p[64 * j] = a.l[j];
+}
+#else
+// host lane simulator: one lane at a time per thread
+static thread_local Fp g_lane_slots[LANE_SLOTS];
+ECG_HD Fp slot_load(int s) { return g_lane_slots[s]; }
+ECG_HD void slot_store(int s, const Fp& a) { g_lane_slots[s] = a; }
+#endif
+ECG_HD Fp2 slot_load2(int s) { return Fp2{slot_load(s), slot_load(s + 1)}; }
+ECG_HD void slot_store2(int s, const Fp2& a) {
+    slot_store(s, a.c0);
+    slot_store(s + 1, a.c1);
+}
+// running point of Miller pair k: slots 6k .. 6k+5 = X, Y, Z
+ECG_HD J2 slot_load_point(int k) { return J2{slot_load2(6 * k), slot_load2(6 * k + 2), slot_load2(6 * k + 4)}; }
+ECG_HD void slot_store_point(int k, const J2& t) {
+    slot_store2(6 * k, t.x);
+    slot_store2(6 * k + 2, t.y);
+    slot_store2(6 * k + 4, t.z);
+}
+ECG_HD Fp12 slot_load_fp12() {
+    Fp12 r;
+    r.c0.c0 = slot_load2(0);
+    r.c0.c1 = slot_load2(2);
+    r.c0.c2 = slot_load2(4);
+    r.c1.c0 = slot_load2(6);
+    r.c1.c1 = slot_load2(8);
+    r.c1.c2 = slot_load2(10);
+    return r;
+}
+ECG_HD void slot_store_fp12(const Fp12& a) {
+    slot_store2(0, a.c0.c0);
+    slot_store2(2, a.c0.c1);
+    slot_store2(4, a.c0.c2);
+    slot_store2(6, a.c1.c0);
+    slot_store2(8, a.c1.c1);
+    slot_store2(10, a.c1.c2);
+}
+
 struct MillerPair {
     Fp px, py;  // P in E1 affine
+    Fp npx;     // 2p - px: the minus sign of the line's w^2 coefficient as a product operand
     Fp2 qx, qy; // Q in E2 affine
-    J2 t;       // running point
+    J2 t;       // running point: the caller's initial value; miller_loop keeps the live one in the lane slots
     u32 active; // 0: P or Q is infinity, the pair contributes 1
 };
 
@@ -24,6 +93,7 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
     m.active = (p.inf || q.inf) ? 0u : 1u;
     m.px = p.x;
     m.py = p.y;
+    m.npx = fp_neg_lazy<2>(p.x);
     m.qx = q.x;
     m.qy = q.y;
     m.t.x = q.x;
@@ -31,9 +101,10 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
     m.t.z = fp2_one();
 }
 
-// T <- 2T, f <- f * line_{T,T}(P)
-ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, MillerPair& m) {
-    const J2& T = m.t;
+#if defined(ECG_TOWER_CALLS)
+// T <- 2T, f <- f * line_{T,T}(P); T = running point of pair k (lane slots).  Textbook dbl-2009-l (compact-code tower).
+ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, const MillerPair& m, int k) {
+    const J2 T = slot_load_point(k);
     Fp2 A = fp2_sqrx(T.x);
     Fp2 B = fp2_sqrx(T.y);
     Fp2 C = fp2_sqrx(B);
@@ -47,15 +118,56 @@ ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, MillerPair& m) {
     Fp2 l2 = fp2_mul_fp(fp2_mulx(Z3, ZZ), m.py);
     Fp2 X3 = fp2_sub(Fq, fp2_dbl(D));
     Fp2 C8 = fp2_dbl(fp2_dbl(fp2_dbl(C)));
-    m.t.y = fp2_sub(fp2_mulx(E, fp2_sub(D, X3)), C8);
-    m.t.x = X3;
-    m.t.z = Z3;
-    fp12_mul_by_line(f, l0, l1, l2);
+    J2 R;
+    R.y = fp2_sub(fp2_mulx(E, fp2_sub(D, X3)), C8);
+    R.x = X3;
+    R.z = Z3;
+    slot_store_point(k, R);
+    fp12_mul_by_line<2>(f, l0, l1, l2);
 }
+#else
+// T <- 2T, f <- f * line_{T,T}(P); T = running point of pair k, read from the lane slots where it is used.
+// The dbl-2009-l quantities regrouped as in jac_dbl_inl (bls_curve.h) so that no modular addition touches a product:
+//   A = X^2, B = Y^2, ZZ = Z^2, E = 3A (lazy), D = (4X) B,
+//   X3 = E E + (8p - 4X)(2B),  Y3 = E (D - X3 + 2p) + (8p - 4B)(2B),  Z3 = (2Y) Z,
+//   line: l0 = E X + (4p - 2B) (a lazy sum: < 6p), l1 = (E ZZ)(2p - xP), l2 = (Z3 ZZ) yP
+// 3 squarings, 5 products, 2 sums of two products and 4 Fp products over lazy operands; the textbook form above costs 6
+// squarings, 5 products and 15 Fp2 modular additions / doublings (30 x ~105 instructions per step, 126 steps per check).
+ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, const MillerPair& m, int k) {
+    const int sx = 6 * k, sy = sx + 2, sz = sx + 4;
+    const Fp2 A = fp2_sqrx(slot_load2(sx));
+    const Fp2 E = fp2_add_lazy(fp2_add_lazy(A, A), A);  // < 6p
+    const Fp2 ZZ = fp2_sqrx(slot_load2(sz));
+    const Fp2 l1 = fp2_mul_fp(fp2_mulx(E, ZZ), m.npx);
+    Fp2 Z3;
+    {
+        const Fp2 Y = slot_load2(sy);
+        Z3 = fp2_mulx(fp2_add_lazy(Y, Y), slot_load2(sz));
+    }
+    slot_store2(sz, Z3);
+    const Fp2 l2 = fp2_mul_fp(fp2_mulx(Z3, ZZ), m.py);
+    const Fp2 B = fp2_sqrx(slot_load2(sy));
+    const Fp2 B2 = fp2_add_lazy(B, B);  // < 4p
+    const Fp2 l0 = fp2_add_lazy(fp2_mulx(E, slot_load2(sx)), f_neg_lazy<4>(B2));  // < 6p
+    Fp2 X3, Y3;
+    {
+        const Fp2 X = slot_load2(sx);
+        const Fp2 X2 = fp2_add_lazy(X, X), X4 = fp2_add_lazy(X2, X2);  // < 8p
+        const Fp2 D = fp2_mulx(X4, B);
+        const Fp2 B4 = fp2_add_lazy(B2, B2);  // < 8p
+        const Fp2 n4X = f_neg_lazy<8>(X4), n4B = f_neg_lazy<8>(B4);
+        X3 = f_sp2<6, 4>(E, E, n4X, B2);
+        Y3 = f_sp2<4, 4>(E, f_sub_lazy<2>(D, X3), n4B, B2);
+    }
+    slot_store2(sx, X3);
+    slot_store2(sy, Y3);
+    fp12_mul_by_line<6>(f, l0, l1, l2);
+}
+#endif
 
 // T <- T + Q, f <- f * line_{T,Q}(P)
-ECG_HD void miller_add_step_inl(Fp12& f, MillerPair& m) {
-    const J2& T = m.t;
+ECG_HD void miller_add_step_inl(Fp12& f, const MillerPair& m, int k) {
+    const J2 T = slot_load_point(k);
     Fp2 Z1Z1 = fp2_sqrx(T.z);
     Fp2 U2 = fp2_mulx(m.qx, Z1Z1);
     Fp2 S2 = fp2_mulx(fp2_mulx(m.qy, T.z), Z1Z1);
@@ -69,32 +181,26 @@ ECG_HD void miller_add_step_inl(Fp12& f, MillerPair& m) {
     Fp2 Y3 = fp2_sub(fp2_mulx(rr, fp2_sub(V, X3)), fp2_dbl(fp2_mulx(T.y, J)));
     Fp2 Z3 = fp2_sub(fp2_sub(fp2_sqrx(fp2_add(T.z, H)), Z1Z1), HH);
     Fp2 l0 = fp2_sub(fp2_mulx(rr, m.qx), fp2_mulx(m.qy, Z3));
-    Fp2 l1 = fp2_neg(fp2_mul_fp(rr, m.px));
+    Fp2 l1 = fp2_mul_fp(rr, m.npx);
     Fp2 l2 = fp2_mul_fp(Z3, m.py);
-    m.t.x = X3;
-    m.t.y = Y3;
-    m.t.z = Z3;
-    fp12_mul_by_line(f, l0, l1, l2);
-}
-// out of line (5 of the 68 iterations): accumulator and pair are locals of miller_loop
-ECG_FP12_FN void miller_add_step(Fp12& f, MillerPair& m) {
-    Fp12 x = ecg_priv_load(f);
-    MillerPair y = ecg_priv_load(m);
-    miller_add_step_inl(x, y);
-    ecg_priv_store(f, x);
-    ecg_priv_store(m, y);
+    slot_store_point(k, J2{X3, Y3, Z3});
+    fp12_mul_by_line<2>(f, l0, l1, l2);
 }
 
 // f = prod_k f_{|x|,Q_k}(P_k), conjugated (x < 0)
-// The accumulator is a local VALUE whose address never leaves this function (the five addition steps work on a copy):
-// it lives in VGPRs/AGPRs across the whole doubling iteration instead of making three round trips through the
-// private segment per bit.
+// The accumulator is a local VALUE whose address never leaves this function: it lives in VGPRs/AGPRs across the whole loop.
+// The five addition steps are inlined as well (round 2 ran them out of line on a copy): a copy of the accumulator to or
+// from the private segment is a merged dwordx4 access, and the register coalescer then keeps the accumulator's limbs in
+// 128-bit tuples for the WHOLE loop, which the allocator can only spill and reload four at a time (see common.h).  The
+// running points live in the lane slots (LDS), the fixed coordinates of the pairs in the private segment (read once per
+// step, long before their use).
 ECG_HD_NOINLINE void miller_loop(Fp12& f, MillerPair* pairs, int n) {
     bool any = false;
     MillerPair lp[2];  // n <= 2 (verify: 2 pairs; aggregate_verify: 1 per lane); private copies, see ecg_priv_load
     for (int k = 0; k < n && k < 2; k++) {
         lp[k] = ecg_priv_load(pairs[k]);
         any = any || lp[k].active;
+        slot_store_point(k, lp[k].t);
     }
     Fp12 acc;
     fp12_set_one(acc);
@@ -102,13 +208,11 @@ ECG_HD_NOINLINE void miller_loop(Fp12& f, MillerPair* pairs, int n) {
         for (int b = 62; b >= 0; b--) {
             if (b != 62) fp12_sqr(acc, acc);
             for (int k = 0; k < n; k++)
-                if (lp[k].active) miller_dbl_step(acc, lp[k]);
+                if (lp[k].active) miller_dbl_step(acc, lp[k], k);
             if ((blsc::X_ABS >> b) & 1)
                 for (int k = 0; k < n; k++)
                     if (lp[k].active) {
-                        Fp12 t = acc;
-                        miller_add_step(t, lp[k]);
-                        acc = t;
+                        miller_add_step_inl(acc, lp[k], k);
                     }
         }
         fp12_conj(acc, acc);
@@ -116,23 +220,48 @@ ECG_HD_NOINLINE void miller_loop(Fp12& f, MillerPair* pairs, int n) {
     ecg_priv_store(f, acc);
 }
 
+// r = a * (the Fp12 value in the lane slots): Karatsuba over three Fp6 products, the second operand read from LDS where it is
+// used.  r may alias a.
+ECG_HD Fp6 slot_load_fp6(int s) { return Fp6{slot_load2(s), slot_load2(s + 2), slot_load2(s + 4)}; }
+ECG_HD void fp12_mul_by_slots_inl(Fp12& r, const Fp12& a) {
+    Fp6 t0, t1, m;
+    {
+        const Fp6 b0 = slot_load_fp6(0);
+        fp6_mul(t0, a.c0, b0);
+    }
+    {
+        const Fp6 b1 = slot_load_fp6(6);
+        fp6_mul(t1, a.c1, b1);
+    }
+    {
+        const Fp6 b0 = slot_load_fp6(0), b1 = slot_load_fp6(6);
+        fp6_mul_sums(m, a.c0, a.c1, b0, b1);
+    }
+    fp12_karatsuba_combine(r.c0, r.c1, m, t0, t1);
+}
+
 // a^x for a in the cyclotomic subgroup (x < 0: conjugate)
 ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
-    // The running value is register-resident (the squaring is inlined, the five products work on a copy); the BASE is not: it
-    // is needed five times in 63 iterations, and 156 more live dwords under the squaring cost 64 reloads per iteration.  `a`
-    // may alias `r` (written only at the end); it is copied once so that the callee of the product never sees `r`'s storage.
-    Fp12 base_mem;
+    // The running value is register-resident (squaring and product are inlined) and never passes through memory inside the
+    // loop: a copy to or from the private segment is a merged dwordx4 access, the register coalescer then keeps the limbs
+    // in 128-bit tuples for the whole loop and the allocator spills and reloads them four at a time (round 2: 9 exposed
+    // reloads per squaring).  The BASE is needed five times in 63 iterations; it waits in the lane slots (LDS) -- 156 more
+    // live dwords under the squaring would come back as spills -- and the product reads it from there, coefficient by
+    // coefficient.  `a` may alias `r` (written only at the end).
     Fp12 acc = ecg_priv_load(a);
-    ecg_priv_store(base_mem, acc);
+    slot_store_fp12(acc);
     for (int b = 62; b >= 0; b--) {
         fp12_cyclotomic_sqr_inl(acc, acc);
         if ((blsc::X_ABS >> b) & 1) {
-            // (the product inlined here as well -- running value never leaves the registers, 5 k fewer private-segment
-            // instructions per pairing -- builds a kernel that does not terminate on the device, while the host build of the same
-            // source passes every test: not pursued, the out-of-line product stays)
-            Fp12 t = acc;
-            fp12_mul(t, t, base_mem);
+#if defined(ECG_POW_PRODUCT_CALL)
+            // round-2 form (the product out of line, the running value through the private segment), kept as a build switch:
+            // round 2 saw a kernel with the product inlined here that did not terminate on the device
+            Fp12 t = acc, base = slot_load_fp12();
+            fp12_mul(t, t, base);
             acc = t;
+#else
+            fp12_mul_by_slots_inl(acc, acc);
+#endif
         }
     }
     fp12_conj(acc, acc);

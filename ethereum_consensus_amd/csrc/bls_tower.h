@@ -241,7 +241,9 @@ ECG_HD void fp6_mul_by_01_sums(Fp6& r, const Fp6& f0, const Fp6& f1, const Fp2& 
     r.c1 = mid;
     r.c2 = fp2_add(t1, s2a);
 }
+template <int K0>
 ECG_MILLER_DBL_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+    static_assert(K0 <= 2, "Karatsuba form: reduced line coefficients");
     Fp6 aa, bb, m;
     fp6_mul_by_01(aa, f.c0, l0, l1);
     fp6_mul_by_1(bb, f.c1, l2);
@@ -254,11 +256,14 @@ ECG_MILLER_DBL_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, c
 //   c0: a0 l0 + xi a2 l1 + xi b1 l2 | a0 l1 + a1 l0 + xi b2 l2 | a1 l1 + a2 l0 + b0 l2
 //   c1: xi a2 l2 + b0 l0 + xi b2 l1 | a0 l2 + b0 l1 + b1 l0    | a1 l2 + b1 l1 + b2 l0
 // 72 half-products, 12 reductions, no recombination (the Karatsuba form needs 60 + 18 and 20 modular additions).
-// Components of f and l < 2p; xi-multiples < 4p: a sum is below 6 * 4p * 2p = 48 p^2.
+// Components of f, l1, l2 < 2p, of l0 < K0 p (the doubling step hands in a lazy sum < 6p); xi-multiples < 4p: a sum is
+// below 2 * 4p * K0 p + 4 * 4p * 2p <= 80 p^2.
+template <int K0>
 ECG_MILLER_DBL_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+    static_assert(8 * K0 + 32 < 632, "sum of products would not reduce below 2p");
     const Fp2 a0 = f.c0.c0, a1 = f.c0.c1, a2 = f.c0.c2, b0 = f.c1.c0, b1 = f.c1.c1, b2 = f.c1.c2;
     const Fp2 xa2 = fp2_mul_xi_lazy<2>(a2), xb1 = fp2_mul_xi_lazy<2>(b1), xb2 = fp2_mul_xi_lazy<2>(b2);
-    const Fp n0 = fp_neg_lazy<2>(l0.c1), n1 = fp_neg_lazy<2>(l1.c1), n2 = fp_neg_lazy<2>(l2.c1);
+    const Fp n0 = fp_neg_lazy<K0>(l0.c1), n1 = fp_neg_lazy<2>(l1.c1), n2 = fp_neg_lazy<2>(l2.c1);
     const Fp2 y[3] = {l0, l1, l2};
     const Fp ny[3] = {n0, n1, n2};
     const Fp2 y120[3] = {l1, l0, l2};

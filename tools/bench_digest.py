@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""One-screen digest of a bench.py JSON line (development aid for GPU visits)."""
+import json
+import sys
+
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = d.get("roofline", {})
+print("step %.2f ms  %.0f %s  kernel %s %.2f ms  check %s" % (d["ms_per_step"], d["value"], d["unit"], r.get("kernel"), r.get("avg_launch_ms") or 0, d.get("check")))
+if "stage_ms" in r:
+    print("  stages", {k: round(v, 2) for k, v in r["stage_ms"].items()}, "T mult/s", {k: round(v, 1) for k, v in r["valu_int"]["achieved"].items()})
+for key in ("aggregates_k2048", "merkle", "epoch", "slots", "strong_2p20"):
+    if key in d:
+        e = d[key]
+        print("  %s: %.3f ms/step  %.4g %s  check %s" % (key, e.get("ms_per_step", 0), e.get("value", 0), e.get("unit"), e.get("check")))
+if "block" in d:
+    print("  block", round(d["block"]["reference_semantics"]["block_verify_ms"], 2), round(d["block"]["validated_key_registry"]["block_verify_ms"], 2))
+if "box_selfcheck" in d:
+    print("  box slowdown", round(d["box_selfcheck"]["large_code_slowdown"], 2), d["box_selfcheck"]["pairing_kernels"])
+if "cpu_baseline" in d:
+    c = d["cpu_baseline"]
+    print("  cpu", round(c["value"]), c["unit"], "cores", c.get("cores"), c.get("cores_effective"))

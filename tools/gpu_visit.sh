@@ -1,0 +1,49 @@
+#!/bin/bash
+# One GPU visit, parametrised: tools/gpu_visit.sh <tag> <step> [<step> ...]   (run through gpurun from the repo root)
+#   tests            whole `pytest -m gpu` suite                     -> gpurun_out/<tag>_gpu_tests.txt
+#   tests:<expr>     pytest -m gpu -k <expr>
+#   bench            the driver's command (python bench.py)          -> gpurun_out/<tag>_bench.json
+#   bench:<args>     python bench.py <args> (underscores for spaces) -> gpurun_out/<tag>_bench_<args>.json
+#   probe[:sizes]    tools/bls_probe.py stage timing                 -> gpurun_out/<tag>_probe.txt
+#   stats            rocprofv3 --kernel-trace --stats of the bench   -> gpurun_out/<tag>_kernel_stats.txt
+#   pmc              FETCH_SIZE / WRITE_SIZE passes of the bench     -> gpurun_out/<tag>_pmc_{fetch,write}.txt
+#   lib:<name>       following steps use lib/libecgpu_<name>.so (tools/build_variant.sh); lib: alone switches back
+#   env:<K=V>        export K=V for the following steps (unenv:<K> removes it)
+#   to:<seconds>     timeout of the following probe steps
+#   py:<script>      python <script> (under tools/)                  -> gpurun_out/<tag>_<script>.txt
+cd "$(dirname "$0")/.."; export TMPDIR=/tmp
+mkdir -p gpurun_out
+tag=$1; shift
+sfx=""; TO=900
+for step in "$@"; do
+  case "$step" in
+    to:*) TO=${step#to:};;
+    unenv:*) unset "${step#unenv:}"; sfx="";;
+    lib:*) n=${step#lib:}; if [ -z "$n" ]; then unset ECGPU_LIB; sfx=""; else export ECGPU_LIB=$PWD/ethereum_consensus_amd/lib/libecgpu_$n.so; sfx="_$n"; fi;;
+    env:*) export "${step#env:}"; sfx="${sfx}_$(echo ${step#env:} | tr -c 'A-Za-z0-9=' '_')";;
+    tests) timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/${tag}${sfx}_gpu_tests.txt;;
+    tests:*) timeout 2400 python -m pytest tests -m gpu -x -q -k "${step#tests:}" 2>&1 | tail -6 | tee gpurun_out/${tag}${sfx}_gpu_tests_k.txt;;
+    bench) timeout 900 python bench.py > gpurun_out/${tag}${sfx}_bench.json 2> gpurun_out/${tag}${sfx}_bench_err.txt; tail -c 600 gpurun_out/${tag}${sfx}_bench_err.txt
+           python tools/bench_digest.py gpurun_out/${tag}${sfx}_bench.json;;
+    bench:*) a=${step#bench:}; timeout 900 python bench.py ${a//_/ } > gpurun_out/${tag}${sfx}_bench_${a//[^A-Za-z0-9]/}.json 2> gpurun_out/${tag}${sfx}_bench_err.txt
+           tail -c 600 gpurun_out/${tag}${sfx}_bench_err.txt; python tools/bench_digest.py gpurun_out/${tag}${sfx}_bench_${a//[^A-Za-z0-9]/}.json;;
+    probe) timeout $TO python tools/bls_probe.py 65536 2>&1 | tee gpurun_out/${tag}${sfx}_probe.txt;;
+    probe:*) s=${step#probe:}; timeout $TO python tools/bls_probe.py ${s//,/ } 2>&1 | tee gpurun_out/${tag}${sfx}_probe.txt;;
+    stats) timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o $tag -- python bench.py --no-cpu-baseline > gpurun_out/${tag}${sfx}_stats.log 2>&1
+           DB=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
+           [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" gpurun_out/${tag}${sfx}_kernel_stats.txt && head -14 gpurun_out/${tag}${sfx}_kernel_stats.txt | cut -c1-70,100-200
+           rm -rf gpurun_out/prof_$tag;;
+    pmc) for c in FETCH_SIZE WRITE_SIZE; do
+           timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-aggregates --workload bls > gpurun_out/${tag}${sfx}_pmc_$c.log 2>&1
+           python tools/pmc_summary.py gpurun_out/pmc_${tag}_$c gpurun_out/${tag}${sfx}_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_pmc_$c.txt | cut -c1-160
+           rm -rf gpurun_out/pmc_${tag}_$c
+         done;;
+    pmc_merkle) for c in FETCH_SIZE WRITE_SIZE; do
+           timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_m_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload merkle > gpurun_out/${tag}${sfx}_merkle_pmc_$c.log 2>&1
+           python tools/pmc_summary.py gpurun_out/pmc_${tag}_m_$c gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt | cut -c1-160
+           rm -rf gpurun_out/pmc_${tag}_m_$c
+         done;;
+    py:*) s=${step#py:}; timeout 900 python tools/${s//_/ } 2>&1 | tee gpurun_out/${tag}${sfx}_$(echo $s | tr -c 'A-Za-z0-9' '_').txt | tail -40;;
+    *) echo "unknown step $step";;
+  esac
+done
