@@ -1,14 +1,18 @@
 #!/usr/bin/env python
 """bench.py -- the two hot paths on MI355X, one JSON line (contract: see README / DESIGN.md).
 
-    python bench.py --gpus N --steps K --warmup W [--workload bls|merkle]
+    python bench.py --gpus N --steps K --warmup W [--workload bls|merkle|epoch|slots] [--tuples T --scaling strong]
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
   bls    : fast_aggregate_verify of 65 536 (pk, msg, sig) tuples  (BASELINE.json configs[1])
   merkle : hash_tree_root(BeaconState), deneb mainnet, 2^20 validators (configs[2])
+  epoch  : 32 slots x 64 committees x 2 048 keys (configs[3]);  slots: sync aggregate + state root per slot (configs[4])
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank processes its own shard
 of the same size (weak scaling); the only collective is the RCCL all-gather of the per-shard
-verify status bytes (bls) / of the 32-byte roots (merkle).
+verify status bytes (bls) / of the 32-byte roots (merkle).  `--tuples 1048576 --scaling strong` is north_star's
+2^20-signature batch: the total is fixed and rank g verifies shard_range(2^20, g, N).
+The default line (N = 1, no flags) carries every configuration as a sub-record: "merkle", "aggregates_k2048", "block",
+"strong_2p20", "epoch", "slots".
 """
 from __future__ import annotations
 
@@ -26,6 +30,45 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s, 6.29 measur
 # Measured ALU ceilings of the two paths' inner loops on MI355X (tools/fpbench.hip, register-resident chains at 8 waves/SIMD):
 HASH64_PEAK_GHS = 17.66    # profiles/r01h_hash64_rate_vs_occupancy.txt: 2410 VALU instructions per hash64 at ~3.7 cycles each
 MUL_PIPE_PEAK_TOPS = 31.0  # profiles/r01a_int_issue_rate_microbench.txt: v_mad_u64_u32 issue rate (fp_mul sustains 28 T, r01f)
+
+
+# The N-rank control flow below (finish, gather_selfcheck, run_epoch, run_bls) is device-agnostic on purpose: tests/
+# test_dist_gloo.py drives it on CPU tensors under gloo with a stub library (the oracle standing in for the kernels), so the
+# only multi-GPU lines left untested without hardware are the RCCL calls themselves.
+DEV = "cuda"
+
+
+def _sync(torch):
+    if DEV == "cuda":
+        torch.cuda.synchronize()
+
+
+def _stream(torch):
+    return torch.cuda.current_stream().cuda_stream if DEV == "cuda" else 0
+
+
+def _device(torch):
+    return torch.device("cuda", torch.cuda.current_device()) if DEV == "cuda" else torch.device("cpu")
+
+
+def effective_cores():
+    """Host parallelism this process is actually granted: the affinity mask capped by the cgroup CPU quota (os.cpu_count()
+    is the machine's, not ours: the GPU box reports 256 hardware threads and grants about ten)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return {"affinity": aff, "cgroup_quota_cores": quota, "cores_effective": aff if quota is None else min(aff, max(1, int(quota + 0.5)))}
 
 
 def pmc_traffic(kernel_key: str):
@@ -52,13 +95,16 @@ def parse():
     ap.add_argument("--workload", default=os.environ.get("ECGPU_BENCH_WORKLOAD", "auto"))
     ap.add_argument("--validators", type=int, default=1 << 20)
     ap.add_argument("--tuples", type=int, default=65536)
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="bls workload with N ranks: weak = --tuples per rank, strong = --tuples in all (rank g takes shard_range)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the strong_2p20 / epoch / slots sub-records of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aggregates", action="store_true", help="skip the secondary K = 2048 aggregates line")
     return ap.parse_args()
 
 
 def cpu_baseline_merkle(n_validators: int):
-    """oracle/c restatement (SHA-NI when the host has it) on one host core: htr(List<Validator>)
+    """oracle/c restatement (SHA-NI when the host has it) on 1 and on 8 host threads: htr(List<Validator>)
     of the same registry -- 93 % of the state's hash64.  Reported, never the target."""
     from oracle import cref
     from ethereum_consensus_amd import synthetic as S
@@ -67,15 +113,28 @@ def cpu_baseline_merkle(n_validators: int):
     hashes = 0
     t_total = time.time()
     reps = 0
-    while reps < 3 or (time.time() - t_total < 10 and reps < 12):
+    while reps < 3 or (time.time() - t_total < 6 and reps < 8):
         t = time.time()
-        _, hashes = cref.htr_validators(enc)
+        root1, hashes = cref.htr_validators(enc)
         dt = time.time() - t
         best = dt if best is None else min(best, dt)
         reps += 1
-    return {"value": hashes / best, "unit": "leaves/s", "cores": 1, "kind": "port",
+    best8, reps8 = None, 0
+    t_total = time.time()
+    while reps8 < 3 or (time.time() - t_total < 4 and reps8 < 8):
+        t = time.time()
+        root8, _ = cref.htr_validators_threads(enc, 8)
+        dt = time.time() - t
+        best8 = dt if best8 is None else min(best8, dt)
+        reps8 += 1
+    assert root8 == root1, "threaded C restatement disagrees with the single-thread root"
+    eff = effective_cores()
+    return {"value": hashes / best8, "unit": "leaves/s", "cores": 8, "cores_effective": min(8, eff["cores_effective"]), "kind": "port",
+            "host": eff, "measured_parallel_speedup": best / best8,
+            "one_thread": {"value": hashes / best, "unit": "leaves/s", "cores": 1, "sample": f"best of {reps}"},
             "sample": f"htr(List<Validator,2^40>) of the same {n_validators} validators ({hashes} hash64), "
-                      f"oracle/c/sha256_merkle.c, sha_ni={int(cref.lib().oc_have_shani())}, best of {reps}"}
+                      f"oracle/c/sha256_merkle.c, sha_ni={int(cref.lib().oc_have_shani())}: 8 threads (aligned subtrees, best of {reps8}) "
+                      f"and 1 thread (best of {reps})"}
 
 
 def run_merkle(args, L, torch, dist, rank, world):
@@ -215,7 +274,13 @@ def cpu_baseline_bls(sample, budget_s: float = 20.0):
     st = cbls.fast_aggregate_verify_batch_k1(pks[:48 * m], msgs[:32 * m], sigs[:96 * m], nthr)
     dt_n = time.time() - t0
     assert st == want[:m], "C++ restatement disagrees with the statuses known by construction"
-    return {"value": m / dt_n, "unit": "sigs/s", "cores": nthr, "kind": "port",
+    eff = effective_cores()
+    speedup = (m / dt_n) / rate1
+    # the threads used are the affinity mask's; what the box GRANTS is the cgroup quota, and where that is not readable the
+    # measured speed-up over one thread says it (round 2 printed "cores": 256 beside an 8.9x speed-up)
+    granted = eff["cores_effective"] if eff["cgroup_quota_cores"] is not None else min(eff["affinity"], max(1, int(speedup + 0.999)))
+    return {"value": m / dt_n, "unit": "sigs/s", "cores": nthr, "cores_effective": granted, "host": eff,
+            "measured_parallel_speedup": speedup, "kind": "port",
             "one_thread": {"value": rate1, "unit": "sigs/s", "cores": 1, "sample": f"first {m1} tuples in {dt_1:.1f} s"},
             "eight_threads": {"value": m8 / dt_8, "unit": "sigs/s", "cores": 8, "sample": f"first {m8} tuples in {dt_8:.1f} s"},
             "sample": f"first {m} K = 1 tuples of the same workload (fault cycle included, statuses equal to construction) in {dt_n:.1f} s on "
@@ -223,55 +288,67 @@ def cpu_baseline_bls(sample, budget_s: float = 20.0):
                       "(blst itself is not available offline: ~1.2-1.5 k/s per core published)"}
 
 
-def run_bls(args, L, torch, dist, rank, world):
-    n = args.tuples
-    dev = torch.device("cuda", torch.cuda.current_device())
-    sks, msgs = bls_inputs(n, rank * n)
-    d_sk = torch.frombuffer(bytearray(sks), dtype=torch.uint8).to(dev)
-    msgs = bytearray(msgs)
-    stream = torch.cuda.current_stream().cuda_stream
-    d_pk = torch.empty(48 * n, dtype=torch.uint8, device=dev)
-    d_sig = torch.empty(96 * n, dtype=torch.uint8, device=dev)
-    d_msg_clean = torch.frombuffer(bytearray(msgs), dtype=torch.uint8).to(dev)
-    # workload generation on the device (SecretKey::public_key / sign, crypto/bls.rs:193-219); untimed
-    assert L.ecgpu_sk_to_pk_batch_dev(d_sk.data_ptr(), n, d_pk.data_ptr(), stream) == 0
-    assert L.ecgpu_sign_batch_dev(d_sk.data_ptr(), 32, d_msg_clean.data_ptr(), n, d_sig.data_ptr(), stream) == 0
-    # fault injection of SURVEY.md 8(d) config 2: tuple i = 0 (mod 64) is corrupted, cycling through eight fault classes
-    # (wrong message, swapped key, signature outside G2, key outside G1, bad flag bits, x >= p, key = infinity, signature =
-    # infinity); the expected status of every tuple is known by construction
-    from ethereum_consensus_amd import synthetic as syn
-    torch.cuda.synchronize()
-    h_pk = bytearray(d_pk.cpu().numpy().tobytes())
-    h_sig = bytearray(d_sig.cpu().numpy().tobytes())
-    want_bytes, _kinds = syn.bls_inject_faults(h_pk, msgs, h_sig, n)
-    d_pk = torch.frombuffer(h_pk, dtype=torch.uint8).to(dev)
-    d_sig = torch.frombuffer(h_sig, dtype=torch.uint8).to(dev)
-    d_msg = torch.frombuffer(msgs, dtype=torch.uint8).to(dev)
-    d_st = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)
+def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
+    """K = 1 tuples.  weak scaling (default): every rank verifies `--tuples` tuples of its own.  strong (`--scaling strong`,
+    north_star's 2^20-signature batch): `--tuples` in all, rank g verifies shard_range(total, g, N) -- ragged shards, one
+    all-gather of the status bytes per step either way."""
     from ethereum_consensus_amd import shard
-    torch.cuda.synchronize()
+    strong = (args.scaling == "strong") if strong is None else strong
+    total = args.tuples if n_total is None else n_total
+    if strong:
+        lo, hi = shard.shard_range(total, rank, world)
+    else:
+        lo, hi = rank * total, (rank + 1) * total
+    n = hi - lo
+    dev = _device(torch)
+    sks, msgs = bls_inputs(n, lo)
+    d_sk = torch.frombuffer(bytearray(sks or b"\0"), dtype=torch.uint8).to(dev)
+    msgs = bytearray(msgs)
+    stream = _stream(torch)
+    d_pk = torch.empty(max(48 * n, 1), dtype=torch.uint8, device=dev)
+    d_sig = torch.empty(max(96 * n, 1), dtype=torch.uint8, device=dev)
+    d_msg_clean = torch.frombuffer(bytearray(msgs or b"\0"), dtype=torch.uint8).to(dev)
+    # workload generation on the device (SecretKey::public_key / sign, crypto/bls.rs:193-219); untimed
+    if n:
+        assert L.ecgpu_sk_to_pk_batch_dev(d_sk.data_ptr(), n, d_pk.data_ptr(), stream) == 0
+        assert L.ecgpu_sign_batch_dev(d_sk.data_ptr(), 32, d_msg_clean.data_ptr(), n, d_sig.data_ptr(), stream) == 0
+    # fault injection of SURVEY.md 8(d) config 2: tuple i = 0 (mod 64) of the shard is corrupted, cycling through eight fault
+    # classes (wrong message, swapped key, signature outside G2, key outside G1, bad flag bits, x >= p, key = infinity,
+    # signature = infinity); the expected status of every tuple is known by construction
+    from ethereum_consensus_amd import synthetic as syn
+    _sync(torch)
+    h_pk = bytearray(d_pk.cpu().numpy().tobytes()[:48 * n])
+    h_sig = bytearray(d_sig.cpu().numpy().tobytes()[:96 * n])
+    want_bytes, _kinds = syn.bls_inject_faults(h_pk, msgs, h_sig, n)
+    d_pk = torch.frombuffer(h_pk or bytearray(1), dtype=torch.uint8).to(dev)
+    d_sig = torch.frombuffer(h_sig or bytearray(1), dtype=torch.uint8).to(dev)
+    d_msg = torch.frombuffer(msgs or bytearray(1), dtype=torch.uint8).to(dev)
+    d_st = torch.full((max(n, 1),), 0xFF, dtype=torch.uint8, device=dev)
+    _sync(torch)
+    gathered = {}
 
     def step():
-        rc = L.ecgpu_fast_aggregate_verify_batch_dev(d_pk.data_ptr(), None, n, d_msg.data_ptr(), d_sig.data_ptr(), n, 0,
-                                                     d_st.data_ptr(), stream)
-        if rc != 0:
-            raise RuntimeError(f"ecgpu_fast_aggregate_verify_batch_dev -> {rc}: {L.ecgpu_last_error()}")
+        if n:
+            rc = L.ecgpu_fast_aggregate_verify_batch_dev(d_pk.data_ptr(), None, n, d_msg.data_ptr(), d_sig.data_ptr(), n, 0,
+                                                         d_st.data_ptr(), stream)
+            if rc != 0:
+                raise RuntimeError(f"ecgpu_fast_aggregate_verify_batch_dev -> {rc}: {L.ecgpu_last_error()}")
         if world > 1:
             # the path's only collective: every rank learns every shard's verify statuses
-            shard.all_gather_bytes(dist, d_st, world)
+            gathered["st"] = shard.all_gather_ragged(dist, d_st[:n], total, world) if strong else shard.all_gather_bytes(dist, d_st, world)
 
     for _ in range(max(args.warmup, 1)):
         step()
-    torch.cuda.synchronize()
+    _sync(torch)
     L.ecgpu_prof_filter(None)
     L.ecgpu_prof_enable(1)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync(torch)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    _sync(torch)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -288,10 +365,14 @@ def run_bls(args, L, torch, dist, rank, world):
         ms, cnt = _prof(L, tag)
         stages[tag] = ms / max(cnt, 1)
     L.ecgpu_prof_enable(0)
-    st = d_st.cpu().numpy()
+    st = d_st[:n].cpu().numpy()
     import numpy as np
     want = np.frombuffer(bytes(want_bytes), dtype=np.uint8)
     ok = bool((st == want).all())
+    if world > 1 and strong:
+        # every rank holds the whole job's statuses after the gather: its own shard sits where shard_range puts it
+        full = gathered["st"].cpu().numpy()
+        ok = ok and full.shape[0] == total and bool((full[lo:hi] == want).all())
     dom = max(stages, key=lambda k: stages[k])
     kern_ms = stages[dom]
     alg_bytes = BLS_BYTES_PER_SIG * n
@@ -306,14 +387,17 @@ def run_bls(args, L, torch, dist, rank, world):
     m_cpu = min(n, 16384)
     return dict(
         host_sample=(bytes(h_pk[:48 * m_cpu]), bytes(msgs[:32 * m_cpu]), bytes(h_sig[:96 * m_cpu]), bytes(want_bytes[:m_cpu])),
-        dt=dt, units_per_step=n, metric="bls_signatures_verified_per_sec", unit="sigs/s", dtype="u32",
-        config={"workload": f"fast_aggregate_verify of {n} synthetic (pk, msg, sig) tuples, K = 1, 32-byte messages, "
+        dt=dt, units_per_step=(total / world) if strong else n, metric="bls_signatures_verified_per_sec", unit="sigs/s", dtype="u32",
+        scaling="strong" if strong else "weak",
+        config={"workload": f"fast_aggregate_verify of {total if strong else n} synthetic (pk, msg, sig) tuples{' in all' if strong else ''}, K = 1, 32-byte messages, "
                             "1/64 tuples corrupted, cycling through 8 fault classes (wrong message, swapped key, signature outside G2, key "
                             "outside G1, bad flags, x >= p, key = infinity, signature = infinity); compressed keys/messages/signatures "
                             "resident in HBM",
-                "tuples": n, "semantics": "reference: every key decompressed + subgroup-checked, every signature "
-                                          "decompressed + subgroup-checked, every message hashed to G2, per-tuple pairing check",
-                "sharding": "one independent batch per GPU; all-gather of the status bytes every step"},
+                "tuples": total if strong else n, "tuples_this_rank": n,
+                "semantics": "reference: every key decompressed + subgroup-checked, every signature "
+                             "decompressed + subgroup-checked, every message hashed to G2, per-tuple pairing check",
+                "sharding": ("strong scaling: the batch is fixed, rank g verifies shard_range(total, g, N); ragged all-gather of the status "
+                             "bytes every step") if strong else "one independent batch per GPU; all-gather of the status bytes every step"},
         roofline={"bound": "hbm", "kernel": pairing_kernel, "kernel_build": "sum-of-products lane groups (vm3)" if path == 3 else {1: "sums of products", 2: "compact-code tower"}.get(build, "?"),
                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"), "traffic_detail": traffic,
@@ -406,7 +490,7 @@ def run_bls_aggregate(args, L, torch, dist, rank, world, n_agg=256, k=2048):
             "check": {"statuses_match_construction": ok}}
 
 
-def run_epoch(args, L, torch, dist, rank, world, n_total=2048, k=2048):
+def run_epoch(args, L, torch, dist, rank, world, n_total=2048, k=2048, n_reg=1 << 20, sk_period=1 << 16):
     """BASELINE.json configs[3]: a full epoch of attestation aggregates -- 32 slots x 64 committees = 2 048 aggregates of
     K = 2 048 keys -- sharded over the ranks (contiguous committee ranges), statuses all-gathered every step.
     Registry = validators 0 .. 2^20 - 1; committee c, member j = validator (2048 c + j) mod 2^20 (the
@@ -415,25 +499,25 @@ def run_epoch(args, L, torch, dist, rank, world, n_total=2048, k=2048):
     decompressed + subgroup-checked on every call) and the validated-key registry.  Total work is fixed: strong scaling."""
     import numpy as np
     from ethereum_consensus_amd import shard
-    dev = torch.device("cuda", torch.cuda.current_device())
-    stream = torch.cuda.current_stream().cuda_stream
-    n_reg = 1 << 20
+    dev = _device(torch)
+    stream = _stream(torch)
     per = (n_total + world - 1) // world
     c0, c1 = min(rank * per, n_total), min((rank + 1) * per, n_total)
     n_agg = c1 - c0
     # the registry's secret keys repeat with period 2^16 (sk_i = sk_(i mod 65536)): 2^20 distinct SHA-derived keys would cost
     # a minute of host hashing per rank; the kernels see 2^20 separately stored, separately validated keys either way
-    sk_small = bls_inputs(1 << 16, 0)[0]
+    assert n_reg % sk_period == 0
+    sk_small = bls_inputs(sk_period, 0)[0]
     d_sk = torch.frombuffer(bytearray(sk_small), dtype=torch.uint8).to(dev)
-    d_pk_small = torch.empty(48 << 16, dtype=torch.uint8, device=dev)
-    assert L.ecgpu_sk_to_pk_batch_dev(d_sk.data_ptr(), 1 << 16, d_pk_small.data_ptr(), stream) == 0
-    d_reg_keys = d_pk_small.view(1 << 16, 48).repeat(n_reg >> 16, 1).contiguous().view(-1)
-    sk_int = [int.from_bytes(sk_small[32 * i:32 * i + 32], "big") for i in range(1 << 16)]
+    d_pk_small = torch.empty(48 * sk_period, dtype=torch.uint8, device=dev)
+    assert L.ecgpu_sk_to_pk_batch_dev(d_sk.data_ptr(), sk_period, d_pk_small.data_ptr(), stream) == 0
+    d_reg_keys = d_pk_small.view(sk_period, 48).repeat(n_reg // sk_period, 1).contiguous().view(-1)
+    sk_int = [int.from_bytes(sk_small[32 * i:32 * i + 32], "big") for i in range(sk_period)]
     # committee c covers validators [2048 c, 2048 c + 2048) mod 2^20: its keys are contiguous in the registry
     agg_sk, msgs = [], bytearray()
     for c in range(c0, c1):
         base = (k * c) % n_reg
-        agg_sk.append(sum(sk_int[(base + j) & 0xFFFF] for j in range(k)) % R_ORDER)
+        agg_sk.append(sum(sk_int[(base + j) % sk_period] for j in range(k)) % R_ORDER)
         msgs += S(b"att", c)
     idx = np.concatenate([(np.arange(k, dtype=np.int64) + (k * c) % n_reg) % n_reg for c in range(c0, c1)]).astype(np.uint32) \
         if n_agg else np.zeros(0, dtype=np.uint32)
@@ -444,7 +528,7 @@ def run_epoch(args, L, torch, dist, rank, world, n_total=2048, k=2048):
             if (c // 64) % 2 == 0:
                 msgs[32 * a] ^= 1          # wrong message
             else:
-                idx[a * k + 7] = (int(idx[a * k + 7]) + 1) % n_reg  # one wrong member (its neighbour's key is not the same: period 2^16)
+                idx[a * k + min(7, k - 1)] = (int(idx[a * k + min(7, k - 1)]) + 1) % n_reg  # one wrong member (its neighbour's key differs: period sk_period)
     d_idx = torch.from_numpy(idx.astype(np.int32)).to(dev)
     d_ask = torch.frombuffer(bytearray(b"".join(x.to_bytes(32, "big") for x in agg_sk) or b"\0"), dtype=torch.uint8).to(dev)
     d_msg_clean = torch.frombuffer(bytearray(b"".join(S(b"att", c) for c in range(c0, c1)) or b"\0"), dtype=torch.uint8).to(dev)
@@ -459,7 +543,7 @@ def run_epoch(args, L, torch, dist, rank, world, n_total=2048, k=2048):
     reg = ctypes.c_void_p()
     assert L.ecgpu_registry_create(n_reg, ctypes.byref(reg)) == 0
     assert L.ecgpu_registry_set_dev(reg, 0, d_reg_keys.data_ptr(), n_reg, stream) == 0
-    torch.cuda.synchronize()
+    _sync(torch)
     gathered = {}
 
     def make_step(use_registry):
@@ -482,21 +566,26 @@ def run_epoch(args, L, torch, dist, rank, world, n_total=2048, k=2048):
         step = make_step(use_registry)
         for _ in range(max(args.warmup, 1)):
             step()
-        torch.cuda.synchronize()
+        _sync(torch)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(torch)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize()
+        _sync(torch)
         if world > 1:
             dist.barrier()
-        out[name] = {"dt": time.perf_counter() - t0, "ok": bool((d_st[:n_agg].cpu().numpy() == want).all())}
+        ok_here = bool((d_st[:n_agg].cpu().numpy() == want).all())
+        if world > 1:
+            # after the gather every rank holds the whole epoch's statuses, rank r's at [r per, r per + its count)
+            full = gathered["st"].cpu().numpy()
+            ok_here = ok_here and full.shape[0] == per * world and bool((full[rank * per:rank * per + n_agg] == want).all())
+        out[name] = {"dt": time.perf_counter() - t0, "ok": ok_here}
     L.ecgpu_registry_destroy(reg)
     ok = out["reference_semantics"]["ok"] and out["validated_key_registry"]["ok"]
     if world > 1:
-        t = torch.tensor([1.0 if ok else 0.0, out["validated_key_registry"]["dt"]], dtype=torch.float64, device="cuda")
+        t = torch.tensor([1.0 if ok else 0.0, out["validated_key_registry"]["dt"]], dtype=torch.float64, device=DEV)
         dist.all_reduce(t[:1], op=dist.ReduceOp.MIN)
         dist.all_reduce(t[1:], op=dist.ReduceOp.MAX)
         ok, out["validated_key_registry"]["dt"] = bool(t[0].item() > 0.5), float(t[1].item())
@@ -692,6 +781,45 @@ def _prof(L, tag):
 
 
 
+def finish(r, args, world, dist, torch):
+    """max-over-ranks wall time of the K timed steps -> the fields of one metric"""
+    dt = r["dt"]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=DEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    steps = r.get("steps", args.steps)
+    total_units = r["units_per_step"] * steps * world
+    out = {"metric": r["metric"], "value": total_units / dt, "unit": r["unit"], "n_gpus": world,
+           "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
+           "higher_is_better": True, "scaling": r.get("scaling", "weak"), "vs_baseline": None, "dtype": r["dtype"],
+           "data": "synthetic", "config": r["config"], "roofline": r["roofline"], "check": r.get("check")}
+    out.update(r.get("extra", {}))
+    return out
+
+
+def gather_selfcheck(mine, world, dist, torch):
+    """every rank's (large-code slowdown, pairing build): with N > 1 the slowest rank sets the step time, so the line carries all"""
+    per_rank = [mine]
+    if world > 1:
+        try:
+            t = torch.tensor(mine, dtype=torch.float64, device=DEV)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            per_rank = [p.cpu().tolist() for p in parts]
+        except Exception:  # noqa: BLE001 - a failed diagnostic must not cost the measurement
+            per_rank = [mine]
+    return per_rank
+
+
+def sub_record(line, keys=("metric", "value", "unit", "ms_per_step", "steps", "scaling", "dtype", "config", "roofline", "check")):
+    out = {k: line[k] for k in keys if k in line}
+    for k in ("validated_key_registry", "aggregates_per_s"):
+        if k in line:
+            out[k] = line[k]
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -718,33 +846,17 @@ def main():
     if workload not in ("bls", "merkle", "both", "epoch", "slots"):
         raise SystemExit("unknown workload " + workload)
 
-    def finish(r):
-        """max-over-ranks wall time of the K timed steps -> the fields of one metric"""
-        dt = r["dt"]
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        steps = r.get("steps", args.steps)
-        total_units = r["units_per_step"] * steps * world
-        out = {"metric": r["metric"], "value": total_units / dt, "unit": r["unit"], "n_gpus": world,
-               "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
-               "higher_is_better": True, "scaling": r.get("scaling", "weak"), "vs_baseline": None, "dtype": r["dtype"],
-               "data": "synthetic", "config": r["config"], "roofline": r["roofline"], "check": r.get("check")}
-        out.update(r.get("extra", {}))
-        return out
-
     # BASELINE.json's metric has two halves.  The line's top level is the BLS half on configs[1]
     # (65 536 tuples); the Merkle half on configs[2] (2^20-validator state root) is timed the same way
     # right after it and reported, complete with its own roofline, under "merkle".
     line = None
     if workload == "epoch":
-        line = finish(run_epoch(args, L, torch, dist, rank, world))
+        line = finish(run_epoch(args, L, torch, dist, rank, world), args, world, dist, torch)
     if workload == "slots":
-        line = finish(run_slots(args, L, torch, dist, rank, world))
+        line = finish(run_slots(args, L, torch, dist, rank, world), args, world, dist, torch)
     if workload in ("bls", "both"):
         r_bls = run_bls(args, L, torch, dist, rank, world)
-        line = finish(r_bls)
+        line = finish(r_bls, args, world, dist, torch)
         if world == 1 and not args.no_aggregates:
             line["aggregates_k2048"] = run_bls_aggregate(args, L, torch, dist, rank, world)
             line["block"] = run_block(args, L, torch)
@@ -753,7 +865,7 @@ def main():
     if workload in ("merkle", "both"):
         r = run_merkle(args, L, torch, dist, rank, world)
         r["check"] = {"root": r.get("root")}
-        m = finish(r)
+        m = finish(r, args, world, dist, torch)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             m["cpu_baseline"] = cpu_baseline_merkle(args.validators)
         if line is None:
@@ -761,6 +873,22 @@ def main():
         else:
             line["merkle"] = {k: m[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline",
                                                 "check", "cpu_baseline") if k in m}
+    # The default line (N = 1, both halves, default sizes) also carries the other configurations of BASELINE.json, each a few
+    # seconds of GPU time, each with its own check: north_star's 2^20-signature K = 1 batch in ONE call ("strong_2p20": the
+    # N = 1 point of `--tuples 1048576 --scaling strong`), configs[3] ("epoch": all 2 048 aggregates of 2 048 keys) and
+    # configs[4] ("slots": 64 slots of sync aggregate + state root).
+    if workload == "both" and world == 1 and not args.no_extras and args.tuples == 65536 and args.scaling == "weak":
+        import copy
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup = 2, 1
+        line["strong_2p20"] = sub_record(finish(run_bls(a2, L, torch, dist, rank, world, n_total=1 << 20, strong=True), a2, world, dist, torch))
+        line["strong_2p20"]["vs_16x_65536_step"] = line["strong_2p20"]["ms_per_step"] / (16 * line["ms_per_step"])
+        a3 = copy.copy(args)
+        a3.steps, a3.warmup = 2, 1
+        line["epoch"] = sub_record(finish(run_epoch(a3, L, torch, dist, rank, world), a3, world, dist, torch))
+        a4 = copy.copy(args)
+        a4.steps, a4.warmup = 64, 2
+        line["slots"] = sub_record(finish(run_slots(a4, L, torch, dist, rank, world), a4, world, dist, torch))
     # box self-check (csrc/selfcheck.hip): 2^21 multiply-adds per lane as loops over 8 KB .. 1 MB of code.  On a healthy box
     # they take the same time; where the large ones are several times slower, so are the sums-of-products lane kernels, and
     # the library has switched that rank to its compact-code build.  Every rank checks its own GPU: with N > 1 the slowest
@@ -769,15 +897,7 @@ def main():
     sweep = (ctypes.c_double * 4)()
     ok = L.ecgpu_selfcheck_ifetch_sweep(sweep) == 0 and sweep[0] > 0
     mine = [sweep[3] / sweep[0] if ok else 0.0, float(L.ecgpu_bls_tower())]
-    per_rank = [mine]
-    if world > 1:
-        try:
-            t = torch.tensor(mine, dtype=torch.float64, device="cuda")
-            parts = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(parts, t)
-            per_rank = [p.cpu().tolist() for p in parts]
-        except Exception:  # noqa: BLE001 - a failed diagnostic must not cost the measurement
-            per_rank = [mine]
+    per_rank = gather_selfcheck(mine, world, dist, torch)
     if rank == 0:
         names = {1: "sums of products", 2: "compact-code tower"}
         if ok:

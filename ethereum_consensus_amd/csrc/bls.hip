@@ -128,13 +128,24 @@ static void launch_sum(hipStream_t s, u32 n_tuples, u32 n_pts, const Aff<F>* pts
 // them is most of the compile time, and the two units build side by side)
 
 // ---- aggregate outputs -----------------------------------------------------------------------
-// status of crypto::aggregate (bls.rs:79-93): every signature is decoded first, then group-checked
-__global__ void k_agg_sig_status(const u8* st_dec, const u8* st_grp, u32 n, u8* st_one) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    u8 s = 0;
-    for (u32 i = 0; i < n && !s; i++) s = st_dec[i];
-    for (u32 i = 0; i < n && !s; i++) s = st_grp[i];
-    *st_one = s;
+// status of crypto::aggregate (bls.rs:79-93): every signature is decoded first, then group-checked -- the first decoding
+// failure in list order wins, and only if there is none the first group-check failure.  One workgroup, every lane strides
+// the list, lowest failing index by atomicMin (like k_sum's first failing key): n = 65 536 signatures are 256 steps per lane
+// instead of a 131 072-step loop on one lane.
+constexpr int AGG_STATUS_BLOCK = 256;
+__global__ void __launch_bounds__(AGG_STATUS_BLOCK) k_agg_sig_status(const u8* st_dec, const u8* st_grp, u32 n, u8* st_one) {
+    __shared__ u32 first_dec, first_grp;
+    if (threadIdx.x == 0) first_dec = first_grp = 0xffffffffu;
+    __syncthreads();
+    u32 my_dec = 0xffffffffu, my_grp = 0xffffffffu;
+    for (u32 i = threadIdx.x; i < n; i += AGG_STATUS_BLOCK) {  // ascending per lane: the first hit is the lane's lowest
+        if (my_dec == 0xffffffffu && st_dec[i]) my_dec = i;
+        if (my_grp == 0xffffffffu && st_grp[i]) my_grp = i;
+    }
+    if (my_dec != 0xffffffffu) atomicMin(&first_dec, my_dec);
+    if (my_grp != 0xffffffffu) atomicMin(&first_grp, my_grp);
+    __syncthreads();
+    if (threadIdx.x == 0) *st_one = first_dec != 0xffffffffu ? st_dec[first_dec] : (first_grp != 0xffffffffu ? st_grp[first_grp] : (u8)0);
 }
 __global__ void k_compress_g1(const A1* p, u8* out48) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -622,7 +633,7 @@ int ecgpu_aggregate_verify(const uint8_t* pks48, uint32_t n_pks, const uint8_t* 
                            (const A1*)pts, (const A2*)hpts, (const A2*)sigpt, npair, fs);
     }
     hipLaunchKernelGGL(g_tower.load() == 2 ? k_aggv_final_calls : k_aggv_final, dim3(1), dim3(BLS_BLOCK), 0, k.s, (const u8*)st, np, nm,
-                       (const u8*)st_dec, (const u8*)st_grp, (const Fp12*)fs, d_status);
+                       (const u8*)st_dec, (const u8*)st_grp, fs, d_status);
     ECG_HIP_CHECK(hipGetLastError());
     u8 out = 0xff;
     ECG_HIP_CHECK(hipMemcpyAsync(&out, d_status, 1, hipMemcpyDeviceToHost, k.s));
@@ -645,7 +656,7 @@ int ecgpu_aggregate_sigs(const uint8_t* sigs96, uint32_t n, uint8_t* out96) {
     u8* d_out = k.ar->take(96 + 1);
     if (!pts || !st_dec || !st_grp || !sum || !d_out) return ECGPU_ERR_OOM;
     hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_sigs, n, pts, st_dec, st_grp);
-    hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(64), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
+    hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(AGG_STATUS_BLOCK), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
     launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr);
     hipLaunchKernelGGL(k_compress_g2, dim3(1), dim3(64), 0, k.s, (const A2*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
@@ -730,7 +741,7 @@ int ecgpu_g2_msm(const uint8_t* sigs96, const uint8_t* scalars32, uint32_t n, ui
     u8* d_out = k.ar->take(96 + 1);
     if (!pts || !st_dec || !st_grp || !sum || !d_out) return ECGPU_ERR_OOM;
     hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_sigs, n, pts, st_dec, st_grp);
-    hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(64), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
+    hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(AGG_STATUS_BLOCK), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
     {
         ProfScope ps("bls_scalar_mul_g2", k.s);
         hipLaunchKernelGGL(k_scalar_mul<Fp2>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st_dec, (const u8*)d_sc, scalar_bits, n);
@@ -923,30 +934,22 @@ int ecgpu_fast_aggregate_verify_batch_multi(const int* devices, uint32_t n_devic
         for (u32 i = 0; i < n; i++)
             if (pk_off[i + 1] < pk_off[i]) return ECGPU_ERR_BAD_ARG;
     const u32 per = (n + n_devices - 1) / n_devices;
-    std::vector<int> rcs(n_devices, 0);
-    std::vector<std::string> errs(n_devices);
-    std::vector<std::thread> th;
-    for (u32 g = 0; g < n_devices; g++) {
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+    // one persistent worker per device (runtime.hip): its streams, arenas and staging are reused by every call
+    int rc0 = run_on_devices(devices, n_devices, [=](unsigned g) -> int {
         const u32 lo = g * per < n ? g * per : n, hi = (g + 1) * per < n ? (g + 1) * per : n;
-        if (lo == hi) continue;
-        th.emplace_back([=, &rcs, &errs] {
-            int rc = ecgpu_bind_thread(devices[g]);
-            if (!rc) {
-                if (pk_off) {
-                    std::vector<u32> off(hi - lo + 1);
-                    for (u32 i = lo; i <= hi; i++) off[i - lo] = pk_off[i] - pk_off[lo];
-                    rc = fav_batch_host(pks48 + 48ull * pk_off[lo], off.data(), off.back(), msgs32 + 32ull * lo, nullptr, 32ull * (hi - lo),
-                                        sigs96 + 96ull * lo, hi - lo, eth_variant, status_out + lo);
-                } else {
-                    rc = fav_batch_host(pks48 + 48ull * lo, nullptr, hi - lo, msgs32 + 32ull * lo, nullptr, 32ull * (hi - lo), sigs96 + 96ull * lo,
-                                        hi - lo, eth_variant, status_out + lo);
-                }
-            }
-            rcs[g] = rc;
-            if (rc) errs[g] = ecgpu_last_error();
-        });
-    }
-    for (auto& t : th) t.join();
+        if (lo == hi) return ECGPU_SUCCESS;
+        if (pk_off) {
+            std::vector<u32> off(hi - lo + 1);
+            for (u32 i = lo; i <= hi; i++) off[i - lo] = pk_off[i] - pk_off[lo];
+            return fav_batch_host(pks48 + 48ull * pk_off[lo], off.data(), off.back(), msgs32 + 32ull * lo, nullptr, 32ull * (hi - lo),
+                                  sigs96 + 96ull * lo, hi - lo, eth_variant, status_out + lo);
+        }
+        return fav_batch_host(pks48 + 48ull * lo, nullptr, hi - lo, msgs32 + 32ull * lo, nullptr, 32ull * (hi - lo), sigs96 + 96ull * lo,
+                              hi - lo, eth_variant, status_out + lo);
+    }, rcs, errs);
+    if (rc0) return rc0;
     for (u32 g = 0; g < n_devices; g++)
         if (rcs[g]) {
             set_last_error("device shard " + std::to_string(g) + ": " + errs[g]);

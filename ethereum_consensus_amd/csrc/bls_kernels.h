@@ -32,12 +32,12 @@ __global__ void k_h2c_calls(const u8* msgs, const u64* msg_off, u32 n, A2* hpts)
 __global__ void k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out);
 __global__ void k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);
-__global__ void k_aggv_final(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, const Fp12* fs, u8* status_out);
+__global__ void k_aggv_final(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, Fp12* fs, u8* status_out);
 
 // bls_pairing_kernels_calls.hip: the same three kernels on the compact-code tower
 __global__ void k_pairing_calls(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                                 const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out);
 __global__ void k_miller_pairs_calls(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);
-__global__ void k_aggv_final_calls(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, const Fp12* fs, u8* status_out);
+__global__ void k_aggv_final_calls(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, Fp12* fs, u8* status_out);
 
 }  // namespace ecg

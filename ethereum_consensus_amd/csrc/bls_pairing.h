@@ -195,6 +195,7 @@ ECG_HD void miller_add_step_inl(Fp12& f, const MillerPair& m, int k) {
 // running points live in the lane slots (LDS), the fixed coordinates of the pairs in the private segment (read once per
 // step, long before their use).
 ECG_HD_NOINLINE void miller_loop(Fp12& f, MillerPair* pairs, int n) {
+    ECG_LONG_BRANCH_GUARD();  // loops far larger than the branch range: see common.h
     bool any = false;
     MillerPair lp[2];  // n <= 2 (verify: 2 pairs; aggregate_verify: 1 per lane); private copies, see ecg_priv_load
     for (int k = 0; k < n && k < 2; k++) {
@@ -248,6 +249,7 @@ ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
     // reloads per squaring).  The BASE is needed five times in 63 iterations; it waits in the lane slots (LDS) -- 156 more
     // live dwords under the squaring would come back as spills -- and the product reads it from there, coefficient by
     // coefficient.  `a` may alias `r` (written only at the end).
+    ECG_LONG_BRANCH_GUARD();  // the loop below is 340 KB of code: see common.h
     Fp12 acc = ecg_priv_load(a);
     slot_store_fp12(acc);
     for (int b = 62; b >= 0; b--) {

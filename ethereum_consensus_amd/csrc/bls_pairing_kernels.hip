@@ -57,28 +57,49 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_miller_pair
     fs[i] = f;
 }
 
+// One workgroup of 64 lanes: the first failing key in list order by atomicMin (as k_sum does), the Miller values multiplied in
+// 64 stripes (lane t: fs[t] fs[t + 64] ...; in place), then lane 0 multiplies the stripe products and runs the final
+// exponentiation: n / 64 + 64 dependent Fp12 products instead of n (round 2: everything on one lane).
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_aggv_final)(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp,
-                                                           const Fp12* fs, u8* status_out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (u32 i = 0; i < n_pks; i++)
-        if (st_pk[i]) {
-            *status_out = st_pk[i];
-            return;
+                                                           Fp12* fs, u8* status_out) {
+    if (blockIdx.x != 0) return;
+    __shared__ u32 first_bad;
+    __shared__ u32 early;  // 0x100 | status: decided without the pairing product
+    const u32 t = threadIdx.x;
+    if (t == 0) {
+        first_bad = 0xffffffffu;
+        early = 0;
+    }
+    __syncthreads();
+    u32 mine = 0xffffffffu;
+    for (u32 i = t; i < n_pks && mine == 0xffffffffu; i += BLS_BLOCK)
+        if (st_pk[i]) mine = i;
+    if (mine != 0xffffffffu) atomicMin(&first_bad, mine);
+    __syncthreads();
+    if (t == 0) {
+        if (first_bad != 0xffffffffu) early = 0x100 | st_pk[first_bad];
+        else if (st_dec[0]) early = 0x100 | st_dec[0];
+        else if (n_pks == 0 || n_pks != n_msgs) early = 0x100 | ECGPU_VERIFY_FAIL;
+        else if (st_grp[0]) early = 0x100 | ECGPU_IN_VERIFY | st_grp[0];  // verify's own group check: Error::InvalidSignature (crypto/bls.rs:106-111)
+    }
+    __syncthreads();
+    if (early) {
+        if (t == 0) *status_out = (u8)early;
+        return;
+    }
+    // fs[0 .. n_pks]: n_pks key pairs and the (-g1, sig) pair
+    if (t <= n_pks) {
+        Fp12 f = fs[t];
+        for (u32 i = t + BLS_BLOCK; i <= n_pks; i += BLS_BLOCK) {
+            Fp12 g = fs[i];
+            fp12_mul(f, f, g);
         }
-    if (st_dec[0]) {
-        *status_out = st_dec[0];
-        return;
+        fs[t] = f;
     }
-    if (n_pks == 0 || n_pks != n_msgs) {
-        *status_out = ECGPU_VERIFY_FAIL;
-        return;
-    }
-    if (st_grp[0]) {
-        *status_out = ECGPU_IN_VERIFY | st_grp[0];  // verify's own group check: Error::InvalidSignature (crypto/bls.rs:106-111)
-        return;
-    }
+    __syncthreads();
+    if (t != 0) return;
     Fp12 f = fs[0];
-    for (u32 i = 1; i <= n_pks; i++) {
+    for (u32 i = 1; i <= n_pks && i < BLS_BLOCK; i++) {
         Fp12 g = fs[i];
         fp12_mul(f, f, g);
     }

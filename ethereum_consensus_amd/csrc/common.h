@@ -82,7 +82,17 @@ ECG_D void ecg_priv_store(T& x, const T& v) {
 #pragma unroll
     for (unsigned i = 0; i < sizeof(T) / 4; i++) p[i] = q[i];
 }
+// COMPILER BUG WORKAROUND (ROCm 7.2 / LLVM AMDGPU branch relaxation).  A branch whose distance exceeds the 16-bit offset
+// (128 KB of code: our loops over inlined tower arithmetic) is expanded to s_getpc_b64 / s_add_u32 / s_addc_u32 /
+// s_setpc_b64 through a scavenged SGPR pair, and in a function that makes NO call the scavenger hands out s[30:31] -- the
+// function's own return address: the return then jumps back into the loop and the kernel never terminates (round 2 met this
+// as "a kernel that does not terminate on the device" and backed off; tools/isa_census.py --check-long-branches finds it
+// statically).  A function that contains a call saves s[30:31] in its prologue and restores it before returning, so a clobber
+// in between is harmless: every out-of-line lane routine with a loop larger than the branch range calls this once.
+static __device__ __attribute__((noinline)) void ecg_force_return_address_save() { asm volatile("" ::: "memory"); }
+#define ECG_LONG_BRANCH_GUARD() ecg_force_return_address_save()
 #else
+#define ECG_LONG_BRANCH_GUARD() ((void)0)
 template <class T>
 ECG_HD T ecg_priv_load(const T& x) { return x; }
 template <class T>

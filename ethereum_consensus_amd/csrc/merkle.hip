@@ -559,30 +559,33 @@ int ecgpu_sha256(const uint8_t* data, size_t len, uint8_t out[32]) { return ecgp
 // and the first device finishes the top of the tree.
 int ecgpu_htr_validators_multi(const int* devices, uint32_t n_devices, const uint8_t* ssz121, uint64_t n, uint64_t limit, uint8_t root[32]) {
     if (!devices || n_devices == 0 || n_devices > (uint32_t)MAX_DEVICES || (!ssz121 && n) || !root || n > limit) return ECGPU_ERR_BAD_ARG;
+    // the tree has ceil_log2(limit) levels: a limit that is not a power of two means the next one (as ecgpu_merkleize treats it)
+    u64 lim2 = 1;
+    while (lim2 < limit) lim2 <<= 1;
     u64 W = 1;
     while (W * n_devices < n) W <<= 1;
+    if (W > lim2) W = lim2;  // n <= limit <= lim2: a single subtree then
     const u32 n_sub = n ? (u32)((n + W - 1) / W) : 0;
     std::vector<u8> sub(32ull * (n_sub ? n_sub : 1));
-    std::vector<int> rcs(n_devices, 0);
-    std::vector<std::thread> th;
-    for (u32 g = 0; g < n_sub; g++) {
-        th.emplace_back([=, &rcs, &sub] {
-            int rc = ecgpu_bind_thread(devices[g]);
-            const u64 lo = g * W, cnt = n - lo < W ? n - lo : W;
-            if (!rc) rc = ecgpu_validators_subtree_root(ssz121 + 121 * lo, cnt, W, sub.data() + 32ull * g);
-            rcs[g] = rc;
-        });
-    }
-    for (auto& t : th) t.join();
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+    // persistent per-device workers (runtime.hip): nothing is created or leaked per call
+    int rc = run_on_devices(devices, n_sub, [&](unsigned g) -> int {
+        const u64 lo = g * W, cnt = n - lo < W ? n - lo : W;
+        return ecgpu_validators_subtree_root(ssz121 + 121 * lo, cnt, W, sub.data() + 32ull * g);
+    }, rcs, errs);
+    if (rc) return rc;
     for (u32 g = 0; g < n_sub; g++)
-        if (rcs[g]) return rcs[g];
-    int rc = 0;  // the top of the tree on devices[0], again on a thread of its own: the caller's binding is left alone
-    std::thread top([&] {
-        rc = ecgpu_bind_thread(devices[0]);
-        if (!rc) rc = ecgpu_merkleize_subtree_roots(sub.data(), n_sub, W, limit, 1, n, root);
-    });
-    top.join();
-    return rc;
+        if (rcs[g]) {
+            set_last_error("device shard " + std::to_string(g) + ": " + errs[g]);
+            return rcs[g];
+        }
+    // the top of the tree on devices[0]'s worker: the caller's own binding is left alone
+    rc = run_on_devices(devices, 1, [&](unsigned) -> int { return ecgpu_merkleize_subtree_roots(sub.data(), n_sub, W, lim2, 1, n, root); },
+                        rcs, errs);
+    if (rc) return rc;
+    if (rcs[0]) set_last_error("top of the tree: " + errs[0]);
+    return rcs[0];
 }
 
 int ecgpu_is_valid_merkle_branch(const uint8_t leaf[32], const uint8_t* branch, uint32_t depth, uint64_t index,

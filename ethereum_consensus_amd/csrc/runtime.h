@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -66,12 +67,21 @@ struct ThreadCtx {
     u64 last_hash64 = 0;
     hipStream_t stream_or_own(ecgpu_stream_t s);
     Arena& arena(hipStream_t s) { return arenas[s]; }
+    void release();  // synchronize and free every stream, event, arena and pinned buffer (thread exit)
 };
 
 constexpr int MAX_DEVICES = 16;
 int current_device();       // the device the calling thread is bound to (ecgpu_bind_thread; default: the process's first)
 int ensure_init();          // ECGPU_SUCCESS or ECGPU_ERR_NO_DEVICE; binds the thread to current_device()
-ThreadCtx* tctx();          // per-thread context (after ensure_init)
+ThreadCtx* tctx();          // per-thread context (after ensure_init); freed when the thread exits
+
+// One persistent worker thread per device for the *_multi entries (several GPUs under one host process): created on first
+// use, bound to its device once, reused by every later call -- so its streams, arenas and pinned staging are too.  (Round 2
+// started fresh std::threads per call, each of which built a context that nothing released: a host calling a *_multi entry
+// once per slot leaked streams and HBM on every device.)  run_on_devices runs fn(g) for g in [0, n) on devices[g]'s worker
+// and returns when all are done; entries for the same device run one after the other.
+int run_on_devices(const int* devices, unsigned n, const std::function<int(unsigned)>& fn, std::vector<int>& rcs,
+                   std::vector<std::string>& errs);
 
 // kernel timing with HIP events on the launch stream
 struct ProfScope {

@@ -2,7 +2,10 @@
 #include "runtime.h"
 
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <thread>
 
 namespace ecg {
 
@@ -88,13 +91,116 @@ int ensure_init() {
     return ECGPU_SUCCESS;
 }
 
-// per (host thread, device): streams and arenas are device objects
-static thread_local std::map<int, ThreadCtx*>* t_ctxs = nullptr;
+// per (host thread, device): streams and arenas are device objects.  The holder's destructor runs when the thread exits
+// (for the main thread: before static destructors, i.e. while the HIP runtime is still up) and gives everything back.
+void ThreadCtx::release() {
+    if (own_stream) (void)hipStreamSynchronize(own_stream);
+    if (aux.ready)
+        for (int i = 0; i < N_AUX_STREAMS; i++) (void)hipStreamSynchronize(aux.st[i]);
+    for (auto& kv : arenas)
+        if (kv.second.base) {
+            if (kv.first && kv.first != own_stream) (void)hipStreamSynchronize(kv.first);  // a caller's stream this thread used
+            (void)hipFree(kv.second.base);
+        }
+    arenas.clear();
+    if (staging.p) (void)hipHostFree(staging.p);
+    staging = PinnedBuf();
+    if (aux.ready) {
+        (void)hipEventDestroy(aux.fork);
+        for (int i = 0; i < N_AUX_STREAMS; i++) {
+            (void)hipEventDestroy(aux.done[i]);
+            (void)hipEventDestroy(aux.reached[i]);
+            (void)hipStreamDestroy(aux.st[i]);
+        }
+        aux = AuxStreams();
+    }
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+    own_stream = nullptr;
+}
+namespace {
+struct ThreadCtxs {
+    std::map<int, ThreadCtx*> by_device;
+    ~ThreadCtxs() {
+        for (auto& kv : by_device) {
+            if (hipSetDevice(kv.first) == hipSuccess) kv.second->release();
+            delete kv.second;
+        }
+    }
+};
+}  // namespace
+static thread_local ThreadCtxs t_ctxs;
 ThreadCtx* tctx() {
-    if (!t_ctxs) t_ctxs = new std::map<int, ThreadCtx*>();  // lives for the thread; a handful of bytes + arenas
-    ThreadCtx*& c = (*t_ctxs)[current_device()];
+    ThreadCtx*& c = t_ctxs.by_device[current_device()];
     if (!c) c = new ThreadCtx();
     return c;
+}
+
+// ---- persistent per-device workers (see runtime.h) ---------------------------------------------------------------------------
+namespace {
+struct DeviceWorker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::thread th;
+    void loop(int device) {
+        (void)ecgpu_bind_thread(device);
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty(); });
+                job = std::move(q.front());
+                q.pop_front();
+            }
+            job();
+        }
+    }
+};
+std::mutex g_workers_mu;
+DeviceWorker* g_workers[MAX_DEVICES];  // never destroyed: the threads sleep until the process ends
+DeviceWorker* worker_of(int device) {
+    std::lock_guard<std::mutex> lk(g_workers_mu);
+    DeviceWorker*& w = g_workers[device];
+    if (!w) {
+        w = new DeviceWorker();
+        w->th = std::thread([w, device] { w->loop(device); });
+        w->th.detach();
+    }
+    return w;
+}
+}  // namespace
+
+int run_on_devices(const int* devices, unsigned n, const std::function<int(unsigned)>& fn, std::vector<int>& rcs,
+                   std::vector<std::string>& errs) {
+    rcs.assign(n, 0);
+    errs.assign(n, std::string());
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return ECGPU_ERR_NO_DEVICE;
+    for (unsigned g = 0; g < n; g++)
+        if (devices[g] < 0 || devices[g] >= n_dev || devices[g] >= MAX_DEVICES) {
+            set_last_error("device index out of range");
+            return ECGPU_ERR_BAD_ARG;
+        }
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    unsigned done = 0;
+    for (unsigned g = 0; g < n; g++) {
+        DeviceWorker* w = worker_of(devices[g]);
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->q.push_back([&, g] {
+            int rc = ensure_init();  // the worker is bound to its device; this (re)selects it for the HIP runtime
+            if (!rc) rc = fn(g);
+            rcs[g] = rc;
+            if (rc) errs[g] = ecgpu_last_error();
+            std::lock_guard<std::mutex> dl(done_mu);
+            done++;
+            done_cv.notify_one();
+        });
+        w->cv.notify_one();
+    }
+    std::unique_lock<std::mutex> lk(done_mu);
+    done_cv.wait(lk, [&] { return done == n; });
+    return ECGPU_SUCCESS;
 }
 
 hipStream_t ThreadCtx::stream_or_own(ecgpu_stream_t s) {

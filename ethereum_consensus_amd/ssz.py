@@ -301,8 +301,16 @@ def prove(ssz_type, encoding: bytes, path):
 def merkle_proof(chunks: bytes, limit_chunks: int, index: int):
     """the branch of chunk `index` in merkleize(chunks, limit_chunks), bottom-up"""
     L = _lib.load()
+    if len(chunks) % 32:
+        raise MerkleizationError("chunks must be a whole number of 32-byte chunks")
     n = len(chunks) // 32
-    depth = max(limit_chunks - 1, 0).bit_length()
+    # the C entry's rule (csrc/ssz_proof.hip): limit_chunks == 0 means "no limit beyond the data": the tree of the chunks themselves
+    eff = limit_chunks or max(n, 1)
+    if n > eff or index < 0:
+        raise MerkleizationError("bad proof request")
+    depth = (eff - 1).bit_length()
+    if index >= 1 << depth:
+        raise MerkleizationError("bad proof request")
     out = ctypes.create_string_buffer(max(32 * depth, 1))
     rc = L.ecgpu_merkle_proof(_buf(chunks), n, limit_chunks, index, out)
     if rc == -3:

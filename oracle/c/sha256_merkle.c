@@ -221,3 +221,13 @@ uint64_t oc_htr_validators(const uint8_t* ssz121, uint64_t n, uint64_t limit, ui
     oc_mix_in_length(root, n);
     return h + 1;
 }
+
+/* root of the aligned subtree of `width` (a power of two) validators holding the first n <= width records: no length mix-in.
+   One thread's share when bench.py times this restatement on several host threads ("1 and 8 threads"). */
+uint64_t oc_validators_subtree_root(const uint8_t* ssz121, uint64_t n, uint64_t width, uint8_t root[32]) {
+    uint8_t* roots = (uint8_t*)malloc(32 * (n ? n : 1));
+    for (uint64_t i = 0; i < n; i++) oc_htr_validator(ssz121 + 121 * i, roots + 32 * i);
+    uint64_t h = 8 * n + oc_merkleize_chunks(roots, n, width, root);
+    free(roots);
+    return h;
+}

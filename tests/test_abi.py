@@ -58,6 +58,23 @@ def test_product_does_not_import_the_oracle():
                 assert needle not in text, (f, needle)
 
 
+def test_no_long_branch_clobbers_a_return_address():
+    """Static guard against an LLVM AMDGPU branch-relaxation bug (csrc/common.h ECG_LONG_BRANCH_GUARD): in a device function
+    without calls a branch longer than 128 KB is expanded through s[30:31] -- the function's own return address -- and the
+    kernel never terminates.  Every device object of the product build is disassembled and checked."""
+    import glob
+    import sys
+    from ethereum_consensus_amd import _lib
+    _lib.load()  # builds the library if needed
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_census
+    objs = sorted(glob.glob(os.path.join(ROOT, "ethereum_consensus_amd", "lib", "obj", "*.o")))
+    if not objs:
+        pytest.skip("no object files next to the library (built elsewhere)")
+    bad = [(os.path.basename(o), fn, addr) for o in objs for fn, addr in isa_census.long_branch_clobbers(o)]
+    assert not bad, bad
+
+
 def _build_c_caller():
     from ethereum_consensus_amd import _lib
     _lib.load()  # builds the library if needed

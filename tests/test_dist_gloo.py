@@ -123,3 +123,146 @@ def test_world2_gloo_sharded_list_root_equals_the_unsharded_root(n_total, limit)
         p.join(timeout=60)
     want = _oracle_merkleize(_validator_roots(0, n_total), limit, n_total)
     assert res[0] == want and res[1] == want
+
+
+# ---- bench.py's N-rank control flow (finish, self-check gather, epoch sharding, strong-scaled K = 1 batch) -----------------
+# bench.py is device-agnostic above its `DEV` switch: here it runs on CPU tensors under gloo with a stub library whose entry
+# points have the C ABI's argument order and are answered by the C++ oracle (oracle/cbls.py).  What stays untested without
+# N GPUs is the RCCL transport itself.
+class _StubLib:
+    """the subset of libecgpu.so's entries bench.run_epoch / bench.run_bls call, over host memory (data_ptr of CPU tensors)"""
+
+    def __init__(self):
+        self.regs = {}
+
+    @staticmethod
+    def _rd(ptr, n):
+        import ctypes
+        return ctypes.string_at(ptr, n) if n else b""
+
+    @staticmethod
+    def _wr(ptr, data):
+        import ctypes
+        ctypes.memmove(ptr, bytes(data), len(data))
+
+    def ecgpu_last_error(self):
+        return b""
+
+    def ecgpu_sk_to_pk_batch_dev(self, d_sk, n, d_pk, stream):
+        from oracle import cbls
+        sk = self._rd(d_sk, 32 * n)
+        self._wr(d_pk, b"".join(cbls.sk_to_pk(int.from_bytes(sk[32 * i:32 * i + 32], "big")) for i in range(n)))
+        return 0
+
+    def ecgpu_sign_batch_dev(self, d_sk, stride, d_msg, n, d_sig, stream):
+        from oracle import cbls
+        sk, msg = self._rd(d_sk, 32 * n if stride else 32), self._rd(d_msg, 32 * n)
+        self._wr(d_sig, b"".join(cbls.sign(int.from_bytes(sk[stride * i:stride * i + 32], "big"), msg[32 * i:32 * i + 32]) for i in range(n)))
+        return 0
+
+    def ecgpu_registry_create(self, n, ref):
+        h = len(self.regs) + 1
+        self.regs[h] = bytearray(48 * n)
+        ref._obj.value = h
+        return 0
+
+    def ecgpu_registry_set_dev(self, reg, first, d_keys, n, stream):
+        self.regs[reg.value][48 * first:48 * (first + n)] = self._rd(d_keys, 48 * n)
+        return 0
+
+    def ecgpu_registry_destroy(self, reg):
+        self.regs.pop(reg.value, None)
+
+    def _fav(self, key_of, d_off, n_keys, d_msg, d_sig, n, eth, d_st):
+        import struct
+        from oracle import cbls
+        off = list(struct.unpack(f"<{n + 1}I", self._rd(d_off, 4 * (n + 1)))) if d_off else list(range(n + 1))
+        msg, sig = self._rd(d_msg, 32 * n), self._rd(d_sig, 96 * n)
+        st = bytes(cbls.fast_aggregate_verify([key_of(j) for j in range(off[i], off[i + 1])], msg[32 * i:32 * i + 32], sig[96 * i:96 * i + 96],
+                                              bool(eth)) & 0xFF for i in range(n))
+        self._wr(d_st, st)
+        return 0
+
+    def ecgpu_fast_aggregate_verify_batch_dev(self, d_pk, d_off, n_pks, d_msg, d_sig, n, eth, d_st, stream):
+        pk = self._rd(d_pk, 48 * n_pks)
+        return self._fav(lambda j: pk[48 * j:48 * j + 48], d_off, n_pks, d_msg, d_sig, n, eth, d_st)
+
+    def ecgpu_fast_aggregate_verify_indexed_batch_dev(self, reg, d_idx, d_off, n_keys, d_msg, d_sig, n, eth, d_st, stream):
+        import struct
+        keys = self.regs[reg.value]
+        idx = struct.unpack(f"<{n_keys}I", self._rd(d_idx, 4 * n_keys))
+        return self._fav(lambda j: bytes(keys[48 * idx[j]:48 * idx[j] + 48]), d_off, n_keys, d_msg, d_sig, n, eth, d_st)
+
+    def ecgpu_prof_filter(self, tag):
+        return 0
+
+    def ecgpu_prof_enable(self, on):
+        return 0
+
+    def ecgpu_prof_read(self, tag, ms, nl):
+        ms._obj.value, nl._obj.value = 1.0, 1
+        return 1
+
+    def ecgpu_bls_tower(self):
+        return 1
+
+    def ecgpu_bls_last_pairing_path(self):
+        return 1
+
+
+def _bench_worker(rank, world, port, q):
+    import argparse
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        bench.DEV = "cpu"
+        args = argparse.Namespace(steps=1, warmup=1, tuples=10, scaling="strong")
+        res = {}
+        # finish(): the slowest rank's wall time sets the step time; value = all ranks' units over it
+        line = bench.finish(dict(dt=0.5 * (rank + 1), units_per_step=100, metric="m", unit="u", dtype="u32", config={}, roofline={},
+                                 check={"r": rank}), args, world, dist, torch)
+        res["finish"] = (line["n_gpus"], round(line["ms_per_step"], 6), round(line["value"], 6), line["scaling"])
+        # the per-rank self-check gather: every rank's pair in rank order
+        res["selfcheck"] = bench.gather_selfcheck([1.0 + rank, float(1 + rank % 2)], world, dist, torch)
+        # configs[3] in miniature: 7 aggregates of 3 keys over `world` ranks (ragged), both key paths, statuses all-gathered
+        L = _StubLib()
+        e = bench.run_epoch(args, L, torch, dist, rank, world, n_total=7, k=3, n_reg=32, sk_period=8)
+        res["epoch"] = (e["check"]["statuses_match_construction"], e["scaling"], e["config"]["aggregates_per_gpu"], e["units_per_step"] * world)
+        # north_star's strong-scaled K = 1 batch in miniature: 10 tuples in all, rank g verifies shard_range(10, g, world)
+        b = bench.run_bls(args, L, torch, dist, rank, world)
+        fb = bench.finish(b, args, world, dist, torch)
+        res["bls"] = (b["check"]["statuses_match_construction"], b["config"]["tuples_this_rank"], fb["scaling"], round(fb["value"] * fb["ms_per_step"] / 1e3, 6))
+        dist.barrier()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_n_rank_control_flow_under_gloo(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        out = res[r]
+        # max over ranks of dt = 0.5 * world seconds for ONE step; value = 100 units x world ranks over that time
+        assert out["finish"] == (world, round(500.0 * world, 6), round(100 * world / (0.5 * world), 6), "weak")
+        assert out["selfcheck"] == [[1.0 + k, float(1 + k % 2)] for k in range(world)]
+        per = -(-7 // world)
+        assert out["epoch"] == (True, "strong", per, 7 * 3)
+        lo, hi = shard.shard_range(10, r, world)
+        assert out["bls"][:3] == (True, hi - lo, "strong")
+        assert abs(out["bls"][3] - 10) < 1e-3  # value x time of one step = the whole batch, whatever the rank count

@@ -517,6 +517,54 @@ def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, 
     assert res["ok"] and res["n"] == n and res["python_samples_checked"] >= (64 if n == 65536 else 8), res
 
 
+def test_north_star_batch_of_2_pow_20_signatures_in_one_call(gpu):
+    """north_star "Target": a 2^20-signature K = 1 batch.  1 048 576 tuples (the workload of `bench.py --tuples 1048576 --scaling
+    strong`: SURVEY 8(d) config 2's generator and fault cycle, every 64th tuple corrupted, eight classes) through ONE
+    ecgpu_fast_aggregate_verify_batch_dev call -- 16x today's largest K = 1 batch: arena sizing, u32 index arithmetic, sixteen
+    back-to-back waves per SIMD -- and through ecgpu_fast_aggregate_verify_batch_multi over the device list [0, 0, 0, 0] (host
+    buffers, four shards).  Checked against the statuses known by construction (all 2^20) and the C++ oracle on a 1/16
+    sample (every 16th tuple: all 16 384 corrupted ones and 49 152 clean ones)."""
+    import numpy as np
+    import torch
+    from ethereum_consensus_amd import _lib, synthetic as syn
+    from oracle import cbls
+    L = _lib.load(build_if_missing=False)
+    n = 1 << 20
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    msgs = bytearray(syn.bls_messages(n))
+    d_sk = torch.frombuffer(bytearray(syn.bls_secret_keys(n)), dtype=torch.uint8).to(dev)
+    d_msg_clean = torch.frombuffer(bytearray(msgs), dtype=torch.uint8).to(dev)
+    d_pk = torch.empty(48 * n, dtype=torch.uint8, device=dev)
+    d_sig = torch.empty(96 * n, dtype=torch.uint8, device=dev)
+    assert L.ecgpu_sk_to_pk_batch_dev(d_sk.data_ptr(), n, d_pk.data_ptr(), stream) == 0
+    assert L.ecgpu_sign_batch_dev(d_sk.data_ptr(), 32, d_msg_clean.data_ptr(), n, d_sig.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    pks = bytearray(d_pk.cpu().numpy().tobytes())
+    sigs = bytearray(d_sig.cpu().numpy().tobytes())
+    want, kind_of = syn.bls_inject_faults(pks, msgs, sigs, n)
+    want = np.frombuffer(bytes(want), dtype=np.uint8)
+    assert int((want != 0).sum()) == n // 64 and sorted(set(kind_of[::64])) == list(range(8))
+    d_pk = torch.frombuffer(pks, dtype=torch.uint8).to(dev)
+    d_sig = torch.frombuffer(sigs, dtype=torch.uint8).to(dev)
+    d_msg = torch.frombuffer(msgs, dtype=torch.uint8).to(dev)
+    d_st = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)
+    rc = L.ecgpu_fast_aggregate_verify_batch_dev(d_pk.data_ptr(), None, n, d_msg.data_ptr(), d_sig.data_ptr(), n, 0, d_st.data_ptr(), stream)
+    assert rc == 0, (rc, L.ecgpu_last_error())
+    torch.cuda.synchronize()
+    got = d_st.cpu().numpy()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad[:8].tolist(), got[bad[:8]].tolist(), want[bad[:8]].tolist())
+    # the same batch from host buffers, sharded over a device list by the library itself
+    multi = np.frombuffer(gpu.fast_aggregate_verify_batch_multi([0, 0, 0, 0], bytes(pks), None, bytes(msgs), bytes(sigs)), dtype=np.uint8)
+    assert (multi == want).all(), np.nonzero(multi != want)[0][:8].tolist()
+    # the C++ oracle on every 16th tuple
+    sel = range(0, n, 16)
+    o = cbls.fast_aggregate_verify_batch_k1(b"".join(bytes(pks[48 * i:48 * i + 48]) for i in sel), b"".join(bytes(msgs[32 * i:32 * i + 32]) for i in sel),
+                                            b"".join(bytes(sigs[96 * i:96 * i + 96]) for i in sel))
+    assert np.array_equal(np.frombuffer(o, dtype=np.uint8), got[::16])
+
+
 def test_error_identity_of_the_two_ambiguous_blst_codes(gpu):
     """crypto/bls.rs:69-76,119-131: a key outside G1 / an infinite key fails its CONVERSION -> Error::BLST; a signature outside
     G2 and keys summing to infinity are found inside blst's verify call -> Error::InvalidSignature.  Same BLST_ERROR values
@@ -655,6 +703,55 @@ def test_several_devices_in_one_process(gpu):
     for devs in ([0], [0, 0], [0, 0, 0, 0, 0]):
         assert ssz.hash_tree_root_validators_multi(devs, v) == want_root
     assert ssz.hash_tree_root_validators_multi([0, 0], b"") == ssz.hash_tree_root_validators(b"")
+    # a limit that is not a power of two (round-2 advisor): the tree has ceil_log2(limit) levels whatever the device count
+    from oracle import cref
+    v50 = syn.validators(50).tobytes()
+    want50, _ = cref.htr_validators(v50, 100)
+    assert ssz.hash_tree_root_validators(v50, limit=100) == want50
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        assert ssz.hash_tree_root_validators_multi(devs, v50, limit=100) == want50
+
+
+def test_multi_entries_do_not_leak_device_memory(gpu):
+    """Round-2 advisor: the *_multi entries used to start fresh threads per call, each building a stream set, an arena and a
+    pinned buffer that nothing released.  They run on one persistent worker per device now: device memory is flat over
+    hundreds of calls (a host calls these once per slot)."""
+    import torch
+    from ethereum_consensus_amd import ssz, synthetic as syn
+    n = 96
+    skb = syn.bls_secret_keys(n)
+    msgs = syn.bls_messages(n)
+    pks = gpu.sk_to_pk_batch(skb)
+    sigs = gpu.sign_batch(skb, [msgs[32 * i:32 * i + 32] for i in range(n)])
+    v = syn.validators(3000).tobytes()
+    want_root = ssz.hash_tree_root_validators(v)
+
+    def once():
+        assert gpu.fast_aggregate_verify_batch_multi([0, 0, 0], pks, None, msgs, sigs) == bytes(n)
+        assert ssz.hash_tree_root_validators_multi([0, 0, 0, 0], v) == want_root
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(150):
+        once()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over 150 calls"
+    # short-lived host threads calling the plain entries give everything back when they exit
+    import threading
+    def worker():
+        assert gpu.fast_aggregate_verify_batch(pks[:48 * 8], None, msgs[:32 * 8], sigs[:96 * 8]) == bytes(8)
+    for _ in range(3):
+        t = threading.Thread(target=worker); t.start(); t.join()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        t = threading.Thread(target=worker); t.start(); t.join()
+    torch.cuda.synchronize()
+    free3, _ = torch.cuda.mem_get_info()
+    assert free2 - free3 < (8 << 20), f"device memory shrank by {(free2 - free3) >> 20} MiB over 40 short-lived threads"
 
 
 def test_multi_scalar_multiplication(gpu):

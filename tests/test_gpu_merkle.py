@@ -414,6 +414,31 @@ def test_resident_state_of_an_older_fork(gpu):
     st.close()
 
 
+def test_merkle_proof_of_a_chunk_array(gpu):
+    """ssz.merkle_proof (ecgpu_merkle_proof): branches of chunks against the oracle's merkleize and is_valid_merkle_branch --
+    with a limit, with a limit that is not a power of two, and with limit_chunks == 0 (the tree of the chunks themselves:
+    the round-2 advisor found the Python wrapper sizing its buffer for depth 0 there)."""
+    from ethereum_consensus_amd import ssz
+    r = random.Random(77)
+    for n, limit in ((1, 0), (2, 0), (5, 0), (64, 0), (100, 0), (5, 8), (5, 100), (33, 4096), (1, 1), (0, 16)):
+        chunks = r.randbytes(32 * n)
+        eff = limit or max(n, 1)
+        depth = (eff - 1).bit_length()
+        root = ossz.merkleize_chunks([chunks[32 * i:32 * i + 32] for i in range(n)], limit or None)
+        for index in sorted({0, max(n - 1, 0), min(n, (1 << depth) - 1), (1 << depth) - 1}):
+            branch = ssz.merkle_proof(chunks, limit, index)
+            assert len(branch) == depth
+            leaf = chunks[32 * index:32 * index + 32] if index < n else bytes(32)
+            assert ossz.is_valid_merkle_branch(leaf, branch, depth, index, root), (n, limit, index)
+            assert ssz.is_valid_merkle_branch(leaf, branch, depth, index, root)
+    with pytest.raises(ssz.MerkleizationError):
+        ssz.merkle_proof(bytes(32 * 9), 8, 0)   # more chunks than the limit
+    with pytest.raises(ssz.MerkleizationError):
+        ssz.merkle_proof(bytes(32 * 4), 0, 4)   # index outside the tree
+    with pytest.raises(ssz.MerkleizationError):
+        ssz.merkle_proof(bytes(33), 0, 0)
+
+
 def test_proofs_and_generalized_indices(gpu):
     """`prove` / `generalized_index` over the generic SSZ description against the oracle's restatement
     (oracle/ssz.py prove), the reference's pinned indices (deneb/beacon_block.rs:139-154) and ecgpu_is_valid_merkle_branch

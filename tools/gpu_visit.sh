@@ -9,20 +9,21 @@
 #   pmc              FETCH_SIZE / WRITE_SIZE passes of the bench     -> gpurun_out/<tag>_pmc_{fetch,write}.txt
 #   lib:<name>       following steps use lib/libecgpu_<name>.so (tools/build_variant.sh); lib: alone switches back
 #   env:<K=V>        export K=V for the following steps (unenv:<K> removes it)
-#   to:<seconds>     timeout of the following probe steps
+#   to:<seconds>     timeout of the following probe steps (tt:<seconds>: of the test steps)
 #   py:<script>      python <script> (under tools/)                  -> gpurun_out/<tag>_<script>.txt
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 mkdir -p gpurun_out
 tag=$1; shift
-sfx=""; TO=900
+sfx=""; TO=900; TT=1200
 for step in "$@"; do
   case "$step" in
     to:*) TO=${step#to:};;
+    tt:*) TT=${step#tt:};;
     unenv:*) unset "${step#unenv:}"; sfx="";;
     lib:*) n=${step#lib:}; if [ -z "$n" ]; then unset ECGPU_LIB; sfx=""; else export ECGPU_LIB=$PWD/ethereum_consensus_amd/lib/libecgpu_$n.so; sfx="_$n"; fi;;
     env:*) export "${step#env:}"; sfx="${sfx}_$(echo ${step#env:} | tr -c 'A-Za-z0-9=' '_')";;
-    tests) timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/${tag}${sfx}_gpu_tests.txt;;
-    tests:*) timeout 2400 python -m pytest tests -m gpu -x -q -k "${step#tests:}" 2>&1 | tail -6 | tee gpurun_out/${tag}${sfx}_gpu_tests_k.txt;;
+    tests) timeout $TT python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/${tag}${sfx}_gpu_tests.txt;;
+    tests:*) timeout $TT python -m pytest tests -m gpu -x -q -k "${step#tests:}" 2>&1 | tail -6 | tee gpurun_out/${tag}${sfx}_gpu_tests_k.txt;;
     bench) timeout 900 python bench.py > gpurun_out/${tag}${sfx}_bench.json 2> gpurun_out/${tag}${sfx}_bench_err.txt; tail -c 600 gpurun_out/${tag}${sfx}_bench_err.txt
            python tools/bench_digest.py gpurun_out/${tag}${sfx}_bench.json;;
     bench:*) a=${step#bench:}; timeout 900 python bench.py ${a//_/ } > gpurun_out/${tag}${sfx}_bench_${a//[^A-Za-z0-9]/}.json 2> gpurun_out/${tag}${sfx}_bench_err.txt

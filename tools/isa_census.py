@@ -80,7 +80,45 @@ def fmt(c):
                c["wait"], c["wait_vm"], c["call"]))
 
 
+def long_branch_clobbers(obj_path):
+    """Functions in which a long-branch expansion (s_getpc_b64 / s_add_u32 / s_addc_u32 / s_setpc_b64 through one SGPR pair)
+    uses s[30:31] -- the return address -- without the function restoring it afterwards: such a function returns into its own
+    loop and never terminates (LLVM AMDGPU branch relaxation in a function without calls; csrc/common.h
+    ECG_LONG_BRANCH_GUARD).  Returns [(function, address)]."""
+    try:
+        obj = device_object(obj_path)
+    except SystemExit:
+        return []  # a host-only object
+    txt = subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", obj], capture_output=True, text=True).stdout
+    bad = []
+    cur, pending = None, None
+    for ln in txt.splitlines():
+        m = re.match(r"^([0-9a-f]+) <(.+)>:$", ln)
+        if m:
+            if pending:
+                bad.append(pending)
+            cur, pending = m.group(2), None
+            continue
+        if "s_getpc_b64 s[30:31]" in ln:
+            a = re.search(r"//\s*([0-9A-Fa-f]+):", ln)
+            pending = (cur, a.group(1) if a else "?")
+        elif pending and re.search(r"v_readlane_b32 s3[01],|s_mov_b64 s\[30:31\]|s_load_dwordx2 s\[30:31\]", ln):
+            pending = None  # restored from its save slot before the return
+        elif pending and "s_swappc_b64 s[30:31]" in ln:
+            pending = None  # a call site: s[30:31] is rewritten anyway, so it is saved around
+    if pending:
+        bad.append(pending)
+    return bad
+
+
 def main():
+    if "--check-long-branches" in sys.argv:
+        rc = 0
+        for path in [a for a in sys.argv[1:] if not a.startswith("--")]:
+            for fn, addr in long_branch_clobbers(path):
+                print(f"{path}: {fn}: long branch at {addr} clobbers the return address s[30:31]")
+                rc = 1
+        sys.exit(rc)
     obj = device_object(sys.argv[1])
     want = sys.argv[2:]
     txt = subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", obj], capture_output=True, text=True).stdout
