@@ -183,38 +183,6 @@ ECG_HD Fp fp_sub(const Fp& a, const Fp& b) { return fp_sub_inl(a, b); }
 ECG_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 ECG_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 
-// Montgomery product a*b/R mod p (result < 2p for a, b < 2p; raw inputs up to 2^384 are fine too).
-ECG_HD Fp fp_mul_body(const Fp& a, const Fp& b) {
-    u64 T[27];
-#pragma unroll
-    for (int i = 0; i < 27; i++) T[i] = 0;
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) {
-        const u32 bi = b.l[i];
-#pragma unroll
-        for (int j = 0; j < FP_N; j++) T[i + j] += (u64)a.l[j] * bi;
-        const u32 m = ((u32)T[i] * blsc::N0) & FP_MASK;
-#pragma unroll
-        for (int j = 0; j < FP_N; j++) T[i + j] += (u64)m * blsc::P[j];
-        T[i + 1] += T[i] >> 30;  // T[i] == 0 mod 2^30 now
-        if (i == 6) {
-            // 14 products per column so far; renormalize so that rows 7..12 (12 more) still fit
-#pragma unroll
-            for (int c = 7; c <= 18; c++) {
-                T[c + 1] += T[c] >> 30;
-                T[c] &= FP_MASK;
-            }
-        }
-    }
-    Fp r;
-#pragma unroll
-    for (int c = 13; c < 25; c++) {
-        T[c + 1] += T[c] >> 30;
-        r.l[c - 13] = (u32)T[c] & FP_MASK;
-    }
-    r.l[12] = (u32)T[25];
-    return r;
-}
 #if defined(__HIP_DEVICE_COMPILE__)
 // nothing but memory and scalar instructions may be scheduled across (operand loads should still be issued early)
 #define ECG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x3f4)
@@ -304,6 +272,35 @@ ECG_HD void ecg_col_pass_hi(u64& next, u64& col) {
     col &= 0xffffffffull;
 }
 #endif
+// Montgomery product a*b/R mod p (result < 2p for a, b < 2p; raw inputs up to 2^384 are fine too).
+ECG_HD Fp fp_mul_body(const Fp& a, const Fp& b) {
+    u64 T[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) T[i] = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        const u32 bi = b.l[i];
+#pragma unroll
+        for (int j = 0; j < FP_N; j++) T[i + j] += (u64)a.l[j] * bi;
+        const u32 m = ((u32)T[i] * blsc::N0) & FP_MASK;
+#pragma unroll
+        for (int j = 0; j < FP_N; j++) T[i + j] += (u64)m * blsc::P[j];
+        T[i + 1] += T[i] >> 30;  // T[i] == 0 mod 2^30 now
+        if (i == 6) {
+            // 14 products per column so far; carry-save pass (top down, see ecg_col_pass_hi) so that rows 7..12 (12 more) still fit
+#pragma unroll
+            for (int c = 18; c >= 7; c--) ecg_col_pass_hi<false>(T[c + 1], T[c]);
+        }
+    }
+    Fp r;
+#pragma unroll
+    for (int c = 13; c < 25; c++) {
+        T[c + 1] += T[c] >> 30;
+        r.l[c - 13] = (u32)T[c] & FP_MASK;
+    }
+    r.l[12] = (u32)T[25];
+    return r;
+}
 // k * p in normalized limbs, evaluated at compile time: the offsets of the lazy subtractions below.
 struct FpConst {
     u32 l[13];
@@ -452,11 +449,9 @@ ECG_HD_NOINLINE Fp fp_sqr(Fp a) {
 #pragma unroll
         for (int j = i + 1; j < FP_N; j++) T[i + j] += (u64)a2 * a.l[j];
     }
+    // carry-save pass before the reduction rows add 13 more products per column (top down: ecg_col_pass_hi)
 #pragma unroll
-    for (int c = 0; c < 25; c++) {
-        T[c + 1] += T[c] >> 30;
-        T[c] &= FP_MASK;
-    }
+    for (int c = 24; c >= 0; c--) ecg_col_pass_hi<false>(T[c + 1], T[c]);
 #pragma unroll
     for (int i = 0; i < FP_N; i++) {
         const u32 m = ((u32)T[i] * blsc::N0) & FP_MASK;

@@ -781,6 +781,43 @@ int fast_aggregate_verify(const u8* pks48, uint32_t k, const u8* msg, size_t len
     return core_verify(jac_to_aff<FOps1>(acc), hash_to_g2(msg, len), sig);
 }
 
+// aggregate_verify (oracle/bls12_381.py aggregate_verify, crypto/bls.rs:95-112): keys left to right, then the signature, then
+// n == 0 / length mismatch -> VERIFY_FAIL, then verify's own checks and the product of n + 1 pairings
+int aggregate_verify(const u8* pks48, uint32_t n_pks, const u8* msgs, const u64* msg_off, uint32_t n_msgs, const u8* sig96) {
+    std::vector<A1> ps;
+    for (uint32_t i = 0; i < n_pks; i++) {
+        A1 p;
+        int st = key_validate(p, pks48 + 48 * (size_t)i);
+        if (st) return st;
+        ps.push_back(p);
+    }
+    A2 sig;
+    int st = g2_decompress(sig, sig96);
+    if (st) return st;
+    if (n_pks == 0 || n_pks != n_msgs) return VERIFY_FAIL;
+    if (!sig.inf && !g2_in_subgroup(sig)) return IN_VERIFY | NOT_IN_GROUP;
+    std::vector<A2> qs;
+    for (uint32_t i = 0; i < n_msgs; i++) qs.push_back(hash_to_g2(msgs + msg_off[i], (size_t)(msg_off[i + 1] - msg_off[i])));
+    ps.push_back(G1_GEN_NEG);
+    qs.push_back(sig);
+    return pairing_product_is_one(ps.data(), qs.data(), (int)ps.size()) ? OK : VERIFY_FAIL;
+}
+// aggregate (oracle/bls12_381.py aggregate, crypto/bls.rs:79-93): every signature decoded first, then group-checked while summing
+int aggregate_sigs(const u8* sigs96, uint32_t n, u8* out96) {
+    std::vector<A2> pts(n);
+    for (uint32_t i = 0; i < n; i++) {
+        int st = g2_decompress(pts[i], sigs96 + 96 * (size_t)i);
+        if (st) return st;
+    }
+    J2 acc = jac_inf<FOps2>();
+    for (uint32_t i = 0; i < n; i++) {
+        if (!pts[i].inf && !g2_in_subgroup(pts[i])) return NOT_IN_GROUP;
+        acc = jac_add<FOps2>(acc, jac_from_aff<FOps2>(pts[i]));
+    }
+    g2_compress(out96, jac_to_aff<FOps2>(acc));
+    return OK;
+}
+
 // ---- constants -----------------------------------------------------------------------------------------------------
 int hexval(char c) { return c <= '9' ? c - '0' : (c | 32) - 'a' + 10; }
 Fp fp_hex(const char* s) {  // plain integer < p in hex -> Montgomery
@@ -969,6 +1006,46 @@ int cbls_pairing(const u8* p48, const u8* q96, u8* out576) {
     if (st) return st;
     f12_to_bytes(final_exponentiation(miller_loop(&p, &q, 1)), out576);
     return 0;
+}
+
+int cbls_aggregate_verify(const u8* pks48, uint32_t n_pks, const u8* msgs, const u64* msg_off, uint32_t n_msgs, const u8* sig96) {
+    init_constants();
+    return aggregate_verify(pks48, n_pks, msgs, msg_off, n_msgs, sig96);
+}
+int cbls_aggregate_sigs(const u8* sigs96, uint32_t n, u8* out96) {
+    init_constants();
+    return aggregate_sigs(sigs96, n, out96);
+}
+// sum_i [k_i] P_i by plain double-and-add (the definition), k_i = 32 big-endian bytes; points are validated keys / decoded
+// group-checked signatures; returns the first failing point's status
+int cbls_g1_msm(const u8* pks48, const u8* scalars32, uint32_t n, u8* out48) {
+    init_constants();
+    J1 acc = jac_inf<FOps1>();
+    for (uint32_t i = 0; i < n; i++) {
+        A1 p;
+        int st = key_validate(p, pks48 + 48 * (size_t)i);
+        if (st) return st;
+        u64 k[4];
+        scalar_from_be32(scalars32 + 32 * (size_t)i, k);
+        acc = jac_add<FOps1>(acc, jac_mul<FOps1>(jac_from_aff<FOps1>(p), k, 4));
+    }
+    g1_compress(out48, jac_to_aff<FOps1>(acc));
+    return OK;
+}
+int cbls_g2_msm(const u8* sigs96, const u8* scalars32, uint32_t n, u8* out96) {
+    init_constants();
+    J2 acc = jac_inf<FOps2>();
+    for (uint32_t i = 0; i < n; i++) {
+        A2 q;
+        int st = g2_decompress(q, sigs96 + 96 * (size_t)i);
+        if (st) return st;
+        if (!q.inf && !g2_in_subgroup(q)) return NOT_IN_GROUP;
+        u64 k[4];
+        scalar_from_be32(scalars32 + 32 * (size_t)i, k);
+        acc = jac_add<FOps2>(acc, jac_mul<FOps2>(jac_from_aff<FOps2>(q), k, 4));
+    }
+    g2_compress(out96, jac_to_aff<FOps2>(acc));
+    return OK;
 }
 
 }  // extern "C"

@@ -27,6 +27,10 @@ def lib():
         L.cbls_sk_to_pk.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         L.cbls_sign.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
         L.cbls_pairing.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+        L.cbls_aggregate_verify.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
+        L.cbls_aggregate_sigs.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p]
+        L.cbls_g1_msm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p]
+        L.cbls_g2_msm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p]
         L.cbls_init()
         _lib = L
     return _lib
@@ -84,3 +88,31 @@ def pairing(p48: bytes, q96: bytes):
     if st:
         return st
     return [int.from_bytes(out.raw[48 * i:48 * i + 48], "big") for i in range(12)]
+
+
+def aggregate_verify(pks, msgs, sig: bytes) -> int:
+    """crypto/bls.rs:95-112 -> status (include/ecgpu.h numbering)"""
+    off = [0]
+    for m in msgs:
+        off.append(off[-1] + len(m))
+    arr = (ctypes.c_uint64 * len(off))(*off)
+    return lib().cbls_aggregate_verify(b"".join(pks), len(pks), b"".join(msgs), arr, len(msgs), sig) & 0xFF
+
+
+def aggregate(sigs):
+    """crypto/bls.rs:79-93 for a non-empty list -> (status, 96 bytes or None)"""
+    out = ctypes.create_string_buffer(96)
+    st = lib().cbls_aggregate_sigs(b"".join(sigs), len(sigs), out)
+    return st, (out.raw if st == 0 else None)
+
+
+def g1_msm(pks, scalars):
+    out = ctypes.create_string_buffer(48)
+    st = lib().cbls_g1_msm(b"".join(pks), b"".join(int(k).to_bytes(32, "big") for k in scalars), len(pks), out)
+    return st, (out.raw if st == 0 else None)
+
+
+def g2_msm(sigs, scalars):
+    out = ctypes.create_string_buffer(96)
+    st = lib().cbls_g2_msm(b"".join(sigs), b"".join(int(k).to_bytes(32, "big") for k in scalars), len(sigs), out)
+    return st, (out.raw if st == 0 else None)

@@ -143,6 +143,99 @@ def S(tag, i):
     return hashlib.sha256(b"ecgpu/v1/" + tag + b"/" + i.to_bytes(4, "little")).digest()
 
 
+def _aggregate_signature(gpu, sks, msgs):
+    """sum_i [sk_i] H(m_i) via the device: per-tuple signatures, then crypto::aggregate"""
+    sigs = gpu.sign_batch(b"".join(sk_bytes(s) for s in sks), msgs)
+    return gpu.aggregate([sigs[96 * i:96 * i + 96] for i in range(len(sks))])
+
+
+@pytest.mark.parametrize("n", [64, 1000])
+def test_aggregate_verify_at_size(gpu, n):
+    """crypto/bls.rs:95-112 at n = 64 and 1 000 (round 2 stopped at 3): one Miller loop per lane (k_miller_pairs), the product of
+    n + 1 Miller values in 64 stripes and the final exponentiation (k_aggv_final) -- with duplicate messages, a message of
+    another length, a bad key in the middle (first failing key wins), a key list longer than the message list, a wrong
+    message.  Every case against the C++ oracle (oracle/c/bls12_381.cpp aggregate_verify, pinned to the Python oracle in
+    tests/test_oracle_cbls.py)."""
+    from ethereum_consensus_amd import synthetic as syn
+    from oracle import cbls
+    sks = [1 + int.from_bytes(S(b"aggv", i), "big") % (B.R - 1) for i in range(n)]
+    pk_all = gpu.sk_to_pk_batch(b"".join(sk_bytes(s) for s in sks))
+    pks = [pk_all[48 * i:48 * i + 48] for i in range(n)]
+    msgs = [S(b"aggv-msg", i) for i in range(n)]
+    msgs[5] = msgs[3]            # duplicate messages (blst's aggregate_verify does not require distinct ones)
+    msgs[n - 1] = msgs[3]
+    msgs[7] = b"short"
+    sig = _aggregate_signature(gpu, sks, msgs)
+    off_pk = syn.off_subgroup_public_key(1)
+    wrong = list(msgs)
+    wrong[n // 2] = S(b"aggv-msg", 10 ** 6)
+    swapped = list(msgs)
+    swapped[0], swapped[1] = swapped[1], swapped[0]
+    cases = [(pks, msgs, sig), (pks, wrong, sig), (pks, swapped, sig),
+             (pks[:n // 2] + [off_pk] + pks[n // 2 + 1:], msgs, sig),                                # a key outside G1 mid-list
+             (pks[:3] + [B.INFINITY_PUBLIC_KEY] + pks[4:n // 2] + [off_pk] + pks[n // 2 + 1:], msgs, sig),  # the FIRST failing key wins
+             (pks, msgs[:-1], sig), (pks[:-1], msgs, sig),                                             # n_pks != n_msgs
+             (pks, msgs, syn.off_subgroup_signature(0)), (pks, msgs, B.INFINITY_SIGNATURE)]
+    for p, m, s in cases:
+        assert gpu.aggregate_verify_status(p, m, s) == cbls.aggregate_verify(p, m, s), (len(p), len(m))
+    assert gpu.aggregate_verify_status(pks, msgs, sig) == 0 and gpu.aggregate_verify_status(pks, wrong, sig) == B.BLST_VERIFY_FAIL
+
+
+def test_aggregate_of_65536_signatures(gpu):
+    """crypto/bls.rs:79-93 at n = 65 536 (round 2: 70): decode + group check of every signature (k_sig), the first failure in
+    list order by a parallel reduction (k_agg_sig_status), the 256-lane strided sum.  The sum of all signatures over ONE
+    message equals sign(sum of keys); one signature outside G2 near the end -> POINT_NOT_IN_GROUP; an undecodable one after
+    it wins over it (every signature is decoded before any is group-checked).  C++ oracle on a 4 096-signature slice."""
+    from ethereum_consensus_amd import synthetic as syn
+    from oracle import cbls
+    n = 65536
+    skb = syn.bls_secret_keys(n)
+    msg = S(b"agg65536", 0)
+    sig_all = gpu.sign_batch(skb, [msg] * n)
+    sigs = [sig_all[96 * i:96 * i + 96] for i in range(n)]
+    total = sum(int.from_bytes(skb[32 * i:32 * i + 32], "big") for i in range(n)) % B.R
+    assert gpu.aggregate_status(sigs) == (0, gpu.sign_batch(sk_bytes(total), [msg]))
+    off = syn.off_subgroup_signature(2)
+    bad = list(sigs)
+    bad[n - 3] = off
+    assert gpu.aggregate_status(bad)[0] == B.BLST_POINT_NOT_IN_GROUP
+    bad[n - 2] = bytes([0x9F]) + b"\xff" * 47 + bytes(48)   # x >= p: BAD_ENCODING, found by the decoding pass first
+    assert gpu.aggregate_status(bad)[0] == B.BLST_BAD_ENCODING
+    r = random.Random(5)
+    while True:  # an x with no point above it: POINT_NOT_ON_CURVE, a different code than the BAD_ENCODING further down the list
+        cand = bytes([0x80 | r.randrange(0x10)]) + r.randbytes(95)
+        if B.aggregate([cand])[0] == B.BLST_POINT_NOT_ON_CURVE:
+            break
+    bad[100] = cand                                         # the FIRST undecodable one in list order wins
+    assert gpu.aggregate_status(bad)[0] == B.BLST_POINT_NOT_ON_CURVE
+    part = sigs[1000:1000 + 4096]
+    assert gpu.aggregate_status(part) == cbls.aggregate(part)
+    part[4000] = off
+    assert gpu.aggregate_status(part) == cbls.aggregate(part)
+
+
+def test_multi_scalar_multiplication_4096_points_255_bit_scalars(gpu):
+    """north_star "multi-scalar-mult" at n = 4 096 with 255-bit scalars (round 2: 37 points) against the C++ oracle's plain
+    double-and-add sums, G1 and G2, with a zero scalar, a repeated point and the identity among the inputs."""
+    from ethereum_consensus_amd import bls as M
+    from ethereum_consensus_amd import synthetic as syn
+    from oracle import cbls
+    r = random.Random(4096)
+    n = 4096
+    skb = syn.bls_secret_keys(n)
+    pk_all = gpu.sk_to_pk_batch(skb)
+    pks = [pk_all[48 * i:48 * i + 48] for i in range(n)]
+    pks[17] = pks[16]
+    ks = [r.randrange(1, 1 << 255) for _ in range(n)]
+    ks[3] = 0
+    assert (0, M.g1_multi_scalar_mul(pks, ks, 255)) == cbls.g1_msm(pks, ks)
+    n2 = 1024
+    sig_all = gpu.sign_batch(skb[:32 * n2], [S(b"msm", i % 7) for i in range(n2)])
+    sigs = [sig_all[96 * i:96 * i + 96] for i in range(n2)]
+    sigs[9] = B.INFINITY_SIGNATURE
+    assert (0, M.g2_multi_scalar_mul(sigs, ks[:n2], 255)) == cbls.g2_msm(sigs, ks[:n2])
+
+
 def test_batch_4096_with_fault_injection(gpu):
     """SURVEY.md 8(d) config-2 shape at a size the GPU finishes in well under a second: K = 1 tuples
     generated on the device (sk -> pk, sign), every 16th tuple corrupted; the expected status of each

@@ -31,6 +31,10 @@ def test_sha256(gpu):
     for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000):
         d = rnd(n, n)
         assert gpu.hash(d) == hashlib.sha256(d).digest()
+    # crypto::hash takes any length (crypto/bls.rs:12-20): one lane walks 16 385 blocks of a 1 MiB input; block-boundary lengths
+    for n in (1 << 20, (1 << 20) - 9, (1 << 20) + 55):
+        d = rnd(n, 7)
+        assert gpu.hash(d) == hashlib.sha256(d).digest(), n
 
 
 def test_reference_fixtures(gpu):

@@ -69,3 +69,41 @@ def test_config2_fault_cycle_batch_threads():
     assert sorted({k for k in kind_of if k != 255}) == list(range(8))
     for i in list(range(0, n, 64))[:8] + [1, 65]:
         assert B.fast_aggregate_verify([bytes(pks[48 * i:48 * i + 48])], bytes(msgs[32 * i:32 * i + 32]), bytes(sigs[96 * i:96 * i + 96])) == got[i]
+
+
+def test_aggregate_verify_aggregate_and_msm_equal_the_python_oracle():
+    """The round-3 additions to the C++ restatement (checkers for the GPU tests at n = 64 .. 65 536, where the Python oracle is
+    too slow): aggregate_verify (crypto/bls.rs:95-112), aggregate (:79-93) and the multi-scalar sums, case by case against
+    oracle/bls12_381.py."""
+    r = random.Random(5)
+    sks = [r.randrange(1, B.R) for _ in range(4)]
+    pks = [B.sk_to_pk(s) for s in sks]
+    msgs = [r.randbytes(32), r.randbytes(5), b"", r.randbytes(32)]
+    msgs[3] = msgs[0]  # a duplicate message
+    pts = [B.g2_mul(B.hash_to_g2(m), s) for s, m in zip(sks, msgs)]
+    acc = None
+    for p in pts:
+        acc = B.g2_add(acc, p)
+    sig = B.g2_compress(acc)
+    off_pk, off_sig = syn.off_subgroup_public_key(0), syn.off_subgroup_signature(0)
+    cases = [(pks, msgs, sig), (pks, msgs[::-1], sig), (pks[:3], msgs[:3], sig), (pks, msgs[:3], sig), ([], [], sig),
+             (pks[:1] + [B.INFINITY_PUBLIC_KEY] + pks[2:], msgs, sig), (pks[:2] + [off_pk] + pks[3:], msgs, sig), (pks, msgs, bytes(96)),
+             (pks, msgs, off_sig), (pks, msgs, B.INFINITY_SIGNATURE), (pks[:1], msgs[:1], B.g2_compress(pts[0]))]
+    for p, m, s in cases:
+        assert cbls.aggregate_verify(p, m, s) == B.aggregate_verify(p, m, s) & 0xFF, (len(p), len(m))
+    sigs = [B.g2_compress(p) for p in pts]
+    for lst in (sigs, sigs[:1], [sigs[0], B.INFINITY_SIGNATURE], [B.INFINITY_SIGNATURE], [sigs[0], off_sig, sigs[1]], [off_sig, bytes(96)],
+                [sigs[0], bytes(96), off_sig]):
+        assert cbls.aggregate(lst) == B.aggregate(lst)
+    ks = [r.randrange(0, 1 << 255) for _ in range(4)]
+    ks[1] = 0
+    want1 = None
+    for k, s in zip(ks, sks):
+        want1 = B.g1_add(want1, B.g1_mul(B.G1, k * s % B.R))
+    assert cbls.g1_msm(pks, ks) == (0, B.g1_compress(want1))
+    want2 = None
+    for k, p in zip(ks, pts):
+        want2 = B.g2_add(want2, B.g2_mul(p, k))
+    assert cbls.g2_msm(sigs, ks) == (0, B.g2_compress(want2))
+    assert cbls.g1_msm(pks[:1] + [off_pk], ks[:2])[0] == B.BLST_POINT_NOT_IN_GROUP
+    assert cbls.g2_msm([sigs[0], off_sig], ks[:2])[0] == B.BLST_POINT_NOT_IN_GROUP

@@ -6,6 +6,7 @@
 #   bench:<args>     python bench.py <args> (underscores for spaces) -> gpurun_out/<tag>_bench_<args>.json
 #   probe[:sizes]    tools/bls_probe.py stage timing                 -> gpurun_out/<tag>_probe.txt
 #   stats            rocprofv3 --kernel-trace --stats of the bench   -> gpurun_out/<tag>_kernel_stats.txt
+#   sq               SQ counters per wave of the stage kernels       -> gpurun_out/<tag>_sq_counters.txt
 #   pmc              FETCH_SIZE / WRITE_SIZE passes of the bench     -> gpurun_out/<tag>_pmc_{fetch,write}.txt
 #   lib:<name>       following steps use lib/libecgpu_<name>.so (tools/build_variant.sh); lib: alone switches back
 #   env:<K=V>        export K=V for the following steps (unenv:<K> removes it)
@@ -39,6 +40,11 @@ for step in "$@"; do
            python tools/pmc_summary.py gpurun_out/pmc_${tag}_$c gpurun_out/${tag}${sfx}_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_pmc_$c.txt | cut -c1-160
            rm -rf gpurun_out/pmc_${tag}_$c
          done;;
+    sq) P1="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INSTS_LDS"
+        timeout 900 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-aggregates --workload bls > gpurun_out/${tag}${sfx}_sq.log 2>&1
+        python tools/pmc_summary.py gpurun_out/pmc_${tag}_sq gpurun_out/${tag}${sfx}_sq_raw.txt
+        python tools/sq_digest.py gpurun_out/${tag}${sfx}_sq_raw.txt | tee gpurun_out/${tag}${sfx}_sq_counters.txt
+        rm -rf gpurun_out/pmc_${tag}_sq;;
     pmc_merkle) for c in FETCH_SIZE WRITE_SIZE; do
            timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_m_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload merkle > gpurun_out/${tag}${sfx}_merkle_pmc_$c.log 2>&1
            python tools/pmc_summary.py gpurun_out/pmc_${tag}_m_$c gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt | cut -c1-160
