@@ -21,7 +21,6 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libecgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-VM2_GEN_ARGS = os.environ.get("ECGPU_VM2_GEN_ARGS", "--lanes 16 --window 200").split()
 VM3_GEN_ARGS = os.environ.get("ECGPU_VM3_GEN_ARGS", "--lanes 16 --lanes-c 12 --window 60").split()
 # -pragma-unroll-threshold: the sums of products (bls_fp.h fp_sumprod) are 13 rows x up to 13 x 13 multiply-adds that
 # must be fully unrolled for their column accumulators to stay in registers; the default threshold stops at ~1000.
@@ -48,7 +47,7 @@ _INC = None
 
 
 def _deps(src: str, seen=None):
-    """files `src` includes with quotes, transitively (the .hip second-build units include a .hip; ECG_VM2_PROG_HEADER is a
+    """files `src` includes with quotes, transitively (the .hip second-build units include a .hip; ECG_VM3_PROG_HEADER is a
     macro include): an edit to one header rebuilds only the objects that see it"""
     import re
     global _INC
@@ -60,8 +59,6 @@ def _deps(src: str, seen=None):
     seen.add(src)
     text = open(src).read()
     names = _INC.findall(text)
-    if "ECG_VM2_PROG_HEADER" in text:
-        names.append("bls_vm2_prog.h")
     if "ECG_VM3_PROG_HEADER" in text:
         names.append("bls_vm3_prog.h")
     for n in names:
@@ -83,9 +80,9 @@ def _run(cmd):
 
 
 def generate_vm_programs(verbose: bool = True) -> str:
-    """csrc/bls_vm2_prog.h (generated tables) is produced by tools/gen_bls_vm2.py, not committed."""
+    """csrc/bls_vm3_prog.h (generated tables) is produced by tools/gen_bls_vm3.py, not committed."""
     out = None
-    for script, header, gen_args in (("gen_bls_vm2.py", "bls_vm2_prog.h", VM2_GEN_ARGS), ("gen_bls_vm3.py", "bls_vm3_prog.h", VM3_GEN_ARGS)):
+    for script, header, gen_args in (("gen_bls_vm3.py", "bls_vm3_prog.h", VM3_GEN_ARGS),):
         gen = os.path.join(ROOT, "tools", script)
         out = os.path.join(CSRC, header)
         stamp = out + ".args"
@@ -132,7 +129,7 @@ def build_lib(verbose: bool = True) -> str:
 
 def build_hostsim(verbose: bool = True, variant: str = "") -> str:
     """g++ build of the same csrc headers: CPU-side kernel simulator for tests ONLY.  variant "calls": the compact-code
-    tower of the slow-box pairing kernels (-DECG_TOWER_CALLS), a library of its own."""
+    build of the G2 stage kernels (-DECG_TOWER_CALLS), a library of its own."""
     d = os.path.join(ROOT, "tests", "hostsim")
     generate_vm_programs(verbose)
     srcs = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".cpp"))

@@ -30,10 +30,7 @@
 
 namespace ecg {
 
-int init_bls_tables(hipStream_t) {
-    int rc = init_vm2_tables();
-    return rc ? rc : init_vm3_tables();
-}
+int init_bls_tables(hipStream_t) { return init_vm3_tables(); }
 
 // ---- stage kernels ---------------------------------------------------------------------------
 static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }
@@ -235,30 +232,27 @@ static const u32 g_h2c_split_max = [] {
     return e ? (u32)strtoul(e, nullptr, 10) : 32768u;
 }();
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
-    const size_t xf = vm2_xfer_bytes(n) > vm3_xfer_bytes(n) ? vm2_xfer_bytes(n) : vm3_xfer_bytes(n);
+    const size_t xf = vm3_xfer_bytes(n);
     const size_t maps = n <= g_h2c_split_max ? (size_t)2 * n * sizeof(J2) + 256 : 0;
     return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + xf + maps + 8192;
 }
-// Which kernels run the pairing check.  The lane kernel (one lane per tuple, state in VGPRs/AGPRs + private segment)
-// has the best throughput but one tuple's check is a 35 ms dependent chain, so a batch of a few thousand tuples
-// leaves most SIMDs idle; the lane-group Fp2 VM (bls_vm2.hip, 16 lanes per tuple) has a third of the throughput and
-// a quarter of the latency.  ECGPU_PAIRING = auto (default: VM below ECGPU_VM2_MAX tuples) | lane | vm2.
+// Which kernels run the pairing check.  The lane kernel (one lane per tuple, state in VGPRs/AGPRs + LDS lane slots + private
+// segment) has the best throughput but one tuple's check is a 24 ms dependent chain, so a batch of a few thousand tuples
+// leaves most SIMDs idle; the sum-of-products lane groups (bls_vm3.hip, 16 / 12 lanes per tuple, 47 KB of code) have 60 % of
+// its throughput at a seventh of its latency.  ECGPU_PAIRING = auto (default: lane groups up to ECGPU_VM_MAX tuples and on
+// boxes with slow instruction fetch) | lane | vm3.  (Round 2 shipped two more -- Fp2 lane groups, a compact-code lane
+// kernel -- which the lane groups beat at every size on every box; removed in round 3.)
 static const int g_pairing_mode = [] {
     const char* e = getenv("ECGPU_PAIRING");
     if (e && !strcmp(e, "lane")) return 0;
-    if (e && !strcmp(e, "vm2")) return 2;
     if (e && !strcmp(e, "vm3")) return 4;
     return 3;
 }();
-// auto mode: which lane-group VM small batches use (ECGPU_SMALL_VM=vm2|vm3)
-static const int g_small_vm = [] {
-    const char* e = getenv("ECGPU_SMALL_VM");
-    return (e && !strcmp(e, "vm2")) ? 2 : 3;
-}();
-// Which tower the lane pairing kernels run on: 1 = sums of products (bls_pairing_kernels.hip), 2 = the compact-code tower
-// (bls_pairing_kernels_calls.hip).  ECGPU_TOWER=sums|calls forces one; otherwise the box self-check decides once per
-// process: where a 1 MB loop of multiply-adds runs more than 1.5x slower than an 8 KB one, instruction fetch does not
-// keep up with megabytes of straight-line code and the compact kernels win.
+// Which build of the G2 stage kernels runs: 1 = sums of products (bls_g2_kernels.hip), 2 = the compact-code tower
+// (bls_g2_kernels_calls.hip).  ECGPU_TOWER=sums|calls forces one; otherwise the box self-check decides once per process:
+// where a 1 MB loop of multiply-adds runs more than 1.5x slower than an 8 KB one, instruction fetch does not keep up with
+// megabytes of straight-line code: the compact G2 kernels win there, and the pairing check goes to the lane groups at every
+// batch size.
 static std::atomic<int> g_tower{0};
 static int decide_tower() {
     int t = g_tower.load();
@@ -276,16 +270,14 @@ static int decide_tower() {
     g_tower.store(t);
     return t;
 }
-// which kernels ran the pairing check of this thread's last batch: 1 = lane kernel (k_pairing[_calls]), 2 = Fp2 lane groups
-// (bls_vm2.hip; tuples with a point at infinity still go through the lane kernel), 3 = Fp lane groups (bls_vm3.hip)
+// which kernels ran the pairing check of this thread's last batch: 1 = lane kernel (k_pairing), 3 = lane groups (bls_vm3.hip)
 static thread_local int t_last_pairing_path = 0;
-// batch size up to which the lane groups run the pairing check in auto mode.  Measured (profiles/r02f_vm3_timing.txt, healthy
-// box): sum-of-products groups 4.1 / 10.5 / 56.7 ms at 2 048 / 8 192 / 65 536 tuples, Fp2 groups 8.1 / 21.3 / 126, lane
-// kernel 27 .. 31 flat -- the groups win up to ~32 k tuples (26.4 ms at 32 768 after the register-file work, profiles/r02g_vm3_timing.txt).  On a box whose instruction fetch is slow (compact-code build
-// selected: the lane kernel takes 52 ms) the sum-of-products groups, 47 KB of code, win at every size.
-static const u32 g_vm2_max_tuples = [] {
-    const char* e = getenv("ECGPU_VM2_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : (g_small_vm == 3 ? 32768u : 12288u);
+// batch size up to which the lane groups run the pairing check in auto mode.  Measured (profiles/r02g_vm3_timing.txt, healthy
+// box): lane groups 4.1 / 10.5 / 26.4 ms at 2 048 / 8 192 / 32 768 tuples, lane kernel 24 .. 25 flat (round 3): the groups win
+// up to ~24 k tuples.  On a box whose instruction fetch is slow they win at every size.
+static const u32 g_vm_max_tuples = [] {
+    const char* e = getenv("ECGPU_VM_MAX");
+    return e ? (u32)strtoul(e, nullptr, 10) : 24576u;
 }();
 
 }  // namespace ecg
@@ -404,21 +396,17 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     }
     {
         ProfScope ps("bls_pairing", s);
-        const bool slow_box = g_tower.load() == 2 && g_small_vm == 3;  // large-code kernels crawl here: the 47 KB kernel at every size
-        const bool auto_vm = g_pairing_mode == 3 && (n <= g_vm2_max_tuples || slow_box);
-        const bool use_vm3 = g_pairing_mode == 4 || (auto_vm && g_small_vm == 3);
-        const bool use_vm = use_vm3 || g_pairing_mode == 2 || auto_vm;
-        t_last_pairing_path = use_vm3 ? 3 : use_vm ? 2 : 1;
-        if (!use_vm) {
-            hipLaunchKernelGGL(g_tower.load() == 2 ? k_pairing_calls : k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg,
-                               (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96,
-                               n, eth_variant, d_status);
+        const bool slow_box = g_tower.load() == 2;  // large-code kernels crawl here: the 47 KB kernel at every size
+        const bool use_vm3 = g_pairing_mode == 4 || (g_pairing_mode == 3 && (n <= g_vm_max_tuples || slow_box));
+        t_last_pairing_path = use_vm3 ? 3 : 1;
+        if (!use_vm3) {
+            hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
+                               (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status);
         } else {
-            u32* xfer = (u32*)ar.take(use_vm3 ? vm3_xfer_bytes(n) : vm2_xfer_bytes(n));
+            u32* xfer = (u32*)ar.take(vm3_xfer_bytes(n));
             if (!xfer) return ECGPU_ERR_OOM;
-            int rc = (use_vm3 ? vm3_pairing_launch : vm2_pairing_launch)(s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
-                                                                         (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n,
-                                                                         eth_variant, d_status, xfer);
+            int rc = vm3_pairing_launch(s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec,
+                                        (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
             if (rc) return rc;
             // (tuples whose pairing involves a point at infinity are decided in the lane groups' status step: such a pair
             // contributes 1, and a single non-degenerate pair cannot be 1)
@@ -629,10 +617,10 @@ int ecgpu_aggregate_verify(const uint8_t* pks48, uint32_t n_pks, const uint8_t* 
     hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(1), dim3(BLS_BLOCK), 0, k.s, d_sig, 1u, sigpt, st_dec, st_grp);
     if (npair) {
         hipLaunchKernelGGL(g_tower.load() == 2 ? k_h2c_calls : k_h2c, grid_for(nm), dim3(BLS_BLOCK), 0, k.s, d_msgs, (const u64*)d_moff, nm, hpts);
-        hipLaunchKernelGGL(g_tower.load() == 2 ? k_miller_pairs_calls : k_miller_pairs, grid_for(npair + 1), dim3(BLS_BLOCK), 0, k.s,
+        hipLaunchKernelGGL(k_miller_pairs, grid_for(npair + 1), dim3(BLS_BLOCK), 0, k.s,
                            (const A1*)pts, (const A2*)hpts, (const A2*)sigpt, npair, fs);
     }
-    hipLaunchKernelGGL(g_tower.load() == 2 ? k_aggv_final_calls : k_aggv_final, dim3(1), dim3(BLS_BLOCK), 0, k.s, (const u8*)st, np, nm,
+    hipLaunchKernelGGL(k_aggv_final, dim3(1), dim3(BLS_BLOCK), 0, k.s, (const u8*)st, np, nm,
                        (const u8*)st_dec, (const u8*)st_grp, fs, d_status);
     ECG_HIP_CHECK(hipGetLastError());
     u8 out = 0xff;

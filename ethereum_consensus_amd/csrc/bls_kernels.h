@@ -11,8 +11,6 @@ constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches 
                          // (re-measured after every restructuring)
 #endif
 
-// status-byte marker inside the Fp2 lane-group kernels: a point at infinity is involved (decided in their status step)
-constexpr u8 VM_NEEDS_LANE_PATH = 0xFE;
 
 // bls_g1_kernels.hip / bls_g1_kernels_w2.hip: the key stage with room for one / two waves per SIMD
 __global__ void k_pk_validate_w1(const u8* pks48, u32 n, A1* pts, u8* st);
@@ -33,11 +31,5 @@ __global__ void k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, con
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out);
 __global__ void k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);
 __global__ void k_aggv_final(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, Fp12* fs, u8* status_out);
-
-// bls_pairing_kernels_calls.hip: the same three kernels on the compact-code tower
-__global__ void k_pairing_calls(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
-                                const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out);
-__global__ void k_miller_pairs_calls(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);
-__global__ void k_aggv_final_calls(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, Fp12* fs, u8* status_out);
 
 }  // namespace ecg

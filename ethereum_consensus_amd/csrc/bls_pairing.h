@@ -101,31 +101,6 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
     m.t.z = fp2_one();
 }
 
-#if defined(ECG_TOWER_CALLS)
-// T <- 2T, f <- f * line_{T,T}(P); T = running point of pair k (lane slots).  Textbook dbl-2009-l (compact-code tower).
-ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, const MillerPair& m, int k) {
-    const J2 T = slot_load_point(k);
-    Fp2 A = fp2_sqrx(T.x);
-    Fp2 B = fp2_sqrx(T.y);
-    Fp2 C = fp2_sqrx(B);
-    Fp2 D = fp2_dbl(fp2_sub(fp2_sub(fp2_sqrx(fp2_add(T.x, B)), A), C));
-    Fp2 E = fp2_mul3(A);
-    Fp2 Fq = fp2_sqrx(E);
-    Fp2 ZZ = fp2_sqrx(T.z);
-    Fp2 Z3 = fp2_dbl(fp2_mulx(T.y, T.z));
-    Fp2 l0 = fp2_sub(fp2_mulx(E, T.x), fp2_dbl(B));
-    Fp2 l1 = fp2_neg(fp2_mul_fp(fp2_mulx(E, ZZ), m.px));
-    Fp2 l2 = fp2_mul_fp(fp2_mulx(Z3, ZZ), m.py);
-    Fp2 X3 = fp2_sub(Fq, fp2_dbl(D));
-    Fp2 C8 = fp2_dbl(fp2_dbl(fp2_dbl(C)));
-    J2 R;
-    R.y = fp2_sub(fp2_mulx(E, fp2_sub(D, X3)), C8);
-    R.x = X3;
-    R.z = Z3;
-    slot_store_point(k, R);
-    fp12_mul_by_line<2>(f, l0, l1, l2);
-}
-#else
 // T <- 2T, f <- f * line_{T,T}(P); T = running point of pair k, read from the lane slots where it is used.
 // The dbl-2009-l quantities regrouped as in jac_dbl_inl (bls_curve.h) so that no modular addition touches a product:
 //   A = X^2, B = Y^2, ZZ = Z^2, E = 3A (lazy), D = (4X) B,
@@ -163,7 +138,6 @@ ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, const MillerPair& m, int k) {
     slot_store2(sy, Y3);
     fp12_mul_by_line<6>(f, l0, l1, l2);
 }
-#endif
 
 // T <- T + Q, f <- f * line_{T,Q}(P)
 ECG_HD void miller_add_step_inl(Fp12& f, const MillerPair& m, int k) {
@@ -255,15 +229,7 @@ ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
     for (int b = 62; b >= 0; b--) {
         fp12_cyclotomic_sqr_inl(acc, acc);
         if ((blsc::X_ABS >> b) & 1) {
-#if defined(ECG_POW_PRODUCT_CALL)
-            // round-2 form (the product out of line, the running value through the private segment), kept as a build switch:
-            // round 2 saw a kernel with the product inlined here that did not terminate on the device
-            Fp12 t = acc, base = slot_load_fp12();
-            fp12_mul(t, t, base);
-            acc = t;
-#else
             fp12_mul_by_slots_inl(acc, acc);
-#endif
         }
     }
     fp12_conj(acc, acc);

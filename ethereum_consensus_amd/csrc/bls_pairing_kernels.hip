@@ -6,17 +6,12 @@
 // (the e(pk, H(m)) == e(g1, sig) equation of /root/reference/ethereum-consensus/src/crypto/bls.rs:71,106,126)
 #include "bls_kernels.h"
 
-// bls_pairing_kernels_calls.hip compiles this file a second time with -DECG_TOWER_CALLS semantics (the compact-code tower)
-// and the kernel names suffixed.
-#ifndef ECG_KN
-#define ECG_KN(name) name
-#endif
 
 namespace ecg {
 
 // fast_aggregate_verify tuple i: status algebra + pairing equation.
 // k_of: number of keys of tuple i = pk_off ? pk_off[i+1]-pk_off[i] : 1.
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_pairing)(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts,
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts,
                                                         const A2* sigpts, const u8* st_dec, const u8* st_grp, const u8* sigs96,
                                                         u32 n, int eth_variant, u8* status_out) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
@@ -36,7 +31,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_pairing)(co
 }
 
 // ---- aggregate_verify: one Miller loop per lane, product + final exponentiation on one lane ------
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_miller_pairs)(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs) {
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i > n) return;
     MillerPair pr;
@@ -60,7 +55,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_miller_pair
 // One workgroup of 64 lanes: the first failing key in list order by atomicMin (as k_sum does), the Miller values multiplied in
 // 64 stripes (lane t: fs[t] fs[t + 64] ...; in place), then lane 0 multiplies the stripe products and runs the final
 // exponentiation: n / 64 + 64 dependent Fp12 products instead of n (round 2: everything on one lane).
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_aggv_final)(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp,
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_aggv_final(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp,
                                                            Fp12* fs, u8* status_out) {
     if (blockIdx.x != 0) return;
     __shared__ u32 first_bad;

@@ -55,23 +55,6 @@ ECG_HD void fp6_mul_v(Fp6& r, const Fp6& a) {
     r.c1 = a.c0;
     r.c0 = t;
 }
-#if defined(ECG_TOWER_CALLS)
-// COMPACT-CODE variant: Karatsuba core, 6 Fp2 products (each three out-of-line Fp products), operands in registers.
-// Operand components may be lazy sums < 4p (the inner pre-sums are < 8p into fp2_mul, which allows 8p).
-template <int KA, int KB>
-ECG_HD void fp6_mul_lazy(Fp6& r, const Fp2& a0, const Fp2& a1, const Fp2& a2, const Fp2& b0, const Fp2& b1, const Fp2& b2) {
-    static_assert(KA <= 4 && KB <= 4, "Karatsuba core: operand components < 4p");
-    Fp2 t0 = fp2_mulx(a0, b0);
-    Fp2 t1 = fp2_mulx(a1, b1);
-    Fp2 t2 = fp2_mulx(a2, b2);
-    Fp2 m12 = fp2_mulx(fp2_add_lazy(a1, a2), fp2_add_lazy(b1, b2));
-    Fp2 m01 = fp2_mulx(fp2_add_lazy(a0, a1), fp2_add_lazy(b0, b1));
-    Fp2 m02 = fp2_mulx(fp2_add_lazy(a0, a2), fp2_add_lazy(b0, b2));
-    r.c0 = fp2_add(t0, fp2_mul_xi(fp2_sub(fp2_sub(m12, t1), t2)));
-    r.c1 = fp2_add(fp2_sub(fp2_sub(m01, t0), t1), fp2_mul_xi(t2));
-    r.c2 = fp2_add(fp2_sub(fp2_sub(m02, t0), t2), t1);
-}
-#else
 // Schoolbook with lazy reduction: every Fp2 coefficient of the result is ONE sum of three Fp2 products (xi folded
 // into the a operands, the minus signs of the Fp2 products into lazily negated b components): 36 half-products and 6
 // reductions, no linear operation on any result (measured 48.7 k cycles against 65.0 k for Karatsuba over 18 reduced
@@ -105,7 +88,6 @@ ECG_HD void fp6_mul_lazy(Fp6& r, const Fp2& a0, const Fp2& a1, const Fp2& a2, co
     r.c1 = c1;
     r.c2 = c2;
 }
-#endif
 // r may alias a or b (operands are loaded before the result is stored).
 ECG_FP6_FN void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
     const Fp2 a0 = a.c0, a1 = a.c1, a2 = a.c2, b0 = b.c0, b1 = b.c1, b2 = b.c2;
@@ -116,20 +98,12 @@ ECG_FP6_FN void fp6_mul_sums(Fp6& r, const Fp6& a0, const Fp6& a1, const Fp6& b0
     fp6_mul_lazy<4, 4>(r, fp2_add_lazy(a0.c0, a1.c0), fp2_add_lazy(a0.c1, a1.c1), fp2_add_lazy(a0.c2, a1.c2), fp2_add_lazy(b0.c0, b1.c0),
                        fp2_add_lazy(b0.c1, b1.c1), fp2_add_lazy(b0.c2, b1.c2));
 }
-#if defined(ECG_TOWER_CALLS)
-// r = (a0 + a1)(a0 + v a1): the first product of the complex squaring (xi a1.c2 reduced: every operand < 4p).
-ECG_FP6_FN void fp6_mul_sqr_sums(Fp6& r, const Fp6& a0, const Fp6& a1) {
-    fp6_mul_lazy<4, 4>(r, fp2_add_lazy(a0.c0, a1.c0), fp2_add_lazy(a0.c1, a1.c1), fp2_add_lazy(a0.c2, a1.c2),
-                       fp2_add_lazy(a0.c0, fp2_mul_xi(a1.c2)), fp2_add_lazy(a0.c1, a1.c0), fp2_add_lazy(a0.c2, a1.c1));
-}
-#else
 // r = (a0 + a1)(a0 + v a1): the first product of the complex squaring.  First operand < 4p; second: a0.c0 + xi a1.c2
 // < 2p + 4p.  r must not alias.
 ECG_FP6_FN void fp6_mul_sqr_sums(Fp6& r, const Fp6& a0, const Fp6& a1) {
     fp6_mul_lazy<4, 6>(r, fp2_add_lazy(a0.c0, a1.c0), fp2_add_lazy(a0.c1, a1.c1), fp2_add_lazy(a0.c2, a1.c2),
                        fp2_add_lazy(a0.c0, fp2_mul_xi_lazy<2>(a1.c2)), fp2_add_lazy(a0.c1, a1.c0), fp2_add_lazy(a0.c2, a1.c1));
 }
-#endif
 // Karatsuba recombination in one pass: r1 = m - t0 - t1, r0 = t0 + v t1.  r0 / r1 may alias m, t0, t1
 // component-wise (every component is read before it is written).
 ECG_FP6_FN void fp12_karatsuba_combine(Fp6& r0, Fp6& r1, const Fp6& m, const Fp6& t0, const Fp6& t1) {
@@ -208,49 +182,6 @@ ECG_MILLER_DBL_FN void fp12_sqr(Fp12& r, const Fp12& a) {
     fp6_mul_sqr_sums(s, a.c0, a.c1);
     fp12_sqr_combine(r, s, ab);
 }
-#if defined(ECG_TOWER_CALLS)
-// COMPACT-CODE variant of the sparse line product: Karatsuba over a * (c0 + c1 v) (5 Fp2 products), a * (c1 v) (3) and
-// the product of the sums (5), then the Fp12 recombination.
-ECG_HD void fp6_mul_by_01(Fp6& r, const Fp6& a, const Fp2& c0, const Fp2& c1) {
-    Fp2 t0 = fp2_mulx(a.c0, c0);
-    Fp2 t1 = fp2_mulx(a.c1, c1);
-    Fp2 mid = fp2_sub(fp2_sub(fp2_mulx(fp2_add_lazy(a.c0, a.c1), fp2_add_lazy(c0, c1)), t0), t1);
-    Fp2 s2b = fp2_mulx(a.c2, c1);
-    Fp2 s2a = fp2_mulx(a.c2, c0);
-    r.c0 = fp2_add(t0, fp2_mul_xi(s2b));
-    r.c1 = mid;
-    r.c2 = fp2_add(t1, s2a);
-}
-ECG_HD void fp6_mul_by_1(Fp6& r, const Fp6& a, const Fp2& c1) {
-    Fp2 t0 = fp2_mul_xi(fp2_mulx(a.c2, c1));
-    Fp2 t1 = fp2_mulx(a.c0, c1);
-    Fp2 t2 = fp2_mulx(a.c1, c1);
-    r.c0 = t0;
-    r.c1 = t1;
-    r.c2 = t2;
-}
-ECG_HD void fp6_mul_by_01_sums(Fp6& r, const Fp6& f0, const Fp6& f1, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
-    // a_k, c1 < 4p; a0 + a1 < 8p and l0 + c1 < 6p as fp2_mul operands
-    const Fp2 a0 = fp2_add_lazy(f0.c0, f1.c0), a1 = fp2_add_lazy(f0.c1, f1.c1), a2 = fp2_add_lazy(f0.c2, f1.c2), c1 = fp2_add_lazy(l1, l2);
-    Fp2 t0 = fp2_mulx(a0, l0);
-    Fp2 t1 = fp2_mulx(a1, c1);
-    Fp2 mid = fp2_sub(fp2_sub(fp2_mulx(fp2_add_lazy(a0, a1), fp2_add_lazy(l0, c1)), t0), t1);
-    Fp2 s2b = fp2_mulx(a2, c1);
-    Fp2 s2a = fp2_mulx(a2, l0);
-    r.c0 = fp2_add(t0, fp2_mul_xi(s2b));
-    r.c1 = mid;
-    r.c2 = fp2_add(t1, s2a);
-}
-template <int K0>
-ECG_MILLER_DBL_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
-    static_assert(K0 <= 2, "Karatsuba form: reduced line coefficients");
-    Fp6 aa, bb, m;
-    fp6_mul_by_01(aa, f.c0, l0, l1);
-    fp6_mul_by_1(bb, f.c1, l2);
-    fp6_mul_by_01_sums(m, f.c0, f.c1, l0, l1, l2);
-    fp12_karatsuba_combine(f.c0, f.c1, m, aa, bb);
-}
-#else
 // f * ((l0 + l1 v) + (l2 v) w): the Miller-loop line shape on the M-twist.  Schoolbook over the sparse operand: with
 // f = (a0, a1, a2) + (b0, b1, b2) w every Fp2 coefficient of the product is one sum of three Fp2 products,
 //   c0: a0 l0 + xi a2 l1 + xi b1 l2 | a0 l1 + a1 l0 + xi b2 l2 | a1 l1 + a2 l0 + b0 l2
@@ -297,7 +228,6 @@ ECG_MILLER_DBL_FN void fp12_mul_by_line(Fp12& f, const Fp2& l0, const Fp2& l1, c
         f.c1.c2 = fp2_sumprod<3>(x, y210, ny210);
     }
 }
-#endif
 ECG_HD void fp12_inv_inl(Fp12& r, const Fp12& a) {
     Fp6 t0, t1;
     fp6_mul(t0, a.c0, a.c0);
@@ -334,15 +264,6 @@ ECG_HD_NOINLINE void fp12_frob(Fp12& r, const Fp12& a) {
 
 // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the
 // final exponentiation): 3 Fp4 squarings instead of 12 Fp2 products.
-#if defined(ECG_TOWER_CALLS)
-// COMPACT-CODE variant: 3 Fp2 squarings
-ECG_HD void fp4_sqr(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
-    Fp2 t0 = fp2_sqrx(a);
-    Fp2 t1 = fp2_sqrx(b);
-    c0 = fp2_add(fp2_mul_xi(t1), t0);
-    c1 = fp2_sub(fp2_sub(fp2_sqrx(fp2_add(a, b)), t0), t1);
-}
-#else
 // Fp4 squaring (a + b s)^2, s^2 = xi: c0 = a^2 + xi b^2, c1 = 2ab as four sums of products over lazy operands --
 //   c0.re = (ar + ai)(ar - ai) + (br + bi)(br - bi) - 2 br bi      c0.im = 2 ar ai + (br + bi)(br - bi) + 2 br bi
 //   c1.re = 2 ar br - 2 ai bi                                      c1.im = 2 ar bi + 2 ai br
@@ -363,7 +284,6 @@ ECG_HD void fp4_sqr(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
     c1.c0 = fp_sumprod2(a2r, b.c0, a2i, nbi);
     c1.c1 = fp_sumprod2(a2r, b.c1, a2i, b.c0);
 }
-#endif
 ECG_HD void fp12_cyclotomic_sqr_inl(Fp12& r, const Fp12& f) {
     Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
     Fp2 t0, t1, t2, t3;

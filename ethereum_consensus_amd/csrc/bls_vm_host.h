@@ -1,19 +1,12 @@
-// Host-side interface of the lane-group ("Fp2 VM") pairing kernels (bls_vm2.hip) used by bls.hip.
+// Host-side interface of the sum-of-products lane-group pairing kernels (bls_vm3.hip) used by bls.hip.
 #pragma once
 #include "bls_kernels.h"
 #include "runtime.h"
 
 namespace ecg {
 
-int init_vm2_tables();
-size_t vm2_xfer_bytes(u32 n);
-// Enqueue on `s`: for every tuple i < n the status of fast_aggregate_verify given the staged results
-// (aggregate key, H(m), decoded signature and their statuses); tuples whose pairing involves a point
-// at infinity are marked VM_NEEDS_LANE_PATH for k_pairing.  xfer: vm2_xfer_bytes(n) of workspace.
-int vm2_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
-                       const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer);
-
-// the same interface for the sum-of-products lane groups (bls_vm3.hip)
+// Enqueue on `s`: for every tuple i < n the status of fast_aggregate_verify given the staged results (aggregate key, H(m),
+// decoded signature and their statuses).  xfer: vm3_xfer_bytes(n) of workspace.
 int init_vm3_tables();
 size_t vm3_xfer_bytes(u32 n);
 int vm3_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,

@@ -319,13 +319,14 @@ int ecgpu_prof_read(const char* kernel_tag, double* total_ms, uint64_t* launches
 int ecgpu_selfcheck_ifetch(double* ms_small_loop, double* ms_large_loop);
 /* the same work over loops of 8 KB, 64 KB, 256 KB and 1 MB of code */
 int ecgpu_selfcheck_ifetch_sweep(double ms[4]);
-/* Which build of the lane pairing kernels this process uses: 1 = sums of products (fastest on a healthy box), 2 = the
- * compact-code tower (faster where the self-check above reports a slowdown beyond 1.5).  Decided once per process, at the
- * first BLS call or here; the environment variable ECGPU_TOWER=sums|calls overrides the self-check. */
+/* Which build of the G2 stage kernels (signature decoding, hash-to-curve) this process uses: 1 = sums of products (fastest
+ * on a healthy box), 2 = the compact-code tower (faster where the self-check above reports a slowdown beyond 1.5; the pairing
+ * check then runs on the lane groups at every batch size).  Decided once per process, at the first BLS call or here; the
+ * environment variable ECGPU_TOWER=sums|calls overrides the self-check. */
 int ecgpu_bls_tower(void);
-/* Which kernels ran the pairing check of the calling thread's last verification: 1 = one lane per tuple (k_pairing /
- * k_pairing_calls), 2 = 16-lane groups over Fp2 registers in LDS (bls_vm2.hip), 3 = 16-lane groups over Fp registers in
- * LDS with sums of products (bls_vm3.hip); 0 = none yet.  ECGPU_PAIRING=lane|vm2|vm3 forces one (default: by batch size). */
+/* Which kernels ran the pairing check of the calling thread's last verification: 1 = one lane per tuple (k_pairing),
+ * 3 = 16 / 12-lane groups over Fp registers in LDS with sums of products (bls_vm3.hip); 0 = none yet.  ECGPU_PAIRING=lane|vm3
+ * forces one (default: by batch size, ECGPU_VM_MAX).  (2 was round 2's Fp2 lane groups, removed.) */
 int ecgpu_bls_last_pairing_path(void);
 
 #ifdef __cplusplus

@@ -7,7 +7,7 @@ configuration runs in a process of its own against one prepared workload file:
         * statuses known by construction,
         * oracle/bls12_381.py (pure Python) on a sample: every fault class twice, neighbours, random tuples,
         * oracle/c/bls12_381.cpp (C++ restatement, all host threads) on the FULL vector.
-    python -m tests._bls_config2 run <path> <n_first> <tower 1|2|0=any> <lane|vm2|vm3|any>
+    python -m tests._bls_config2 run <path> <n_first> <tower 1|2|0=any> <lane|vm3|any>
         verifies the first n_first tuples on the GPU and compares the whole status vector with all three.
 
 Test infrastructure (imports oracle/)."""
@@ -17,7 +17,7 @@ import random
 import sys
 import time
 
-PATH_NAMES = {0: "none", 1: "lane", 2: "vm2", 3: "vm3"}
+PATH_NAMES = {0: "none", 1: "lane", 3: "vm3"}
 
 
 def prepare(n: int, path: str, n_samples: int = 72) -> dict:

@@ -9,8 +9,6 @@
 #include "bls_verify.h"
 #include <thread>
 
-#include "bls_vm2.h"
-#include "bls_vm2_prog.h"
 #include "bls_vm3.h"
 #include "bls_vm3_prog.h"
 
@@ -278,33 +276,8 @@ void hs_op_census(const u8* pk48, const u8* msg, u64 msg_len, const u8* sig96, u
     snap(3);
 }
 
-// The Fp2 lane-group programs (tools/gen_bls_vm2.py) executed with lock-step semantics on one tuple: part A, the Fp
-// inversion, part C.  Inputs/outputs canonical big-endian like hs_pairing.
-int hs_vm2_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
-    std::vector<u32> RA((size_t)ECG_VM2_A_NREG * 26, 0), RC((size_t)ECG_VM2_C_NREG * 26, 0);
-    for (int c = 0; c < ECG_VM2_A_NCONST; c++)
-        for (int i = 0; i < 26; i++) RA[(size_t)ECG_VM2_A_CONST_REG[c] * 26 + i] = ECG_VM2_A_CONST_VAL[c * 26 + i];
-    for (int c = 0; c < ECG_VM2_C_NCONST; c++)
-        for (int i = 0; i < 26; i++) RC[(size_t)ECG_VM2_C_CONST_REG[c] * 26 + i] = ECG_VM2_C_CONST_VAL[c * 26 + i];
-    A1 p = in_a1(p_xy, 0);
-    A2 h = in_a2(h_xy, 0), sg = in_a2(s_xy, 0);
-    const Fp2 in[5] = {Fp2{p.x, p.y}, h.x, h.y, sg.x, sg.y};
-    for (int k = 0; k < 5; k++) vm2_store(RA.data(), ECG_VM2_A_IN[k], in[k]);
-    vm2_run_serial(ECG_VM2_A_PROG, ECG_VM2_A_CLS, ECG_VM2_A_ROUNDS, ECG_VM2_LANES, RA.data());
-    for (int k = 0; k < 6; k++) vm2_store(RC.data(), ECG_VM2_C_IN[k], vm2_load(RA.data(), ECG_VM2_A_OUT[k]));
-    Fp2 dinv = vm2_load(RA.data(), ECG_VM2_A_OUT[6]);
-    dinv.c0 = fp_inv(dinv.c0);
-    vm2_store(RC.data(), ECG_VM2_C_IN[6], dinv);
-    vm2_run_serial(ECG_VM2_C_PROG, ECG_VM2_C_CLS, ECG_VM2_C_ROUNDS, ECG_VM2_LANES, RC.data());
-    Fp12 e;
-    Fp2* c[6] = {&e.c0.c0, &e.c0.c1, &e.c0.c2, &e.c1.c0, &e.c1.c1, &e.c1.c2};
-    for (int k = 0; k < 6; k++) *c[k] = vm2_load(RC.data(), ECG_VM2_C_OUT[k]);
-    out_fp12(e, out576);
-    return fp12_is_one(e) ? 1 : 0;
-}
-
 // The sum-of-products lane-group programs (tools/gen_bls_vm3.py) executed with the kernel's lock-step semantics on one tuple:
-// part A, the Fp inversion, part C.  Same interface as hs_vm2_pairing; Fp12 coefficients arrive in w-power order.
+// part A, the Fp inversion, part C.  Inputs / outputs canonical big-endian like hs_pairing; Fp12 coefficients arrive in w-power order.
 int hs_vm3_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
     std::vector<u32> RA((size_t)ECG_VM3_A_NREG * 13, 0), RC((size_t)ECG_VM3_C_NREG * 13, 0), KA(64 * 13, 0), KC(64 * 13, 0);
     for (int c = 0; c < ECG_VM3_A_NCONST; c++)

@@ -524,11 +524,11 @@ def test_validated_key_registry_matches_the_uncached_path(gpu):
     reg.close()
 
 
-def test_compact_code_pairing_kernels_in_a_subprocess(gpu):
-    """The second build of the lane pairing kernels (compact-code tower, chosen automatically on boxes whose instruction
-    fetch is slow) must return what the default build returns.  The choice is made once per process, so the
-    forced run lives in a subprocess: reference KAT, a forged message, a faulty batch and aggregate_verify through the lane
-    kernels (ECGPU_PAIRING=lane) of the ECGPU_TOWER=calls build."""
+def test_compact_code_g2_kernels_in_a_subprocess(gpu):
+    """The second build of the G2 stage kernels (compact-code tower: k_sig_calls, k_h2c*_calls; chosen automatically on boxes
+    whose instruction fetch is slow) must return what the default build returns; on such a box the pairing check
+    goes to the lane groups at every size.  The choice is made once per process, so the forced run lives in a subprocess:
+    reference KAT, a forged message, the status-algebra cases and aggregate_verify under ECGPU_TOWER=calls."""
     import os
     import subprocess
     import sys
@@ -543,6 +543,7 @@ assert L.ecgpu_bls_tower() == 2
 B = C.B
 pk = bls.sk_to_pk_batch(C.CAN_SIGN_SK.to_bytes(32, "big"))
 bls.verify_signature(pk, C.CAN_SIGN_MSG, C.CAN_SIGN_SIG)
+assert L.ecgpu_bls_last_pairing_path() == 3
 try:
     bls.verify_signature(pk, C.CAN_SIGN_MSG + b"x", C.CAN_SIGN_SIG)
     raise SystemExit("forged message accepted")
@@ -550,9 +551,8 @@ except bls.Error:
     pass
 for pks, msg, sig, eth in C.fav_cases():
     want = C.oracle_fav(pks, msg, sig, eth)
-    got = bls.fast_aggregate_verify_status(pks, msg, sig, eth) if hasattr(bls, "fast_aggregate_verify_status") else None
-    if got is not None:
-        assert got == want, (len(pks), eth, got, want)
+    got = bls.fast_aggregate_verify_status(pks, msg, sig, eth)
+    assert got == want, (len(pks), eth, got, want)
 sks = [5, 7, 11]
 msgs = [b"a" * 32, b"b" * 32, b"c" * 32]
 pks = [bls.sk_to_pk_batch(s.to_bytes(32, "big")) for s in sks]
@@ -566,7 +566,7 @@ except bls.Error:
     pass
 print("compact-code kernels ok")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
-    env = dict(os.environ, ECGPU_TOWER="calls", ECGPU_PAIRING="lane")
+    env = dict(os.environ, ECGPU_TOWER="calls")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "compact-code kernels ok" in out.stdout, out.stdout + out.stderr
 
@@ -583,11 +583,10 @@ def config2_workload(gpu, tmp_path_factory):
 
 
 @pytest.mark.parametrize("tower,pairing,n,want_tower,want_path", [
-    ("sums", "lane", 65536, 1, "lane"),     # the default large-batch kernel on a healthy box: k_pairing on the sums-of-products tower
-    ("calls", "lane", 65536, 2, "lane"),    # the compact-code build chosen on boxes with slow instruction fetch: k_pairing_calls
-    ("sums", "vm2", 8192, 1, "vm2"),        # the Fp2 lane-group programs (round 1's small-batch path)
+    ("sums", "lane", 65536, 1, "lane"),     # the large-batch kernel on a healthy box: k_pairing (lane slots in LDS)
     ("sums", "vm3", 8192, 1, "vm3"),        # the sum-of-products lane groups: the small-batch path
-    ("sums", "vm3", 65536, 1, "vm3"),       # ... and at full size (what a box with slow instruction fetch would run)
+    ("sums", "vm3", 65536, 1, "vm3"),       # ... and at full size
+    ("calls", "auto", 65536, 2, "vm3"),     # a box with slow instruction fetch: compact G2 stage kernels + lane groups at every size
     ("sums", "auto", 4096, 1, "vm3"),       # a small batch as dispatched by default: two-lane message stage + lane groups
     ("calls", "auto", 4096, 2, "vm3"),      # ... and on the compact-code build (k_h2c_map_calls / k_h2c_finish_calls, k_sig_calls)
 ])
