@@ -437,8 +437,7 @@ ECG_HD_NOINLINE Fp fp_mul(Fp a, Fp b) {
 
 // Montgomery square: 91 a_i*a_j products (off-diagonal ones doubled) + one carry pass, then the
 // 13 reduction rows: 260 multiplies instead of 351.
-ECG_HD_NOINLINE Fp fp_sqr(Fp a) {
-    ECG_COUNT_SQR();
+ECG_HD Fp fp_sqr_body(const Fp& a) {
     u64 T[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) T[i] = 0;
@@ -468,11 +467,19 @@ ECG_HD_NOINLINE Fp fp_sqr(Fp a) {
     r.l[12] = (u32)T[25];
     return r;
 }
+ECG_HD_NOINLINE Fp fp_sqr(Fp a) {
+    ECG_COUNT_SQR();
+    return fp_sqr_body(a);
+}
 
 // small-constant multiples
 ECG_HD Fp fp_mul3(const Fp& a) { return fp_add(fp_dbl(a), a); }
 
-// a^e for a public 384-bit exponent (12 LE words), 4-bit fixed window.
+// a^e for a public 384-bit exponent (12 LE words), 4-bit fixed window.  The window's table entry is read BEFORE the four
+// squarings that precede its use, and those are inlined: the table lives in the private segment (dynamic index), a load issued
+// right in front of the product was an exposed trip to memory per window -- 90 per exponentiation, five exponentiations per
+// message -- and every out-of-line routine starts by waiting for ALL outstanding memory operations (the calling convention's
+// s_waitcnt 0), so a load cannot be hidden behind a call.
 ECG_HD_NOINLINE Fp fp_pow(Fp a, const u32* e) {
     Fp tab[16];
     tab[0] = fp_one();
@@ -481,15 +488,17 @@ ECG_HD_NOINLINE Fp fp_pow(Fp a, const u32* e) {
     Fp r = fp_one();
     bool started = false;
     for (int w = 95; w >= 0; w--) {
-        u32 nib = (e[w >> 3] >> ((w & 7) * 4)) & 15;
+        const u32 nib = (e[w >> 3] >> ((w & 7) * 4)) & 15;
+        const Fp m = ecg_priv_load(tab[nib]);
         if (started) {
-            r = fp_sqr(r);
-            r = fp_sqr(r);
-            r = fp_sqr(r);
-            r = fp_sqr(r);
+            // inlined: a call would wait for the load above at its entry (the ABI's s_waitcnt 0)
+            for (int k = 0; k < 4; k++) {
+                ECG_COUNT_SQR();
+                r = fp_sqr_body(r);
+            }
         }
         if (nib) {
-            r = started ? fp_mul(r, tab[nib]) : tab[nib];
+            r = started ? fp_mul(r, m) : m;
             started = true;
         }
     }

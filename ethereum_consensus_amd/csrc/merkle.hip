@@ -158,8 +158,13 @@ __global__ void __launch_bounds__(TILE_LANES) k_tree_tiles1(TileDesc d, const Ze
     run_tile(d, zt);
 }
 
-__global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u32 n, u8* dst) {
+__global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u32 n, u8* dst, u64 chk_off, u32 chk_expect, u32* flag) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && flag && chk_off != ~0ull) {
+        u32 w[1];
+        load_bytes_le<1>(w, src, chk_off, src_total);
+        if (w[0] != chk_expect) *flag = 1u;
+    }
     if (i >= n) return;
     GatherDesc g = desc[i];
     u32 d[8];
@@ -173,6 +178,57 @@ __global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u
     u32* q = reinterpret_cast<u32*>(dst + 32ull * g.dst_chunk);
 #pragma unroll
     for (int k = 0; k < 8; k++) q[k] = d[k];
+}
+
+// The fused tail of a BeaconState root: see merkle_driver.h TailPlan.
+__device__ __forceinline__ bool tail_last_arrival(u32* counter, u32 parties) {
+    __shared__ u32 ticket;
+    __syncthreads();  // the unit's result has been stored (by lane 0) before this
+    if (threadIdx.x == 0) {
+        __threadfence();  // release: the result is visible device-wide before the ticket is
+        ticket = atomicAdd(counter, 1u);
+    }
+    __syncthreads();
+    const bool last = ticket == parties - 1;
+    if (last) __threadfence();  // acquire: the other parties' results
+    return last;
+}
+__global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u8* buf, const ZeroTable* zt) {
+    __builtin_amdgcn_s_setprio(3);
+    const TailPlan& P = *pl;
+    u32 group;
+    if (blockIdx.x < P.n_tile_wgs) {
+        u32 f = 0;
+        for (u32 i = 1; i < P.n_fields; i++)
+            if (blockIdx.x >= P.fields[i].tile.first_wg) f = i;
+        const TileDesc d = P.fields[f].tile;
+        run_tile(d, zt);
+        if (!tail_last_arrival(&P.counters[f], P.fields[f].n_tiles)) return;
+        const TreeJob job = P.fields[f].job;
+        run_tree_job(job, buf, zt);
+        group = P.fields[f].group;
+    } else {
+        const u32 j = blockIdx.x - P.n_tile_wgs;
+        const TreeJob job = P.jobs0[j];
+        run_tree_job(job, buf, zt);
+        group = P.jobs0_group[j];
+    }
+    if (group == 0) {
+        if (!tail_last_arrival(&P.counters[P.n_fields], P.units_a)) return;
+        for (u32 j = 0; j < P.n_jobs1; j++) {
+            const TreeJob job = P.jobs1[j];
+            run_tree_job(job, buf, zt);
+            __syncthreads();  // lane 0 is done with the LDS nodes before the next job loads its own
+        }
+    }
+    if (!tail_last_arrival(&P.counters[P.n_fields + 1], P.units_b)) return;
+    const TreeJob top = P.job2;
+    run_tree_job(top, buf, zt);
+    __syncthreads();
+    const u32 t = threadIdx.x;
+    const bool bad = *P.poison != 0;
+    if (t < 8) reinterpret_cast<u32*>(P.d_root)[t] = bad ? 0xffffffffu : reinterpret_cast<const u32*>(buf + P.root_off)[t];
+    if (P.d_field_roots) reinterpret_cast<u32*>(P.d_field_roots)[t] = reinterpret_cast<const u32*>(buf + P.froots_off)[t];  // 32 x 32 B = 256 dwords
 }
 
 // crypto::hash: one lane per message (latency path; the batch form is what a caller should use)
@@ -260,7 +316,7 @@ int launch_tiles(hipStream_t s, const TileDesc* d_descs, u32 n_desc, u32 n_wg) {
 
 int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes, u64 n0, u32 depth, bool mix,
                      u64 mix_len, u8* d_out, u8* ws, u64* hash_count, TreeJob* deferred, const u8* job_base, bool background,
-                     hipEvent_t after_wide_passes) {
+                     hipEvent_t after_wide_passes, TileDesc* deferred_tile, u32* deferred_tile_wgs) {
     if (depth > 64) {
         set_last_error("limit too large");
         return ECGPU_ERR_BAD_ARG;
@@ -317,9 +373,16 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
         td.top = depth;
         td.first_wg = 0;
         const u32 n_wg = (u32)((sc.tile_n_in + TILE_NODES - 1) / TILE_NODES);
-        int rc = launch_tiles_inline(s, td, n_wg);
-        if (rc) return rc;
+        if (deferred_tile) {
+            *deferred_tile = td;
+            *deferred_tile_wgs = n_wg;
+        } else {
+            int rc = launch_tiles_inline(s, td, n_wg);
+            if (rc) return rc;
+        }
         cur = out;
+    } else if (deferred_tile_wgs) {
+        *deferred_tile_wgs = 0;
     }
     // finishing job: <= 512 nodes at job_level (or the empty tree) -> climb -> mix-in -> d_out
     TreeJob job;
@@ -352,9 +415,18 @@ int launch_tree_jobs(hipStream_t s, const TreeJob* d_jobs, u32 n_jobs, u8* d_buf
     return ECGPU_SUCCESS;
 }
 
-int launch_gather(hipStream_t s, const u8* d_src, u64 src_total, const GatherDesc* d_desc, u32 n, u8* d_dst) {
-    if (n == 0) return ECGPU_SUCCESS;
-    hipLaunchKernelGGL(k_gather, dim3((n + 63) / 64), dim3(64), 0, s, d_src, src_total, d_desc, n, d_dst);
+int launch_gather(hipStream_t s, const u8* d_src, u64 src_total, const GatherDesc* d_desc, u32 n, u8* d_dst, u64 chk_off, u32 chk_expect,
+                  u32* d_flag) {
+    if (n == 0 && chk_off == ~0ull) return ECGPU_SUCCESS;
+    hipLaunchKernelGGL(k_gather, dim3((n + 63) / 64 ? (n + 63) / 64 : 1), dim3(64), 0, s, d_src, src_total, d_desc, n, d_dst, chk_off, chk_expect, d_flag);
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+
+int launch_state_tail(hipStream_t s, const TailPlan* d_plan, u32 n_wgs, u8* d_buf) {
+    if (n_wgs == 0) return ECGPU_ERR_BAD_ARG;
+    ProfScope ps("merkle_state_tail", s);
+    hipLaunchKernelGGL(k_state_tail, dim3(n_wgs), dim3(TILE_LANES), 0, s, d_plan, d_buf, device_zero_table());
     ECG_HIP_CHECK(hipGetLastError());
     return ECGPU_SUCCESS;
 }

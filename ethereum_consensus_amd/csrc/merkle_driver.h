@@ -27,9 +27,12 @@ size_t merkle_ws_bytes(u64 n0);
 // relative to `job_base` so that the caller can batch it with others (launch_tree_jobs); `background`
 // selects the fewer-launches pass schedule (state_plan.h); `after_wide_passes` is recorded on `s` once the wide
 // (chip-filling) passes are enqueued, i.e. where the tree's latency-bound tail begins.
+// With `deferred_tile` set as well, the tile stage is not launched either: its descriptor (first_wg left 0) and workgroup
+// count are returned (*deferred_tile_wgs = 0: the tree has no tile stage) for the fused tail of a BeaconState root.
 int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes, u64 n0, u32 depth,
                      bool mix, u64 mix_len, u8* d_out, u8* ws, u64* hash_count, TreeJob* deferred = nullptr,
-                     const u8* job_base = nullptr, bool background = false, hipEvent_t after_wide_passes = nullptr);
+                     const u8* job_base = nullptr, bool background = false, hipEvent_t after_wide_passes = nullptr,
+                     TileDesc* deferred_tile = nullptr, u32* deferred_tile_wgs = nullptr);
 
 // Batched small trees: jobs live in device memory at d_jobs.
 int launch_tree_jobs(hipStream_t s, const TreeJob* d_jobs, u32 n_jobs, u8* d_buf);
@@ -37,7 +40,41 @@ int launch_tree_jobs(hipStream_t s, const TreeJob* d_jobs, u32 n_jobs, u8* d_buf
 // Batched tile stage: descriptors (merkle.h TileDesc) in device memory, n_wg = total workgroups.
 int launch_tiles(hipStream_t s, const TileDesc* d_descs, u32 n_desc, u32 n_wg);
 
-int launch_gather(hipStream_t s, const u8* d_src, u64 src_total, const GatherDesc* d_desc, u32 n, u8* d_dst);
+// chk_off != ~0: the gather kernel also compares the little-endian u32 at byte chk_off of the source with chk_expect and sets
+// *d_flag = 1 when they differ (a check the host cannot make when it never sees the bytes: ecgpu_htr_beacon_state_dev)
+int launch_gather(hipStream_t s, const u8* d_src, u64 src_total, const GatherDesc* d_desc, u32 n, u8* d_dst, u64 chk_off = ~0ull,
+                  u32 chk_expect = 0, u32* d_flag = nullptr);
+
+// ---- the fused tail of a BeaconState root (state_deneb.hip) -----------------------------------------------------------------
+// After the wide passes, everything that is left of a state root is latency: per field a tile stage (1024 nodes -> 1 per
+// workgroup), a finishing job (<= 512 nodes -> root, zero ladder, length mix-in), then the nested containers and the state
+// container.  Round 2 ran that as ~6 dependent launches on two streams joined by events (~0.3 ms of a 1.08 ms root, a third
+// of it launch and event latency).  k_state_tail is ONE launch: every tile workgroup takes a ticket of its field when its
+// node is stored, the LAST one runs the field's finishing job; every finished unit of group A (everything but the field on
+// the critical path) takes a ticket, the last one runs the nested containers; that arrival and the critical field's are the
+// two tickets of group B, and the later one runs the state container and writes the root.  No workgroup ever waits for
+// another (no spinning, nothing to deadlock): whoever arrives last carries on.
+struct TailField {
+    TileDesc tile;
+    TreeJob job;
+    u32 n_tiles;
+    u32 group;  // 0 = A, 1 = B
+};
+constexpr u32 TAIL_MAX_FIELDS = 24, TAIL_MAX_JOBS0 = 64, TAIL_MAX_JOBS1 = 8;
+struct TailPlan {
+    TailField fields[TAIL_MAX_FIELDS];  // fields with a tile stage, in workgroup order
+    TreeJob jobs0[TAIL_MAX_JOBS0];      // units without one: leaf containers, finishing jobs of short or empty fields
+    u32 jobs0_group[TAIL_MAX_JOBS0];
+    TreeJob jobs1[TAIL_MAX_JOBS1];      // nested containers (inputs: group A only)
+    TreeJob job2;                       // the state container
+    u32 n_fields, n_tile_wgs, n_jobs0, n_jobs1, units_a, units_b;
+    u64 root_off, froots_off;           // byte offsets in the job buffer: the state root, the 32 field-root chunks
+    u8* d_root;
+    u8* d_field_roots;                  // may be null
+    u32* counters;                      // [n_fields] tile tickets, [n_fields] group A, [n_fields + 1] group B; zero before the launch
+    const u32* poison;                  // *poison != 0: the root is written as 32 x 0xFF (launch_gather's check failed)
+};
+int launch_state_tail(hipStream_t s, const TailPlan* d_plan, u32 n_wgs, u8* d_buf);
 
 const ZeroTable* device_zero_table();
 

@@ -40,126 +40,106 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     // ---- device buffers --------------------------------------------------------------------------
     Arena& ar = c->arena(s);
     ar.reset();
-    size_t need = 4096;
+    size_t need = 8192;
     for (auto& b : plan.bigs) need += merkle_ws_bytes(b.n0) + 512;
     const size_t small_bytes = 32ull * plan.n_small_chunks;
-    const size_t n_jobs = plan.jobs[0].size() + plan.jobs[1].size() + plan.jobs[2].size() + plan.bigs.size();
-    need += small_bytes + n_jobs * sizeof(TreeJob) + plan.gathers.size() * sizeof(GatherDesc) + plan.bigs.size() * (sizeof(TileDesc) + 256) + 2048;
+    need += small_bytes + plan.gathers.size() * sizeof(GatherDesc) + sizeof(TailPlan) + 2048;
     int rc = ar.reserve(need);
     if (rc) return rc;
     u8* d_small = ar.take(small_bytes);
-    TreeJob* d_jobs = (TreeJob*)ar.take(n_jobs * sizeof(TreeJob));
     GatherDesc* d_gath = (GatherDesc*)ar.take(plan.gathers.size() * sizeof(GatherDesc));
+    TailPlan* d_tail = (TailPlan*)ar.take(sizeof(TailPlan));
+    u32* d_counters = (u32*)ar.take((TAIL_MAX_FIELDS + 4) * sizeof(u32));  // tile tickets, group A, group B, the poison flag
+    if (!d_small || !d_gath || !d_tail || !d_counters) return ECGPU_ERR_OOM;
+    u32* d_poison = d_counters + TAIL_MAX_FIELDS + 3;
     // descriptors travel through pageable memory: hipMemcpyAsync stages them before returning,
     // so the host vectors may die at the end of this call while the stream is still running.
     ECG_HIP_CHECK(hipMemcpyAsync(d_gath, plan.gathers.data(), plan.gathers.size() * sizeof(GatherDesc),
                                  hipMemcpyHostToDevice, s));
     ECG_HIP_CHECK(hipMemsetAsync(d_small, 0, small_bytes, s));
-    rc = launch_gather(s, d_ssz, n_bytes, d_gath, (u32)plan.gathers.size(), d_small);
+    ECG_HIP_CHECK(hipMemsetAsync(d_counters, 0, (TAIL_MAX_FIELDS + 4) * sizeof(u32), s));
+    // The device entry never sees the payload header on the host: the extra_data offset word the host entries check
+    // (state_plan.h) is compared on the device, and a mismatch poisons the root (32 x 0xFF; include/ecgpu.h).
+    const bool dev_check = fork >= FORK_BELLATRIX && !h_payload_fixed && plan.payload_header_off != ~0ull;
+    rc = launch_gather(s, d_ssz, n_bytes, d_gath, (u32)plan.gathers.size(), d_small,
+                       dev_check ? plan.payload_header_off + PAYLOAD_EXTRA_DATA_OFFSET_WORD : ~0ull, (u32)payload_header_fixed(fork), d_poison);
     if (rc) return rc;
     for (const StatePlan::ExtChunk& e : plan.ext_chunks)  // phase0: roots computed by the generic planner (pageable copy: staged before return)
         ECG_HIP_CHECK(hipMemcpyAsync(d_small + 32ull * e.dst_chunk, ext_roots + e.src_off, 32, hipMemcpyHostToDevice, s));
     u64 hc = plan.small_hashes;
-    // The 14 big fields are independent trees and so are the leaf-container jobs; only the nested containers
-    // and the 28-field state container wait for them.  The validator registry (93 % of the hashes) runs on the
-    // caller's stream, launched first; every other field runs underneath it on two auxiliary streams with the
-    // fewer-launches schedule, and their finishing jobs (<= 512 nodes -> zero-ladder climb -> mix-in, a chain of
-    // ~30 sequential hash64 each) are batched with the leaf-container jobs into ONE launch instead of fourteen
-    // back-to-back single-workgroup kernels.
-    AuxStreams& ax = c->aux;
-    rc = ax.init();
-    if (rc) return rc;
+    // Schedule (round 3): ONE stream.  The wide passes first -- the validator registry, 93 % of the hashes, and whatever other
+    // field is too wide for a tile stage --, then ONE launch for everything that is left: the tile stages of all fields, their
+    // finishing jobs, the leaf containers, the nested containers and the state container, chained by arrival tickets inside the
+    // kernel (merkle_driver.h TailPlan).  Round 2 overlapped the other 13 fields with the validator pass on two auxiliary streams:
+    // their latency-bound workgroups cost the chip-filling pass 25 % (0.62 -> 0.78 ms) and the tail was ~6 dependent launches
+    // joined by events.
     size_t biggest = 0;
     for (size_t i = 1; i < plan.bigs.size(); i++)
         if (plan.bigs[i].bytes > plan.bigs[biggest].bytes) biggest = i;
-    std::vector<u8*> wss(plan.bigs.size());
-    for (size_t i = 0; i < plan.bigs.size(); i++) wss[i] = ar.take(merkle_ws_bytes(plan.bigs[i].n0));
-    {
-        // The other fields are ~7 % of the hashes but their latency-bound workgroups would take wave slots from the
-        // chip-filling validator pass for its whole duration (measured 0.63 -> 0.79 ms); they start when that pass
-        // has been issued and overlap with the validator tree's own latency-bound tail instead.
-        const BigField& b = plan.bigs[biggest];
-        // (the other fields from the START of the pass, now that their chain kernels carry issue priority: 1.02 against 1.05 ms,
-        // inside the run-to-run spread -- profiles/r02n_committee_and_priority.txt; kept in the middle)
-        static const bool aux_early = getenv("ECGPU_STATE_AUX_EARLY") != nullptr;
-        if (aux_early) ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
-        rc = merkleize_device(s, b.kind, fptr[biggest], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk,
-                              wss[biggest], &hc, nullptr, nullptr, false, aux_early ? nullptr : ax.fork);
-        if (rc) return rc;
-    }
-    for (int i = 0; i < 2; i++) ECG_HIP_CHECK(hipStreamWaitEvent(ax.st[i], ax.fork, 0));
-    std::vector<TreeJob> first_jobs;  // deferred finishing jobs of the other big fields + dependency level 0
-    std::vector<TileDesc> tdescs;     // their tile stages, one launch for all of them
-    u32 tile_wgs = 0;
-    for (size_t i = 0; i < plan.bigs.size(); i++) {
-        if (i == biggest) continue;
+    // the field on the critical path takes the second ticket of group B on its own -- unless a nested container waits for it
+    const bool main_alone = plan.bigs[biggest].out_chunk < 32;
+    static TailPlan tp_init{};
+    TailPlan tp = tp_init;
+    u32 units_a = 0, units_main = 0;
+    std::vector<size_t> order{biggest};
+    for (size_t i = 0; i < plan.bigs.size(); i++)
+        if (i != biggest) order.push_back(i);
+    for (size_t i : order) {
         const BigField& b = plan.bigs[i];
-        const MerkleSchedule sc = schedule_merkleize(b.kind, b.n0, b.depth, b.mix, true);
+        u8* ws = ar.take(merkle_ws_bytes(b.n0));
+        if (!ws) return ECGPU_ERR_OOM;
         TreeJob dj;
-        if (sc.passes.empty()) {
-            // <= 2^19 leaves: leaf functor + 10 levels in the shared tile launch, then the batched finishing job
-            if (sc.tile) {
-                tdescs.push_back({fptr[i], b.bytes, b.n0, wss[i], (u32)b.kind, 0u, b.depth, tile_wgs});
-                tile_wgs += (u32)((b.n0 + TILE_NODES - 1) / TILE_NODES);
-            }
-            dj.in_off = (u64)(wss[i] - ar.base);
-            dj.out_off = (u64)(d_small + 32ull * b.out_chunk - ar.base);
-            dj.mix_len = b.mix_len;
-            dj.n = sc.job_n;
-            dj.level = sc.job_level;
-            dj.depth = b.depth;
-            dj.mix = b.mix ? 1 : 0;
-            hc += sc.hashes;
-        } else {
-            rc = merkleize_device(ax.st[1], b.kind, fptr[i], b.bytes, b.n0, b.depth, b.mix, b.mix_len,
-                                  d_small + 32ull * b.out_chunk, wss[i], &hc, &dj, ar.base, true);
-            if (rc) return rc;
-        }
-        first_jobs.push_back(dj);
-    }
-    if (!tdescs.empty()) {
-        TileDesc* d_td = (TileDesc*)ar.take(tdescs.size() * sizeof(TileDesc));
-        if (!d_td) return ECGPU_ERR_OOM;
-        ECG_HIP_CHECK(hipMemcpyAsync(d_td, tdescs.data(), tdescs.size() * sizeof(TileDesc), hipMemcpyHostToDevice, ax.st[0]));
-        rc = launch_tiles(ax.st[0], d_td, (u32)tdescs.size(), tile_wgs);
+        TileDesc td;
+        u32 n_tiles = 0;
+        rc = merkleize_device(s, b.kind, fptr[i], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk, ws, &hc, &dj, ar.base,
+                              i != biggest, nullptr, &td, &n_tiles);
         if (rc) return rc;
+        const u32 group = (i == biggest && main_alone) ? 1u : 0u;
+        if (n_tiles) {
+            if (tp.n_fields >= TAIL_MAX_FIELDS) return ECGPU_ERR_BAD_ARG;
+            td.first_wg = tp.n_tile_wgs;
+            tp.fields[tp.n_fields++] = TailField{td, dj, n_tiles, group};
+            tp.n_tile_wgs += n_tiles;
+        } else {
+            if (tp.n_jobs0 >= TAIL_MAX_JOBS0) return ECGPU_ERR_BAD_ARG;
+            tp.jobs0[tp.n_jobs0] = dj;
+            tp.jobs0_group[tp.n_jobs0++] = group;
+        }
+        (group ? units_main : units_a)++;
     }
     // level jobs were planned relative to the small-chunk buffer: rebase them onto the arena like the deferred ones
     const u64 small_off = (u64)(d_small - ar.base);
-    std::vector<TreeJob> all_jobs = first_jobs;
-    size_t level_start[4];
-    level_start[0] = 0;
-    for (int l = 0; l < 3; l++) {
-        for (TreeJob j : plan.jobs[l]) {
-            j.in_off += small_off;
-            j.out_off += small_off;
-            all_jobs.push_back(j);
-        }
-        level_start[l + 1] = all_jobs.size();
+    auto rebased = [&](TreeJob j) {
+        j.in_off += small_off;
+        j.out_off += small_off;
+        return j;
+    };
+    if (tp.n_jobs0 + plan.jobs[0].size() > TAIL_MAX_JOBS0 || plan.jobs[1].size() > TAIL_MAX_JOBS1 || plan.jobs[2].size() != 1) {
+        set_last_error("state plan does not fit the fused tail");
+        return ECGPU_ERR_BAD_ARG;
     }
-    ECG_HIP_CHECK(hipEventRecord(ax.done[1], ax.st[1]));
-    ECG_HIP_CHECK(hipStreamWaitEvent(ax.st[0], ax.done[1], 0));
-    ECG_HIP_CHECK(hipMemcpyAsync(d_jobs, all_jobs.data(), all_jobs.size() * sizeof(TreeJob), hipMemcpyHostToDevice, ax.st[0]));
-    rc = launch_tree_jobs(ax.st[0], d_jobs, (u32)level_start[1], ar.base);
+    for (const TreeJob& j : plan.jobs[0]) {
+        tp.jobs0[tp.n_jobs0] = rebased(j);
+        tp.jobs0_group[tp.n_jobs0++] = 0;
+        units_a++;
+    }
+    for (const TreeJob& j : plan.jobs[1]) tp.jobs1[tp.n_jobs1++] = rebased(j);
+    tp.job2 = rebased(plan.jobs[2][0]);
+    tp.units_a = units_a;
+    tp.units_b = 1 + units_main;  // group A's last arrival + the critical field
+    tp.root_off = small_off + 32ull * plan.root_chunk;
+    tp.froots_off = small_off;  // chunks 0 .. 31 of the small buffer are the roots of the state's fields (proofs: ssz_proof.hip)
+    tp.d_root = d_root;
+    tp.d_field_roots = d_field_roots;
+    tp.counters = d_counters;
+    tp.poison = d_poison;
+    if (units_a == 0) {  // cannot happen with the forks this plan knows (there are always leaf containers)
+        set_last_error("state plan without small fields");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    ECG_HIP_CHECK(hipMemcpyAsync(d_tail, &tp, sizeof(TailPlan), hipMemcpyHostToDevice, s));
+    rc = launch_state_tail(s, d_tail, tp.n_tile_wgs + tp.n_jobs0, ar.base);
     if (rc) return rc;
-    // nested containers (sync committees, payload header): off the critical path too, unless the field on the
-    // caller's stream is itself an input of one (its root is not one of the 28 state-container chunks)
-    const bool lvl1_on_main = plan.bigs[biggest].out_chunk >= 32;
-    if (!lvl1_on_main) {
-        rc = launch_tree_jobs(ax.st[0], d_jobs + level_start[1], (u32)(level_start[2] - level_start[1]), ar.base);
-        if (rc) return rc;
-    }
-    ECG_HIP_CHECK(hipEventRecord(ax.done[0], ax.st[0]));
-    ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[0], 0));
-    if (lvl1_on_main) {
-        rc = launch_tree_jobs(s, d_jobs + level_start[1], (u32)(level_start[2] - level_start[1]), ar.base);
-        if (rc) return rc;
-    }
-    rc = launch_tree_jobs(s, d_jobs + level_start[2], (u32)(level_start[3] - level_start[2]), ar.base);
-    if (rc) return rc;
-    ECG_HIP_CHECK(hipMemcpyAsync(d_root, d_small + 32ull * plan.root_chunk, 32, hipMemcpyDeviceToDevice, s));
-    if (d_field_roots)  // chunks 0 .. 31 of the small buffer are the roots of the state's fields (proofs: ssz_proof.hip)
-        ECG_HIP_CHECK(hipMemcpyAsync(d_field_roots, d_small, 32ull * 32, hipMemcpyDeviceToDevice, s));
     c->last_hash64 = hc;
     return ECGPU_SUCCESS;
 }

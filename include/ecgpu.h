@@ -99,7 +99,11 @@ int ecgpu_is_valid_merkle_branch(const uint8_t leaf[32], const uint8_t* branch, 
 #define ECGPU_PRESET_MINIMAL 1
 int ecgpu_htr_beacon_state_deneb(const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32]);
 /* device-resident state bytes; `h_fixed` = host copy of the fixed-size part of the encoding
- * (the first ecgpu_beacon_state_deneb_fixed_size(preset) bytes: offsets and small fields). */
+ * (the first ecgpu_beacon_state_deneb_fixed_size(preset) bytes: offsets and small fields).  Asynchronous: the root appears
+ * at d_root in stream order.  Everything the host entries reject is rejected here at the call too (ECGPU_ERR_BAD_ARG), with one
+ * exception: the `extra_data` offset word INSIDE the payload header (bellatrix+) lives in the variable part, which the
+ * host never sees -- it is compared on the device, and an encoding that fails the comparison gets the root 0xFF x 32 (no
+ * SHA-256 output a caller will ever meet) instead of an error code. */
 int ecgpu_htr_beacon_state_deneb_dev(const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed,
                                      int preset, uint8_t* d_root, ecgpu_stream_t stream);
 uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);

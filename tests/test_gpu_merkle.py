@@ -379,6 +379,20 @@ def test_beacon_state_root_of_every_fork(gpu, fork):
         bad[h + 436] ^= 4
         with pytest.raises(ssz.MerkleizationError):
             ssz.hash_tree_root_beacon_state(fork, bytes(bad), ssz.MINIMAL)
+        # the device entry (the encoding never visits the host) makes the same check on the device: a good encoding gives the
+        # same root, the malformed one gives the poisoned root of include/ecgpu.h (32 x 0xFF) -- round-2 advisor: one entry
+        # used to return a root for what the other rejected
+        import torch
+        L = ssz._lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        out = torch.zeros(32, dtype=torch.uint8, device="cuda")
+        for blob, want in ((enc, t.htr(v)), (bytes(bad), b"\xff" * 32)):
+            d = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+            fixed_part = ctypes.create_string_buffer(bytes(blob[:fixed]), fixed)
+            rc = L.ecgpu_htr_beacon_state_dev(ssz.FORKS[fork], d.data_ptr(), len(blob), fixed_part, ssz.MINIMAL, out.data_ptr(), st)
+            assert rc == 0, (rc, L.ecgpu_last_error())
+            torch.cuda.synchronize()
+            assert bytes(out.cpu().numpy()) == want
 
 
 def test_resident_state_of_an_older_fork(gpu):

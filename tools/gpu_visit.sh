@@ -11,6 +11,7 @@
 #   lib:<name>       following steps use lib/libecgpu_<name>.so (tools/build_variant.sh); lib: alone switches back
 #   env:<K=V>        export K=V for the following steps (unenv:<K> removes it)
 #   to:<seconds>     timeout of the following probe steps (tt:<seconds>: of the test steps)
+#   run:<binary>     a probe binary (commas for spaces)              -> gpurun_out/<tag>_<binary>.txt
 #   py:<script>      python <script> (under tools/)                  -> gpurun_out/<tag>_<script>.txt
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -50,6 +51,7 @@ for step in "$@"; do
            python tools/pmc_summary.py gpurun_out/pmc_${tag}_m_$c gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt | cut -c1-160
            rm -rf gpurun_out/pmc_${tag}_m_$c
          done;;
+    run:*) c=${step#run:}; timeout $TO ${c//,/ } 2>&1 | tee gpurun_out/${tag}${sfx}_$(basename ${c%%,*}).txt | tail -40;;
     py:*) s=${step#py:}; timeout 900 python tools/${s//_/ } 2>&1 | tee gpurun_out/${tag}${sfx}_$(echo $s | tr -c 'A-Za-z0-9' '_').txt | tail -40;;
     *) echo "unknown step $step";;
   esac
