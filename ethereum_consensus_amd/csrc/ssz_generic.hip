@@ -9,14 +9,23 @@
 
 using namespace ecg;
 
+namespace ecg {
+int htr_ssz_impl(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs, uint32_t root_type,
+                 const uint8_t* ssz, uint64_t n_bytes, uint8_t root[32], bool allow_internal);
+}
 extern "C" int ecgpu_htr_ssz(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs,
                              uint32_t root_type, const uint8_t* ssz, uint64_t n_bytes, uint8_t root[32]) {
+    return ecg::htr_ssz_impl(types, n_types, fields, n_field_refs, root_type, ssz, n_bytes, root, false);
+}
+// allow_internal: the type table may contain ECG_SSZ_LIST_NOMIX (ssz_proof.hip)
+int ecg::htr_ssz_impl(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs, uint32_t root_type,
+                      const uint8_t* ssz, uint64_t n_bytes, uint8_t root[32], bool allow_internal) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!types || !root || (!ssz && n_bytes)) return ECGPU_ERR_BAD_ARG;
     SszPlan plan;
     static const u8 empty[4] = {0, 0, 0, 0};
-    if (!build_ssz_plan(types, n_types, fields, n_field_refs, root_type, ssz ? ssz : empty, n_bytes, plan)) {
+    if (!build_ssz_plan(types, n_types, fields, n_field_refs, root_type, ssz ? ssz : empty, n_bytes, plan, allow_internal)) {
         set_last_error(plan.error);
         return ECGPU_ERR_BAD_ARG;
     }

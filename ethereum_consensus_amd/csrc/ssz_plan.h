@@ -16,6 +16,12 @@
 
 namespace ecg {
 
+// Internal kind (never accepted from a caller: include/ecgpu.h stops at ECGPU_SSZ_CONTAINER): a list WITHOUT its length
+// mix-in, i.e. merkleize(element roots, limit).  ecgpu_ssz_prove uses it for the sibling subtrees of a long homogeneous
+// sequence: one plan per level instead of one hash_tree_root call per element.
+constexpr u32 ECG_SSZ_LIST_NOMIX = 0x100u + ECGPU_SSZ_LIST;
+
+
 struct SszBigTree {
     LeafKind kind;     // LEAF_CHUNKS: bytes of the encoding; LEAF_NODES: child roots in the small buffer
     u64 src;           // byte offset into the encoding (CHUNKS) or chunk index in the small buffer (NODES)
@@ -38,8 +44,9 @@ struct SszPlan {
 
 class SszPlanner {
   public:
-    SszPlanner(const ecgpu_ssz_type* types, u32 n_types, const u32* fields, u32 n_field_refs, const u8* enc, u64 n_bytes, SszPlan& plan)
-        : T(types), nT(n_types), F(fields), nF(n_field_refs), h(enc), n(n_bytes), P(plan), fixed_memo(n_types, kUnknown) {}
+    SszPlanner(const ecgpu_ssz_type* types, u32 n_types, const u32* fields, u32 n_field_refs, const u8* enc, u64 n_bytes, SszPlan& plan,
+               bool allow_internal = false)
+        : T(types), nT(n_types), F(fields), nF(n_field_refs), h(enc), n(n_bytes), P(plan), fixed_memo(n_types, kUnknown), internal_ok(allow_internal) {}
 
     bool run(u32 root_type) {
         if (!validate()) return false;
@@ -56,6 +63,7 @@ class SszPlanner {
     u64 n;
     SszPlan& P;
     std::vector<u64> fixed_memo;
+    bool internal_ok;
 
     int fail(const char* m) {
         if (P.error.empty()) P.error = m;
@@ -64,8 +72,9 @@ class SszPlanner {
     bool validate() {
         for (u32 i = 0; i < nT; i++) {
             const ecgpu_ssz_type& t = T[i];
-            if (t.kind > ECGPU_SSZ_CONTAINER) return fail("unknown SSZ kind") >= 0;
-            if ((t.kind == ECGPU_SSZ_VECTOR || t.kind == ECGPU_SSZ_LIST) && t.elem >= i) return fail("element type must precede its container") >= 0;
+            if (t.kind > ECGPU_SSZ_CONTAINER && !(internal_ok && t.kind == ECG_SSZ_LIST_NOMIX)) return fail("unknown SSZ kind") >= 0;
+            if ((t.kind == ECGPU_SSZ_VECTOR || t.kind == ECGPU_SSZ_LIST || t.kind == ECG_SSZ_LIST_NOMIX) && t.elem >= i)
+                return fail("element type must precede its container") >= 0;
             if (t.kind == ECGPU_SSZ_CONTAINER) {
                 if ((u64)t.first_field + t.n_fields > nF || t.n_fields == 0) return fail("bad field range") >= 0;
                 for (u32 k = 0; k < t.n_fields; k++)
@@ -198,14 +207,16 @@ class SszPlanner {
                 return bytes_tree(off, dlen, (t.param + 255) / 256, true, bits, dst, mask);
             }
             case ECGPU_SSZ_VECTOR:
-            case ECGPU_SSZ_LIST: {
-                const bool is_list = t.kind == ECGPU_SSZ_LIST;
+            case ECGPU_SSZ_LIST:
+            case ECG_SSZ_LIST_NOMIX: {
+                const bool is_list = t.kind != ECGPU_SSZ_VECTOR;
+                const bool mix_len = t.kind == ECGPU_SSZ_LIST;
                 if (is_basic(t.elem)) {
                     const u64 s = T[t.elem].param;
                     if (len % s) return fail("packed sequence length is not a multiple of the element size");
                     const u64 cnt = len / s;
                     if (is_list ? cnt > t.param : cnt != t.param) return fail("sequence length does not fit the type");
-                    return bytes_tree(off, len, (t.param * s + 31) / 32, is_list, cnt, dst);
+                    return bytes_tree(off, len, (t.param * s + 31) / 32, mix_len, cnt, dst);
                 }
                 // composite elements: ranges from the stride or from the offset table
                 std::vector<u64> starts;
@@ -238,7 +249,7 @@ class SszPlanner {
                     if (l < 0) return -1;
                     if (l > lvl) lvl = l;
                 }
-                return nodes_tree(blk, cnt, lvl, t.param, is_list, dst);
+                return nodes_tree(blk, cnt, lvl, t.param, mix_len, dst);
             }
             default: {  // ECGPU_SSZ_CONTAINER
                 const u32 nf = t.n_fields;
@@ -280,12 +291,12 @@ class SszPlanner {
 };
 
 inline bool build_ssz_plan(const ecgpu_ssz_type* types, u32 n_types, const u32* fields, u32 n_field_refs, u32 root_type, const u8* enc,
-                           u64 n_bytes, SszPlan& plan) {
+                           u64 n_bytes, SszPlan& plan, bool allow_internal = false) {
     if (!types || root_type >= n_types || (n_field_refs && !fields)) {
         plan.error = "bad type description";
         return false;
     }
-    SszPlanner p(types, n_types, fields, n_field_refs, enc, n_bytes, plan);
+    SszPlanner p(types, n_types, fields, n_field_refs, enc, n_bytes, plan, allow_internal);
     return p.run(root_type);
 }
 

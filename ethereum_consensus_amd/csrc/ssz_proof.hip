@@ -14,6 +14,9 @@
 #include "ssz_plan.h"
 
 namespace ecg {
+int htr_ssz_impl(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_t* fields, uint32_t n_field_refs, uint32_t root_type,
+                 const uint8_t* ssz, uint64_t n_bytes, uint8_t root[32], bool allow_internal);  // ssz_generic.hip
+
 
 namespace {
 
@@ -258,7 +261,10 @@ int ecgpu_ssz_prove(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_
         // ---- the chunks of this object's data tree (roots of its children, or its packed bytes) and its length
         std::vector<u8> chunks;
         u64 n_chunks = 0, length = 0, pos = 0;
-        std::vector<u64> a, b;  // child ranges (composite children)
+        std::vector<u64> a, b;  // child ranges (the fields of a container)
+        bool is_seq = false;    // a vector / list of composite elements: ranges by stride or from the offset table
+        u64 seq_fs = 0;
+        auto seq_lo = [&](u64 i) -> u64 { return seq_fs != kVariable ? i * seq_fs : (i < n_chunks ? rd32p(obj + 4 * i) : len); };
         if (t.kind == ECGPU_SSZ_CONTAINER) {
             const u32 nf = t.n_fields;
             a.resize(nf);
@@ -282,20 +288,18 @@ int ecgpu_ssz_prove(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_
             n_chunks = nf;
             pos = elem;
         } else if ((t.kind == ECGPU_SSZ_VECTOR || t.kind == ECGPU_SSZ_LIST) && types[t.elem].kind != ECGPU_SSZ_UINT) {
-            const u64 fs = w.fixed_size(t.elem);
+            // a homogeneous sequence of composite elements: element ranges on demand (a registry has 2^20 of them)
+            seq_fs = w.fixed_size(t.elem);
             u64 cnt = 0;
-            if (fs != kVariable) {
-                cnt = fs ? len / fs : 0;
-                for (u64 i = 0; i < cnt; i++) {
-                    a.push_back(i * fs);
-                    b.push_back((i + 1) * fs);
-                }
+            if (seq_fs != kVariable) {
+                if (seq_fs == 0 || len % seq_fs) return bad("sequence length is not a multiple of the element size");
+                cnt = len / seq_fs;
             } else if (len) {
+                if (len < 4) return bad("truncated offset table");
                 cnt = rd32p(obj) / 4;
-                for (u64 i = 0; i < cnt; i++) a.push_back(rd32p(obj + 4 * i));
-                for (u64 i = 0; i < cnt; i++) b.push_back(i + 1 < cnt ? a[i + 1] : len);
+                if (cnt == 0 || 4 * cnt > len) return bad("bad first offset");
             }
-            if (cnt > 65536) return bad("prove: sequences of more than 65 536 composite elements are not supported by the generic path");
+            is_seq = true;
             n_chunks = cnt;
             length = cnt;
             pos = elem;
@@ -318,7 +322,7 @@ int ecgpu_ssz_prove(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_
             n_chunks = chunks.size() / 32;
             pos = g & ((1ull << ceil_log2_u64(limit)) - 1);
         }
-        if (!a.empty() || t.kind == ECGPU_SSZ_CONTAINER) {
+        if (t.kind == ECGPU_SSZ_CONTAINER) {
             chunks.assign(32 * (n_chunks ? n_chunks : 1), 0);
             const u32* ftypes = t.kind == ECGPU_SSZ_CONTAINER ? fields + t.first_field : nullptr;
             for (u64 i = 0; i < n_chunks; i++) {
@@ -334,7 +338,13 @@ int ecgpu_ssz_prove(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_
         u8 data_root[32];
         if (is_len) {
             // proving the length node: its sibling is the root of the data tree
-            rc = ecgpu_merkleize(chunks.data(), 32 * n_chunks, limit, 0, 0, data_root);
+            if (is_seq) {  // merkleize(element roots, limit): the list without its mix-in, one plan
+                std::vector<ecgpu_ssz_type> tt(types, types + n_types);
+                tt.push_back(ecgpu_ssz_type{ECG_SSZ_LIST_NOMIX, t.elem, limit, 0, 0});
+                rc = htr_ssz_impl(tt.data(), n_types + 1, fields, n_field_refs, n_types, obj, len, data_root, true);
+            } else {
+                rc = ecgpu_merkleize(chunks.data(), 32 * n_chunks, limit, 0, 0, data_root);
+            }
             if (rc) return rc;
             std::memcpy(part.data(), data_root, 32);
             part.resize(32);
@@ -343,7 +353,43 @@ int ecgpu_ssz_prove(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_
             at_leaf_chunk = true;
         } else {
             if (pos >= (1ull << depth)) return bad("element outside the tree");
-            if (depth) {
+            if (depth && is_seq) {
+                // The sibling at level l is the root of the aligned subtree over elements [s 2^l, (s + 1) 2^l): ONE plan per level
+                // (a list of those elements without its length mix-in: ssz_plan.h ECG_SSZ_LIST_NOMIX), i.e. <= 40 batched
+                // launches for state.validators[i] of a 2^20-validator registry.  (Round 2 computed every element's root with a
+                // call of its own -- 65 535 host round trips per level -- and refused sequences beyond 65 536 elements.)
+                std::vector<ecgpu_ssz_type> tt(types, types + n_types);
+                tt.push_back(ecgpu_ssz_type{ECG_SSZ_LIST_NOMIX, t.elem, 0, 0, 0});
+                std::vector<u8> synth;
+                for (u32 l = 0; l < depth; l++) {
+                    const u64 sidx = (pos >> l) ^ 1, lo = sidx << l;
+                    u64 hi = (sidx + 1) << l;
+                    if (hi > n_chunks) hi = n_chunks;
+                    u8* dst = part.data() + 32ull * l;
+                    if (lo >= n_chunks) {  // an all-zero subtree of height l: the ladder entry, from the device
+                        rc = ecgpu_merkleize(nullptr, 0, 1ull << l, 0, 0, dst);
+                        if (rc) return rc;
+                        continue;
+                    }
+                    tt.back().param = 1ull << l;
+                    const u64 b0 = seq_lo(lo), b1 = hi < n_chunks ? seq_lo(hi) : len;
+                    if (b1 < b0 || b1 > len) return bad("offsets outside the object");
+                    if (seq_fs != kVariable) {
+                        rc = htr_ssz_impl(tt.data(), n_types + 1, fields, n_field_refs, n_types, obj + b0, b1 - b0, dst, true);
+                    } else {
+                        // variable-size elements: a list encoding of its own -- a fresh offset table in front of the elements' bytes
+                        const u64 k = hi - lo;
+                        synth.resize(4 * k + (b1 - b0));
+                        for (u64 i = 0; i < k; i++) {
+                            const u64 o = 4 * k + (seq_lo(lo + i) - b0);
+                            for (int q = 0; q < 4; q++) synth[4 * i + q] = (u8)(o >> (8 * q));
+                        }
+                        std::memcpy(synth.data() + 4 * k, obj + b0, b1 - b0);
+                        rc = htr_ssz_impl(tt.data(), n_types + 1, fields, n_field_refs, n_types, synth.data(), synth.size(), dst, true);
+                    }
+                    if (rc) return rc;
+                }
+            } else if (depth) {
                 rc = ecgpu_merkle_proof(chunks.data(), n_chunks, limit, pos, part.data());
                 if (rc) return rc;
             }
@@ -358,8 +404,10 @@ int ecgpu_ssz_prove(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_
                 at_leaf_chunk = true;
             } else {
                 if (pos >= n_chunks) return bad("path selects an element beyond the list's length");
-                obj = obj + a[pos];
-                len = b[pos] - a[pos];
+                const u64 c0 = is_seq ? seq_lo(pos) : a[pos], c1 = is_seq ? (pos + 1 < n_chunks ? seq_lo(pos + 1) : len) : b[pos];
+                if (c1 < c0 || c1 > len) return bad("offsets outside the object");
+                obj = obj + c0;
+                len = c1 - c0;
                 ti = child;
             }
         }

@@ -52,20 +52,30 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     u32* d_counters = (u32*)ar.take((TAIL_MAX_FIELDS + 4) * sizeof(u32));  // tile tickets, group A, group B, the poison flag
     if (!d_small || !d_gath || !d_tail || !d_counters) return ECGPU_ERR_OOM;
     u32* d_poison = d_counters + TAIL_MAX_FIELDS + 3;
+    // The small operations -- descriptor uploads, clearing the chunk buffer and the tickets, the gather kernel -- go to an
+    // auxiliary stream that starts where the caller's stream stands now (everything that wrote the encoding or still reads this
+    // arena is before that point) and joins it again in front of the tail: they run underneath the wide passes instead of in
+    // front of them (five dependent stream operations, ~30 us of a 1 ms root).
+    AuxStreams& ax = c->aux;
+    rc = ax.init();
+    if (rc) return rc;
+    hipStream_t sa = ax.st[0];
+    ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
+    ECG_HIP_CHECK(hipStreamWaitEvent(sa, ax.fork, 0));
     // descriptors travel through pageable memory: hipMemcpyAsync stages them before returning,
     // so the host vectors may die at the end of this call while the stream is still running.
     ECG_HIP_CHECK(hipMemcpyAsync(d_gath, plan.gathers.data(), plan.gathers.size() * sizeof(GatherDesc),
-                                 hipMemcpyHostToDevice, s));
-    ECG_HIP_CHECK(hipMemsetAsync(d_small, 0, small_bytes, s));
-    ECG_HIP_CHECK(hipMemsetAsync(d_counters, 0, (TAIL_MAX_FIELDS + 4) * sizeof(u32), s));
+                                 hipMemcpyHostToDevice, sa));
+    ECG_HIP_CHECK(hipMemsetAsync(d_small, 0, small_bytes, sa));
+    ECG_HIP_CHECK(hipMemsetAsync(d_counters, 0, (TAIL_MAX_FIELDS + 4) * sizeof(u32), sa));
     // The device entry never sees the payload header on the host: the extra_data offset word the host entries check
     // (state_plan.h) is compared on the device, and a mismatch poisons the root (32 x 0xFF; include/ecgpu.h).
     const bool dev_check = fork >= FORK_BELLATRIX && !h_payload_fixed && plan.payload_header_off != ~0ull;
-    rc = launch_gather(s, d_ssz, n_bytes, d_gath, (u32)plan.gathers.size(), d_small,
+    rc = launch_gather(sa, d_ssz, n_bytes, d_gath, (u32)plan.gathers.size(), d_small,
                        dev_check ? plan.payload_header_off + PAYLOAD_EXTRA_DATA_OFFSET_WORD : ~0ull, (u32)payload_header_fixed(fork), d_poison);
     if (rc) return rc;
     for (const StatePlan::ExtChunk& e : plan.ext_chunks)  // phase0: roots computed by the generic planner (pageable copy: staged before return)
-        ECG_HIP_CHECK(hipMemcpyAsync(d_small + 32ull * e.dst_chunk, ext_roots + e.src_off, 32, hipMemcpyHostToDevice, s));
+        ECG_HIP_CHECK(hipMemcpyAsync(d_small + 32ull * e.dst_chunk, ext_roots + e.src_off, 32, hipMemcpyHostToDevice, sa));
     u64 hc = plan.small_hashes;
     // Schedule (round 3): ONE stream.  The wide passes first -- the validator registry, 93 % of the hashes, and whatever other
     // field is too wide for a tile stage --, then ONE launch for everything that is left: the tile stages of all fields, their
@@ -137,7 +147,9 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         set_last_error("state plan without small fields");
         return ECGPU_ERR_BAD_ARG;
     }
-    ECG_HIP_CHECK(hipMemcpyAsync(d_tail, &tp, sizeof(TailPlan), hipMemcpyHostToDevice, s));
+    ECG_HIP_CHECK(hipMemcpyAsync(d_tail, &tp, sizeof(TailPlan), hipMemcpyHostToDevice, sa));
+    ECG_HIP_CHECK(hipEventRecord(ax.done[0], sa));
+    ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[0], 0));
     rc = launch_state_tail(s, d_tail, tp.n_tile_wgs + tp.n_jobs0, ar.base);
     if (rc) return rc;
     c->last_hash64 = hc;

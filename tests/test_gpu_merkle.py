@@ -457,6 +457,37 @@ def test_merkle_proof_of_a_chunk_array(gpu):
         ssz.merkle_proof(bytes(33), 0, 0)
 
 
+def test_proof_into_a_registry_of_more_than_65536_validators(gpu):
+    """state.validators[i].exit_epoch-style proofs through the generic prover on a List[Validator, 2^40] of 70 001 records
+    (round 2 refused sequences beyond 65 536 composite elements and made one host round trip per element): one plan per tree
+    level now.  Checked without the (slow) Python prover: the witness root equals the registry root of the dedicated entry,
+    the generalized index equals the oracle's, the leaf is the field's chunk, and the branch folds to the root."""
+    from ethereum_consensus_amd import ssz_types as T
+    from ethereum_consensus_amd import synthetic as syn
+    ssz = gpu
+    n = 70001
+    enc = syn.validators(n, seed=9).tobytes()
+    Validator_g = T.container(("public_key", T.bytevector(48)), ("withdrawal_credentials", T.Bytes32), ("effective_balance", T.uint64),
+                              ("slashed", T.uint(8)), ("activation_eligibility_epoch", T.uint64), ("activation_epoch", T.uint64),
+                              ("exit_epoch", T.uint64), ("withdrawable_epoch", T.uint64))
+    reg_g = T.list_(Validator_g, 1 << 40)
+    reg_o = ossz.SSZList(ossz.Validator, 1 << 40)
+    want_root = ssz.hash_tree_root_validators(enc)
+    for i, field, lo in ((0, "exit_epoch", 105), (n - 1, "effective_balance", 80), (65536, "withdrawable_epoch", 113), (40000, "withdrawal_credentials", 48)):
+        leaf, branch, g, root = ssz.prove(reg_g, enc, [i, field])
+        assert root == want_root
+        assert g == ossz.generalized_index(reg_o, [i, field])
+        size = 32 if field == "withdrawal_credentials" else 8
+        assert leaf == enc[121 * i + lo:121 * i + lo + size].ljust(32, b"\0")
+        depth = len(branch)
+        assert depth == 40 + 1 + 3 and ossz.is_valid_merkle_branch(leaf, branch, depth, g - (1 << depth), root)
+    # the length node of the same list, and an element past the end
+    leaf, branch, g, root = ssz.prove(reg_g, enc, [ssz.LENGTH])
+    assert leaf == n.to_bytes(32, "little") and len(branch) == 1 and ossz.is_valid_merkle_branch(leaf, branch, 1, 1, root) and root == want_root
+    with pytest.raises(ssz.MerkleizationError):
+        ssz.prove(reg_g, enc, [n, "exit_epoch"])
+
+
 def test_proofs_and_generalized_indices(gpu):
     """`prove` / `generalized_index` over the generic SSZ description against the oracle's restatement
     (oracle/ssz.py prove), the reference's pinned indices (deneb/beacon_block.rs:139-154) and ecgpu_is_valid_merkle_branch

@@ -12,7 +12,7 @@
 #   env:<K=V>        export K=V for the following steps (unenv:<K> removes it)
 #   to:<seconds>     timeout of the following probe steps (tt:<seconds>: of the test steps)
 #   run:<binary>     a probe binary (commas for spaces)              -> gpurun_out/<tag>_<binary>.txt
-#   py:<script>      python <script> (under tools/)                  -> gpurun_out/<tag>_<script>.txt
+#   py:<script>      python tools/<script> (commas for spaces)                  -> gpurun_out/<tag>_<script>.txt
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 mkdir -p gpurun_out
 tag=$1; shift
@@ -52,7 +52,7 @@ for step in "$@"; do
            rm -rf gpurun_out/pmc_${tag}_m_$c
          done;;
     run:*) c=${step#run:}; timeout $TO ${c//,/ } 2>&1 | tee gpurun_out/${tag}${sfx}_$(basename ${c%%,*}).txt | tail -40;;
-    py:*) s=${step#py:}; timeout 900 python tools/${s//_/ } 2>&1 | tee gpurun_out/${tag}${sfx}_$(echo $s | tr -c 'A-Za-z0-9' '_').txt | tail -40;;
+    py:*) s=${step#py:}; timeout 900 python tools/${s//,/ } 2>&1 | tee gpurun_out/${tag}${sfx}_$(echo $s | tr -c 'A-Za-z0-9' '_').txt | tail -40;;
     *) echo "unknown step $step";;
   esac
 done
