@@ -73,7 +73,7 @@ def effective_cores():
 
 def pmc_traffic(kernel_key: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate runs, see
-    profiles/pmc_traffic.json and tools/gpu_round1*.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the factor 2 is the gfx950
+    profiles/pmc_traffic.json and the `pmc` step of tools/gpu_visit.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the factor 2 is the gfx950
     FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  None when no pass has been recorded for this kernel."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -215,9 +215,9 @@ R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 # (ecgpu_bls_tower(): 1 = sums of products, 2 = compact-code G2 stage kernels; tools/bls_op_census.py prints these tuples).
 BLS_OPS_BY_BUILD = {
     1: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (218, 756, 522626), "bls_h2c": (562, 1895, 1205350),
-        "bls_pairing": (548, 2, 7410710)},
+        "bls_pairing": (588, 22, 6932650)},
     # compact-code build of the G2 stages (boxes with slow instruction fetch); the pairing check runs on the lane groups there
-    2: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (1476, 756, 0), "bls_h2c": (3512, 1895, 7920), "bls_pairing": (548, 2, 7410710)},
+    2: {"bls_pk_validate": (485, 686, 131040), "bls_sig": (1476, 756, 0), "bls_h2c": (3512, 1895, 7920), "bls_pairing": (588, 22, 6932650)},
 }
 BLS_OPS = BLS_OPS_BY_BUILD[1]
 PAIRING_KERNEL_BY_BUILD = {1: "k_pairing", 2: "k_pairing"}

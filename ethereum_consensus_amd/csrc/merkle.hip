@@ -56,9 +56,13 @@ __global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass(Leaf leaf, u64 n_in,
 constexpr int JOB_BLOCK = 256;
 __device__ __forceinline__ void run_tree_job(const TreeJob& job, u8* buf, const ZeroTable* zt) {
     __shared__ Node nodes[TREEJOB_MAX_NODES];
+    // the zero ladder in LDS: the climb below is up to ~30 dependent hash64 on one lane, and a global load per step (an L2
+    // miss whenever another workgroup's fence has invalidated the cache meanwhile) sat in that chain
+    __shared__ Node zl[65];
     const u32 t = threadIdx.x;
     u32 m = job.n;
     for (u32 i = t; i < m; i += JOB_BLOCK) node_load(nodes[i], buf + job.in_off + 32ull * i);
+    if (t < 65) zl[t] = zt->z[t];
     __syncthreads();
     u32 lvl = job.level;
     while (m > 1) {
@@ -69,7 +73,7 @@ __device__ __forceinline__ void run_tree_job(const TreeJob& job, u8* buf, const 
             u32 i = t + k * JOB_BLOCK;
             if (i < pairs) {
                 Node l = nodes[2 * i];
-                Node r = (2 * i + 1 < m) ? nodes[2 * i + 1] : zt->z[lvl];
+                Node r = (2 * i + 1 < m) ? nodes[2 * i + 1] : zl[lvl];
                 h[k] = hash64(l, r);
             }
         }
@@ -84,9 +88,9 @@ __device__ __forceinline__ void run_tree_job(const TreeJob& job, u8* buf, const 
         lvl++;
     }
     if (t == 0) {
-        Node x = (job.n == 0) ? zt->z[job.depth] : nodes[0];
+        Node x = (job.n == 0) ? zl[job.depth] : nodes[0];
         if (job.n != 0) {
-            for (; lvl < job.depth; lvl++) x = hash64(x, zt->z[lvl]);
+            for (; lvl < job.depth; lvl++) x = hash64(x, zl[lvl]);
         }
         if (job.mix) x = hash64(x, len_chunk(job.mix_len));
         node_store(x, buf + job.out_off);
@@ -194,7 +198,6 @@ __device__ __forceinline__ bool tail_last_arrival(u32* counter, u32 parties) {
     return last;
 }
 __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u8* buf, const ZeroTable* zt) {
-    __builtin_amdgcn_s_setprio(3);
     const TailPlan& P = *pl;
     u32 group;
     if (blockIdx.x < P.n_tile_wgs) {
@@ -202,6 +205,10 @@ __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u
         for (u32 i = 1; i < P.n_fields; i++)
             if (blockIdx.x >= P.fields[i].tile.first_wg) f = i;
         const TileDesc d = P.fields[f].tile;
+        // every wave here is a dependent chain of hash64; the critical field's chain (group B) is the longest: it gets issue
+        // priority over the others where they share a SIMD
+        if (P.fields[f].group) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(1);
         run_tile(d, zt);
         if (!tail_last_arrival(&P.counters[f], P.fields[f].n_tiles)) return;
         const TreeJob job = P.fields[f].job;

@@ -101,8 +101,9 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         TreeJob dj;
         TileDesc td;
         u32 n_tiles = 0;
-        rc = merkleize_device(s, b.kind, fptr[i], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk, ws, &hc, &dj, ar.base,
-                              i != biggest, nullptr, &td, &n_tiles);
+        // the critical field's passes on the caller's stream, the narrower fields' (one short pass each, if any) underneath them
+        rc = merkleize_device(i == biggest ? s : sa, b.kind, fptr[i], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk, ws,
+                              &hc, &dj, ar.base, i != biggest, nullptr, &td, &n_tiles);
         if (rc) return rc;
         const u32 group = (i == biggest && main_alone) ? 1u : 0u;
         if (n_tiles) {

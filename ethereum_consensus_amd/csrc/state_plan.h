@@ -100,6 +100,9 @@ inline MerkleSchedule schedule_merkleize(LeafKind kind, u64 n0, u32 depth, bool 
         n = n_out;
         first = false;
     };
+    // (Round 3 tried a throughput pre-pass for background fields wider than 2^15 nodes, on an auxiliary stream underneath the
+    // validator pass: the fused tail got shorter, 0.46 -> 0.39 ms, and the validator pass longer, 0.62 -> 0.68 ms -- 1.14 ms
+    // per root against 1.09: profiles/r03j_merkle_prepass_kernel_stats.txt.  Not kept.)
     while (n > 0 && ((first && kind == LEAF_VALIDATORS) || n > TILE_MAX_IN)) {
         int D = choose_pass_height(n, background);
         if ((u32)D > depth - level) D = (int)(depth - level);

@@ -1,4 +1,4 @@
-"""profiles/pmc_traffic.json from the two rocprofv3 --pmc passes of tools/gpu_profile_round.sh: per bench step, the sum of
+"""profiles/pmc_traffic.json from the two rocprofv3 --pmc passes of tools/gpu_visit.sh (step `pmc`): per bench step, the sum of
 FETCH_SIZE / WRITE_SIZE (KiB) over the launches of each dominant kernel.  usage: pmc_to_json.py TAG N_STEPS_IN_PMC_RUN"""
 import csv
 import glob
