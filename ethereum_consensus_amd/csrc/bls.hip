@@ -224,6 +224,185 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_scalar_mul(Aff<F>*
     pts[i] = a;
 }
 
+// ---- multi-scalar multiplication by buckets (Pippenger), n >= MSM_BUCKET_MIN terms ---------------------------------------------
+// 8-bit windows: window w of term i is byte w of its scalar (d in 0..255).  sum_i k_i P_i = sum_w 2^(8w) R_w with
+// R_w = sum_d d S_{w,d} and S_{w,d} the sum of the points whose window-w digit is d.  Phases, one launch each:
+//   digits -> histogram -> exclusive scan -> scatter : a counting sort of the (term, window) pairs by (window, digit); the order
+//       inside a bucket depends on the atomics and does not matter (the group law is exact: the sum is the same point)
+//   k_msm_buckets : one 64-lane workgroup per bucket -- lanes stride the bucket's list with mixed additions, LDS tree
+//   k_msm_windows : one workgroup per window, lane j owns buckets 4j+1 .. 4j+4: running sums give T_j = sum S and
+//       U_j = sum (d - 4j) S in 8 additions, the lane adds [4j] T_j (a 6-bit double-and-add), LDS tree over the 64 lanes
+//   k_msm_horner  : one lane, acc = 2^8 acc + R_w from the top window down -- the ~8 W dependent doublings no multi-scalar method
+//       avoids; then affine + compression like every aggregate.
+// Work per term: W mixed additions (32 for 255-bit scalars) instead of ~255 doublings + ~128 additions; the fixed cost is
+// 8 160 bucket workgroups + ~250 dependent doublings, which is why short inputs keep the lane-per-term form.
+constexpr u32 MSM_BUCKET_MIN = 4096;
+constexpr u32 MSM_C = 8, MSM_NB = 256;
+static size_t msm_ws_bytes(u32 n, size_t jac_bytes) {
+    return n >= MSM_BUCKET_MIN ? (size_t)32 * n * 4 + 32 * MSM_NB * (12 + jac_bytes) + 32 * jac_bytes + 4096 : 0;
+}
+ECG_D u32 msm_digit(const u8* scalars32, u32 i, u32 w, u32 bits) {
+    if (8 * w >= bits) return 0;
+    u32 d = scalars32[32 * (size_t)i + 31 - w];
+    if (8 * w + 8 > bits) d &= (1u << (bits - 8 * w)) - 1;
+    return d;
+}
+// usable terms only: a term with a failing status or the point at infinity contributes nothing (a failing status decides the
+// whole call elsewhere)
+template <class F>
+__global__ void k_msm_hist(const Aff<F>* pts, const u8* st, const u8* scalars32, u32 n, u32 n_win, u32 bits, u32* cnt) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_win) return;
+    const u32 i = t / n_win, w = t % n_win;
+    if ((st && st[i]) || pts[i].inf) return;
+    const u32 d = msm_digit(scalars32, i, w, bits);
+    if (d) atomicAdd(&cnt[w * MSM_NB + d], 1u);
+}
+// per window: exclusive prefix of the 256 counts (bucket d's list starts at w * n + off[d]) and the running cursors
+__global__ void __launch_bounds__(MSM_NB) k_msm_scan(const u32* cnt, u32* off, u32* cur) {
+    __shared__ u32 sh[MSM_NB];
+    const u32 w = blockIdx.x, d = threadIdx.x;
+    sh[d] = cnt[w * MSM_NB + d];
+    __syncthreads();
+    for (u32 s = 1; s < MSM_NB; s <<= 1) {
+        const u32 v = d >= s ? sh[d - s] : 0;
+        __syncthreads();
+        sh[d] += v;
+        __syncthreads();
+    }
+    const u32 excl = sh[d] - cnt[w * MSM_NB + d];
+    off[w * MSM_NB + d] = excl;
+    cur[w * MSM_NB + d] = excl;
+}
+template <class F>
+__global__ void k_msm_scatter(const Aff<F>* pts, const u8* st, const u8* scalars32, u32 n, u32 n_win, u32 bits, u32* cur, u32* idx) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_win) return;
+    const u32 i = t / n_win, w = t % n_win;
+    if ((st && st[i]) || pts[i].inf) return;
+    const u32 d = msm_digit(scalars32, i, w, bits);
+    if (d) idx[(size_t)w * n + atomicAdd(&cur[w * MSM_NB + d], 1u)] = i;
+}
+template <class F>
+__global__ void __launch_bounds__(64, ECG_BLS_WAVES) k_msm_buckets(const Aff<F>* pts, const u32* cnt, const u32* off, const u32* idx, u32 n,
+                                                                 Jac<F>* S) {
+    __shared__ Jac<F> sh[64];
+    const u32 b = blockIdx.x, w = b / MSM_NB, tid = threadIdx.x;  // bucket (w, d), d = b % 256; d = 0 is never used
+    const u32 m = cnt[b];
+    const u32* list = idx + (size_t)w * n + off[b];
+    Jac<F> acc;
+    jac_set_inf(acc);
+    for (u32 k = tid; k < m; k += 64) {
+        const u32 j = list[k];
+        F x = pts[j].x, y = pts[j].y;
+        jac_add_aff_inl(acc, acc, x, y);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (u32 stride = 32; stride > 0; stride >>= 1) {
+        if (tid < stride) {
+            Jac<F> o = sh[tid + stride];
+            jac_add_inl(acc, acc, o);
+            sh[tid] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) S[b] = acc;
+}
+template <class F>
+__global__ void __launch_bounds__(64, ECG_BLS_WAVES) k_msm_windows(const Jac<F>* S, Jac<F>* R) {
+    __shared__ Jac<F> sh[64];
+    const u32 w = blockIdx.x, j = threadIdx.x;
+    Jac<F> run, acc;
+    jac_set_inf(run);
+    jac_set_inf(acc);
+    for (int d = 4; d >= 1; d--) {  // buckets 4j + d, top down: acc = sum_d d S, run = sum_d S
+        const u32 bd = 4 * j + (u32)d;
+        if (bd < MSM_NB) {
+            Jac<F> s = S[w * MSM_NB + bd];
+            jac_add_inl(run, run, s);
+        }
+        jac_add_inl(acc, acc, run);
+    }
+    // + [4j] run: [j] ([4] run), j < 64
+    Jac<F> t4 = run;
+    jac_dbl_inl(t4, t4);
+    jac_dbl_inl(t4, t4);
+    Jac<F> m;
+    jac_set_inf(m);
+    for (int bit = 5; bit >= 0; bit--) {
+        jac_dbl_inl(m, m);
+        if ((j >> bit) & 1) jac_add_inl(m, m, t4);
+    }
+    jac_add_inl(acc, acc, m);
+    sh[j] = acc;
+    __syncthreads();
+    for (u32 stride = 32; stride > 0; stride >>= 1) {
+        if (j < stride) {
+            Jac<F> o = sh[j + stride];
+            jac_add_inl(acc, acc, o);
+            sh[j] = acc;
+        }
+        __syncthreads();
+    }
+    if (j == 0) R[w] = acc;
+}
+template <class F>
+__global__ void __launch_bounds__(64, ECG_BLS_WAVES) k_msm_horner(const Jac<F>* R, u32 n_win, Aff<F>* out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Jac<F> acc = R[n_win - 1];
+    for (int w = (int)n_win - 2; w >= 0; w--) {
+        for (u32 k = 0; k < MSM_C; k++) jac_dbl_inl(acc, acc);
+        Jac<F> r = R[w];
+        jac_add_inl(acc, acc, r);
+    }
+    Aff<F> a;
+    jac_to_aff(a, acc);
+    *out = a;
+}
+// sum over the usable terms into *sum (affine); workspace from the call's arena.  st: per-term status or nullptr.
+template <class F>
+static int msm_buckets_device(hipStream_t s, Arena& ar, const Aff<F>* pts, const u8* st, const u8* d_scalars32, u32 n, u32 bits, Aff<F>* sum) {
+    const u32 n_win = (bits + MSM_C - 1) / MSM_C;
+    u32* cnt = (u32*)ar.take((size_t)3 * n_win * MSM_NB * 4);
+    u32* idx = (u32*)ar.take((size_t)n_win * n * 4);
+    Jac<F>* S = (Jac<F>*)ar.take((size_t)n_win * MSM_NB * sizeof(Jac<F>));
+    Jac<F>* R = (Jac<F>*)ar.take((size_t)n_win * sizeof(Jac<F>));
+    if (!cnt || !idx || !S || !R) return ECGPU_ERR_OOM;
+    u32 *off = cnt + n_win * MSM_NB, *cur = off + n_win * MSM_NB;
+    ECG_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)n_win * MSM_NB * 4, s));
+    const u32 items = n * n_win;
+    {
+        ProfScope ps("bls_msm_sort", s);
+        hipLaunchKernelGGL(k_msm_hist<F>, dim3((items + 255) / 256), dim3(256), 0, s, pts, st, d_scalars32, n, n_win, bits, cnt);
+        hipLaunchKernelGGL(k_msm_scan, dim3(n_win), dim3(MSM_NB), 0, s, (const u32*)cnt, off, cur);
+        hipLaunchKernelGGL(k_msm_scatter<F>, dim3((items + 255) / 256), dim3(256), 0, s, pts, st, d_scalars32, n, n_win, bits, cur, idx);
+    }
+    {
+        ProfScope ps("bls_msm_buckets", s);
+        hipLaunchKernelGGL(k_msm_buckets<F>, dim3(n_win * MSM_NB), dim3(64), 0, s, pts, (const u32*)cnt, (const u32*)off, (const u32*)idx, n, S);
+    }
+    {
+        ProfScope ps("bls_msm_reduce", s);
+        hipLaunchKernelGGL(k_msm_windows<F>, dim3(n_win), dim3(64), 0, s, (const Jac<F>*)S, R);
+        hipLaunchKernelGGL(k_msm_horner<F>, dim3(1), dim3(64), 0, s, (const Jac<F>*)R, n_win, sum);
+    }
+    ECG_HIP_CHECK(hipGetLastError());
+    return ECGPU_SUCCESS;
+}
+// first non-zero status of a list (the G1 form of k_agg_sig_status)
+__global__ void __launch_bounds__(AGG_STATUS_BLOCK) k_first_status(const u8* st, u32 n, u8* out) {
+    __shared__ u32 first;
+    if (threadIdx.x == 0) first = 0xffffffffu;
+    __syncthreads();
+    u32 mine = 0xffffffffu;
+    for (u32 i = threadIdx.x; i < n && mine == 0xffffffffu; i += AGG_STATUS_BLOCK)
+        if (st[i]) mine = i;
+    if (mine != 0xffffffffu) atomicMin(&first, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = first != 0xffffffffu ? st[first] : (u8)0;
+}
+
 // ---- host drivers ----------------------------------------------------------------------------
 
 // message stage on two lanes per message up to this many tuples (twice as many lanes still fit one wave per SIMD)
@@ -686,7 +865,7 @@ int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uin
     if (n == 0) return ECGPU_EMPTY_AGGREGATE;
     if (!pks48 || !scalars32 || !out48 || scalar_bits == 0 || scalar_bits > 256) return ECGPU_ERR_BAD_ARG;
     CallCtx k;
-    int rc = begin_call(k, nullptr, (size_t)n * (48 + 32 + sizeof(A1) + 1) + sizeof(A1) + 8192);
+    int rc = begin_call(k, nullptr, (size_t)n * (48 + 32 + sizeof(A1) + 1) + sizeof(A1) + msm_ws_bytes(n, sizeof(J1)) + 8192);
     if (rc) return rc;
     u8 *d_pks, *d_sc;
     if ((rc = h2d(k, d_pks, pks48, (size_t)n * 48))) return rc;
@@ -697,11 +876,17 @@ int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uin
     u8* d_out = k.ar->take(48 + 1);
     if (!pts || !st || !sum || !d_out) return ECGPU_ERR_OOM;
     launch_pk_validate(k.s, d_pks, n, pts, st);
-    {
-        ProfScope ps("bls_scalar_mul_g1", k.s);
-        hipLaunchKernelGGL(k_scalar_mul<Fp>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st, (const u8*)d_sc, scalar_bits, n);
+    if (n >= MSM_BUCKET_MIN) {
+        hipLaunchKernelGGL(k_first_status, dim3(1), dim3(AGG_STATUS_BLOCK), 0, k.s, (const u8*)st, n, d_out + 48);
+        rc = msm_buckets_device<Fp>(k.s, *k.ar, (const A1*)pts, (const u8*)st, (const u8*)d_sc, n, scalar_bits, sum);
+        if (rc) return rc;
+    } else {
+        {
+            ProfScope ps("bls_scalar_mul_g1", k.s);
+            hipLaunchKernelGGL(k_scalar_mul<Fp>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st, (const u8*)d_sc, scalar_bits, n);
+        }
+        launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48);
     }
-    launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48);
     hipLaunchKernelGGL(k_compress_g1, dim3(1), dim3(64), 0, k.s, (const A1*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
     u8 h[49];
@@ -717,7 +902,7 @@ int ecgpu_g2_msm(const uint8_t* sigs96, const uint8_t* scalars32, uint32_t n, ui
     if (n == 0) return ECGPU_EMPTY_AGGREGATE;
     if (!sigs96 || !scalars32 || !out96 || scalar_bits == 0 || scalar_bits > 256) return ECGPU_ERR_BAD_ARG;
     CallCtx k;
-    int rc = begin_call(k, nullptr, (size_t)n * (96 + 32 + sizeof(A2) + 2) + sizeof(A2) + 8192);
+    int rc = begin_call(k, nullptr, (size_t)n * (96 + 32 + sizeof(A2) + 2) + sizeof(A2) + msm_ws_bytes(n, sizeof(J2)) + 8192);
     if (rc) return rc;
     u8 *d_sigs, *d_sc;
     if ((rc = h2d(k, d_sigs, sigs96, (size_t)n * 96))) return rc;
@@ -730,11 +915,17 @@ int ecgpu_g2_msm(const uint8_t* sigs96, const uint8_t* scalars32, uint32_t n, ui
     if (!pts || !st_dec || !st_grp || !sum || !d_out) return ECGPU_ERR_OOM;
     hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_sigs, n, pts, st_dec, st_grp);
     hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(AGG_STATUS_BLOCK), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
-    {
-        ProfScope ps("bls_scalar_mul_g2", k.s);
-        hipLaunchKernelGGL(k_scalar_mul<Fp2>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st_dec, (const u8*)d_sc, scalar_bits, n);
+    if (n >= MSM_BUCKET_MIN) {
+        // (a signature that fails its decoding or group check decides the call through k_agg_sig_status; the sum is then unused)
+        rc = msm_buckets_device<Fp2>(k.s, *k.ar, (const A2*)pts, (const u8*)st_dec, (const u8*)d_sc, n, scalar_bits, sum);
+        if (rc) return rc;
+    } else {
+        {
+            ProfScope ps("bls_scalar_mul_g2", k.s);
+            hipLaunchKernelGGL(k_scalar_mul<Fp2>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st_dec, (const u8*)d_sc, scalar_bits, n);
+        }
+        launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr);
     }
-    launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr);
     hipLaunchKernelGGL(k_compress_g2, dim3(1), dim3(64), 0, k.s, (const A2*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
     u8 h[97];

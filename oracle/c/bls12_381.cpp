@@ -938,6 +938,42 @@ void f12_to_bytes(const Fp12& a, u8* out) {  // 12 x 48 canonical big-endian byt
     }
 }
 
+// (the terms are independent: `threads` host threads each sum a stride, the partial sums are added in thread order)
+template <class Ops, class AffT, class Decode>
+static int msm_threads(const u8* pts, size_t pt_bytes, const u8* scalars32, uint32_t n, int threads, Decode decode, Jac<Ops>& total) {
+    if (threads < 1) threads = 1;
+    std::vector<Jac<Ops>> part(threads, jac_inf<Ops>());
+    std::vector<int> status(threads, OK);
+    std::vector<uint32_t> bad_at(threads, 0xffffffffu);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            for (uint32_t i = t; i < n; i += threads) {
+                AffT p;
+                int st = decode(p, pts + pt_bytes * (size_t)i);
+                if (st) {
+                    status[t] = st;
+                    bad_at[t] = i;
+                    return;
+                }
+                u64 k[4];
+                scalar_from_be32(scalars32 + 32 * (size_t)i, k);
+                part[t] = jac_add<Ops>(part[t], jac_mul<Ops>(jac_from_aff<Ops>(p), k, 4));
+            }
+        });
+    for (auto& x : th) x.join();
+    uint32_t first = 0xffffffffu;
+    int st = OK;
+    for (int t = 0; t < threads; t++)
+        if (bad_at[t] < first) {
+            first = bad_at[t];
+            st = status[t];
+        }
+    if (st) return st;
+    total = jac_inf<Ops>();
+    for (int t = 0; t < threads; t++) total = jac_add<Ops>(total, part[t]);
+    return OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1018,32 +1054,23 @@ int cbls_aggregate_sigs(const u8* sigs96, uint32_t n, u8* out96) {
 }
 // sum_i [k_i] P_i by plain double-and-add (the definition), k_i = 32 big-endian bytes; points are validated keys / decoded
 // group-checked signatures; returns the first failing point's status
-int cbls_g1_msm(const u8* pks48, const u8* scalars32, uint32_t n, u8* out48) {
+int cbls_g1_msm(const u8* pks48, const u8* scalars32, uint32_t n, u8* out48, int threads) {
     init_constants();
-    J1 acc = jac_inf<FOps1>();
-    for (uint32_t i = 0; i < n; i++) {
-        A1 p;
-        int st = key_validate(p, pks48 + 48 * (size_t)i);
-        if (st) return st;
-        u64 k[4];
-        scalar_from_be32(scalars32 + 32 * (size_t)i, k);
-        acc = jac_add<FOps1>(acc, jac_mul<FOps1>(jac_from_aff<FOps1>(p), k, 4));
-    }
+    J1 acc;
+    int st = msm_threads<FOps1, A1>(pks48, 48, scalars32, n, threads, [](A1& p, const u8* b) { return key_validate(p, b); }, acc);
+    if (st) return st;
     g1_compress(out48, jac_to_aff<FOps1>(acc));
     return OK;
 }
-int cbls_g2_msm(const u8* sigs96, const u8* scalars32, uint32_t n, u8* out96) {
+int cbls_g2_msm(const u8* sigs96, const u8* scalars32, uint32_t n, u8* out96, int threads) {
     init_constants();
-    J2 acc = jac_inf<FOps2>();
-    for (uint32_t i = 0; i < n; i++) {
-        A2 q;
-        int st = g2_decompress(q, sigs96 + 96 * (size_t)i);
-        if (st) return st;
-        if (!q.inf && !g2_in_subgroup(q)) return NOT_IN_GROUP;
-        u64 k[4];
-        scalar_from_be32(scalars32 + 32 * (size_t)i, k);
-        acc = jac_add<FOps2>(acc, jac_mul<FOps2>(jac_from_aff<FOps2>(q), k, 4));
-    }
+    J2 acc;
+    int st = msm_threads<FOps2, A2>(sigs96, 96, scalars32, n, threads, [](A2& q, const u8* b) {
+        int s = g2_decompress(q, b);
+        if (s) return s;
+        return (!q.inf && !g2_in_subgroup(q)) ? (int)NOT_IN_GROUP : (int)OK;
+    }, acc);
+    if (st) return st;
     g2_compress(out96, jac_to_aff<FOps2>(acc));
     return OK;
 }

@@ -29,8 +29,8 @@ def lib():
         L.cbls_pairing.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
         L.cbls_aggregate_verify.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
         L.cbls_aggregate_sigs.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p]
-        L.cbls_g1_msm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p]
-        L.cbls_g2_msm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p]
+        L.cbls_g1_msm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int]
+        L.cbls_g2_msm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int]
         L.cbls_init()
         _lib = L
     return _lib
@@ -108,11 +108,11 @@ def aggregate(sigs):
 
 def g1_msm(pks, scalars):
     out = ctypes.create_string_buffer(48)
-    st = lib().cbls_g1_msm(b"".join(pks), b"".join(int(k).to_bytes(32, "big") for k in scalars), len(pks), out)
+    st = lib().cbls_g1_msm(b"".join(pks), b"".join(int(k).to_bytes(32, "big") for k in scalars), len(pks), out, host_threads())
     return st, (out.raw if st == 0 else None)
 
 
 def g2_msm(sigs, scalars):
     out = ctypes.create_string_buffer(96)
-    st = lib().cbls_g2_msm(b"".join(sigs), b"".join(int(k).to_bytes(32, "big") for k in scalars), len(sigs), out)
+    st = lib().cbls_g2_msm(b"".join(sigs), b"".join(int(k).to_bytes(32, "big") for k in scalars), len(sigs), out, host_threads())
     return st, (out.raw if st == 0 else None)

@@ -236,6 +236,38 @@ def test_multi_scalar_multiplication_4096_points_255_bit_scalars(gpu):
     assert (0, M.g2_multi_scalar_mul(sigs, ks[:n2], 255)) == cbls.g2_msm(sigs, ks[:n2])
 
 
+def test_multi_scalar_multiplication_by_buckets(gpu):
+    """The bucket method (csrc/bls.hip: counting sort by window digit, one workgroup per bucket, running-sum reduction per
+    window, Horner over the windows; n >= 4 096 terms) against the C++ oracle's plain double-and-add sums: G1 at n = 2^16 with
+    255-bit scalars (round-2 verdict), 64-bit coefficients (the batch-check use), a scalar width that is not a multiple of the
+    window, G2 at n = 2^13; zero scalars, repeated points and the identity among the terms; a bad point near the end decides
+    the call with its status."""
+    from ethereum_consensus_amd import bls as M
+    from ethereum_consensus_amd import synthetic as syn
+    from oracle import cbls
+    r = random.Random(65536)
+    n = 65536
+    skb = syn.bls_secret_keys(n)
+    pk_all = gpu.sk_to_pk_batch(skb)
+    pks = [pk_all[48 * i:48 * i + 48] for i in range(n)]
+    pks[17] = pks[16]
+    for bits, m in ((255, n), (64, 8192), (13, 5000)):
+        ks = [r.randrange(0, 1 << bits) for _ in range(m)]
+        ks[3] = 0
+        ks[5] = (1 << bits) - 1
+        assert (0, M.g1_multi_scalar_mul(pks[:m], ks, bits)) == cbls.g1_msm(pks[:m], ks), (bits, m)
+    bad = list(pks[:6000])
+    bad[5990] = syn.off_subgroup_public_key(3)
+    with pytest.raises(M.BLSTError):
+        M.g1_multi_scalar_mul(bad, [1] * 6000, 64)
+    n2 = 8192
+    sig_all = gpu.sign_batch(skb[:32 * n2], [S(b"msm", i % 5) for i in range(n2)])
+    sigs = [sig_all[96 * i:96 * i + 96] for i in range(n2)]
+    sigs[9] = B.INFINITY_SIGNATURE
+    ks = [r.randrange(0, 1 << 255) for _ in range(n2)]
+    assert (0, M.g2_multi_scalar_mul(sigs, ks, 255)) == cbls.g2_msm(sigs, ks)
+
+
 def test_batch_4096_with_fault_injection(gpu):
     """SURVEY.md 8(d) config-2 shape at a size the GPU finishes in well under a second: K = 1 tuples
     generated on the device (sk -> pk, sign), every 16th tuple corrupted; the expected status of each

@@ -14,6 +14,8 @@ for key in ("aggregates_k2048", "merkle", "epoch", "slots", "strong_2p20"):
         print("  %s: %.3f ms/step  %.4g %s  check %s" % (key, e.get("ms_per_step", 0), e.get("value", 0), e.get("unit"), e.get("check")))
 if "block" in d:
     print("  block", round(d["block"]["reference_semantics"]["block_verify_ms"], 2), round(d["block"]["validated_key_registry"]["block_verify_ms"], 2))
+if "msm" in d:
+    print("  msm", {k: (round(v["ms"], 2), round(v["points_per_s"])) for k, v in d["msm"].items() if k.startswith("g1_")}, d["msm"]["check"])
 if "box_selfcheck" in d:
     print("  box slowdown", round(d["box_selfcheck"]["large_code_slowdown"], 2), d["box_selfcheck"]["pairing_kernels"])
 if "cpu_baseline" in d:
