@@ -199,36 +199,32 @@ __device__ __forceinline__ bool tail_last_arrival(u32* counter, u32 parties) {
 }
 __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u8* buf, const ZeroTable* zt) {
     const TailPlan& P = *pl;
-    u32 group;
+    u32 feeds;
     if (blockIdx.x < P.n_tile_wgs) {
         u32 f = 0;
         for (u32 i = 1; i < P.n_fields; i++)
             if (blockIdx.x >= P.fields[i].tile.first_wg) f = i;
         const TileDesc d = P.fields[f].tile;
-        // every wave here is a dependent chain of hash64; the critical field's chain (group B) is the longest: it gets issue
-        // priority over the others where they share a SIMD
-        if (P.fields[f].group) __builtin_amdgcn_s_setprio(3);
+        // every wave here is a dependent chain of hash64; the critical field's gets issue priority where chains share a SIMD
+        if (P.fields[f].prio) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(1);
         run_tile(d, zt);
         if (!tail_last_arrival(&P.counters[f], P.fields[f].n_tiles)) return;
         const TreeJob job = P.fields[f].job;
         run_tree_job(job, buf, zt);
-        group = P.fields[f].group;
+        feeds = P.fields[f].feeds;
     } else {
         const u32 j = blockIdx.x - P.n_tile_wgs;
         const TreeJob job = P.jobs0[j];
         run_tree_job(job, buf, zt);
-        group = P.jobs0_group[j];
+        feeds = P.jobs0_feeds[j];
     }
-    if (group == 0) {
-        if (!tail_last_arrival(&P.counters[P.n_fields], P.units_a)) return;
-        for (u32 j = 0; j < P.n_jobs1; j++) {
-            const TreeJob job = P.jobs1[j];
-            run_tree_job(job, buf, zt);
-            __syncthreads();  // lane 0 is done with the LDS nodes before the next job loads its own
-        }
+    if (feeds != TAIL_NONE) {  // an input of a nested container: its last input to arrive computes it
+        if (!tail_last_arrival(&P.counters[P.n_fields + feeds], P.jobs1_deps[feeds])) return;
+        const TreeJob job = P.jobs1[feeds];
+        run_tree_job(job, buf, zt);
     }
-    if (!tail_last_arrival(&P.counters[P.n_fields + 1], P.units_b)) return;
+    if (!tail_last_arrival(&P.counters[P.n_fields + P.n_jobs1], P.final_parties)) return;
     const TreeJob top = P.job2;
     run_tree_job(top, buf, zt);
     __syncthreads();

@@ -48,30 +48,34 @@ int launch_gather(hipStream_t s, const u8* d_src, u64 src_total, const GatherDes
 // ---- the fused tail of a BeaconState root (state_deneb.hip) -----------------------------------------------------------------
 // After the wide passes, everything that is left of a state root is latency: per field a tile stage (1024 nodes -> 1 per
 // workgroup), a finishing job (<= 512 nodes -> root, zero ladder, length mix-in), then the nested containers and the state
-// container.  Round 2 ran that as ~6 dependent launches on two streams joined by events (~0.3 ms of a 1.08 ms root, a third
-// of it launch and event latency).  k_state_tail is ONE launch: every tile workgroup takes a ticket of its field when its
-// node is stored, the LAST one runs the field's finishing job; every finished unit of group A (everything but the field on
-// the critical path) takes a ticket, the last one runs the nested containers; that arrival and the critical field's are the
-// two tickets of group B, and the later one runs the state container and writes the root.  No workgroup ever waits for
-// another (no spinning, nothing to deadlock): whoever arrives last carries on.
+// container.  Round 2 ran that as ~6 dependent launches on two streams joined by events.  k_state_tail is ONE launch chained by
+// ARRIVAL TICKETS: every tile workgroup takes a ticket of its field when its node is stored, and the LAST one runs the field's
+// finishing job; a finished unit whose root is an input of a nested container takes a ticket of THAT container, and the last
+// one runs it; every unit that feeds the state container directly, and every nested container, takes a ticket of the state
+// container, and the last one computes it and writes the root.  No workgroup ever waits for another (no spinning, nothing to
+// deadlock): whoever arrives last carries on.
+constexpr u32 TAIL_NONE = 0xffffffffu;
 struct TailField {
     TileDesc tile;
     TreeJob job;
     u32 n_tiles;
-    u32 group;  // 0 = A, 1 = B
+    u32 feeds;  // index of the nested container this field's root is an input of, or TAIL_NONE
+    u32 prio;   // 1: the field on the critical path (its chain waves get issue priority)
+    u32 pad_;
 };
 constexpr u32 TAIL_MAX_FIELDS = 24, TAIL_MAX_JOBS0 = 64, TAIL_MAX_JOBS1 = 8;
 struct TailPlan {
     TailField fields[TAIL_MAX_FIELDS];  // fields with a tile stage, in workgroup order
     TreeJob jobs0[TAIL_MAX_JOBS0];      // units without one: leaf containers, finishing jobs of short or empty fields
-    u32 jobs0_group[TAIL_MAX_JOBS0];
-    TreeJob jobs1[TAIL_MAX_JOBS1];      // nested containers (inputs: group A only)
+    u32 jobs0_feeds[TAIL_MAX_JOBS0];
+    TreeJob jobs1[TAIL_MAX_JOBS1];      // nested containers
+    u32 jobs1_deps[TAIL_MAX_JOBS1];     // units feeding each (>= 1)
     TreeJob job2;                       // the state container
-    u32 n_fields, n_tile_wgs, n_jobs0, n_jobs1, units_a, units_b;
+    u32 n_fields, n_tile_wgs, n_jobs0, n_jobs1, final_parties, pad_;
     u64 root_off, froots_off;           // byte offsets in the job buffer: the state root, the 32 field-root chunks
     u8* d_root;
     u8* d_field_roots;                  // may be null
-    u32* counters;                      // [n_fields] tile tickets, [n_fields] group A, [n_fields + 1] group B; zero before the launch
+    u32* counters;                      // [n_fields] tile tickets, [n_jobs1] nested containers, [1] the state container; zero before the launch
     const u32* poison;                  // *poison != 0: the root is written as 32 x 0xFF (launch_gather's check failed)
 };
 int launch_state_tail(hipStream_t s, const TailPlan* d_plan, u32 n_wgs, u8* d_buf);

@@ -49,9 +49,9 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     u8* d_small = ar.take(small_bytes);
     GatherDesc* d_gath = (GatherDesc*)ar.take(plan.gathers.size() * sizeof(GatherDesc));
     TailPlan* d_tail = (TailPlan*)ar.take(sizeof(TailPlan));
-    u32* d_counters = (u32*)ar.take((TAIL_MAX_FIELDS + 4) * sizeof(u32));  // tile tickets, group A, group B, the poison flag
+    u32* d_counters = (u32*)ar.take((TAIL_MAX_FIELDS + TAIL_MAX_JOBS1 + 4) * sizeof(u32));  // tickets (fields, nested, state), the poison flag
     if (!d_small || !d_gath || !d_tail || !d_counters) return ECGPU_ERR_OOM;
-    u32* d_poison = d_counters + TAIL_MAX_FIELDS + 3;
+    u32* d_poison = d_counters + TAIL_MAX_FIELDS + TAIL_MAX_JOBS1 + 3;
     // The small operations -- descriptor uploads, clearing the chunk buffer and the tickets, the gather kernel -- go to an
     // auxiliary stream that starts where the caller's stream stands now (everything that wrote the encoding or still reads this
     // arena is before that point) and joins it again in front of the tail: they run underneath the wide passes instead of in
@@ -67,7 +67,7 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     ECG_HIP_CHECK(hipMemcpyAsync(d_gath, plan.gathers.data(), plan.gathers.size() * sizeof(GatherDesc),
                                  hipMemcpyHostToDevice, sa));
     ECG_HIP_CHECK(hipMemsetAsync(d_small, 0, small_bytes, sa));
-    ECG_HIP_CHECK(hipMemsetAsync(d_counters, 0, (TAIL_MAX_FIELDS + 4) * sizeof(u32), sa));
+    ECG_HIP_CHECK(hipMemsetAsync(d_counters, 0, (TAIL_MAX_FIELDS + TAIL_MAX_JOBS1 + 4) * sizeof(u32), sa));
     // The device entry never sees the payload header on the host: the extra_data offset word the host entries check
     // (state_plan.h) is compared on the device, and a mismatch poisons the root (32 x 0xFF; include/ecgpu.h).
     const bool dev_check = fork >= FORK_BELLATRIX && !h_payload_fixed && plan.payload_header_off != ~0ull;
@@ -86,11 +86,8 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     size_t biggest = 0;
     for (size_t i = 1; i < plan.bigs.size(); i++)
         if (plan.bigs[i].bytes > plan.bigs[biggest].bytes) biggest = i;
-    // the field on the critical path takes the second ticket of group B on its own -- unless a nested container waits for it
-    const bool main_alone = plan.bigs[biggest].out_chunk < 32;
     static TailPlan tp_init{};
     TailPlan tp = tp_init;
-    u32 units_a = 0, units_main = 0;
     std::vector<size_t> order{biggest};
     for (size_t i = 0; i < plan.bigs.size(); i++)
         if (i != biggest) order.push_back(i);
@@ -101,22 +98,19 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         TreeJob dj;
         TileDesc td;
         u32 n_tiles = 0;
-        // the critical field's passes on the caller's stream, the narrower fields' (one short pass each, if any) underneath them
-        rc = merkleize_device(i == biggest ? s : sa, b.kind, fptr[i], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk, ws,
-                              &hc, &dj, ar.base, i != biggest, nullptr, &td, &n_tiles);
+        rc = merkleize_device(s, b.kind, fptr[i], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk, ws, &hc, &dj, ar.base,
+                              i != biggest, nullptr, &td, &n_tiles);
         if (rc) return rc;
-        const u32 group = (i == biggest && main_alone) ? 1u : 0u;
         if (n_tiles) {
             if (tp.n_fields >= TAIL_MAX_FIELDS) return ECGPU_ERR_BAD_ARG;
             td.first_wg = tp.n_tile_wgs;
-            tp.fields[tp.n_fields++] = TailField{td, dj, n_tiles, group};
+            tp.fields[tp.n_fields++] = TailField{td, dj, n_tiles, TAIL_NONE, i == biggest ? 1u : 0u, 0u};
             tp.n_tile_wgs += n_tiles;
         } else {
             if (tp.n_jobs0 >= TAIL_MAX_JOBS0) return ECGPU_ERR_BAD_ARG;
             tp.jobs0[tp.n_jobs0] = dj;
-            tp.jobs0_group[tp.n_jobs0++] = group;
+            tp.jobs0_feeds[tp.n_jobs0++] = TAIL_NONE;
         }
-        (group ? units_main : units_a)++;
     }
     // level jobs were planned relative to the small-chunk buffer: rebase them onto the arena like the deferred ones
     const u64 small_off = (u64)(d_small - ar.base);
@@ -125,29 +119,60 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         j.out_off += small_off;
         return j;
     };
-    if (tp.n_jobs0 + plan.jobs[0].size() > TAIL_MAX_JOBS0 || plan.jobs[1].size() > TAIL_MAX_JOBS1 || plan.jobs[2].size() != 1) {
+    if (tp.n_jobs0 + plan.jobs[0].size() + plan.jobs[1].size() > TAIL_MAX_JOBS0 || plan.jobs[1].size() > TAIL_MAX_JOBS1 || plan.jobs[2].size() != 1) {
         set_last_error("state plan does not fit the fused tail");
         return ECGPU_ERR_BAD_ARG;
     }
     for (const TreeJob& j : plan.jobs[0]) {
         tp.jobs0[tp.n_jobs0] = rebased(j);
-        tp.jobs0_group[tp.n_jobs0++] = 0;
-        units_a++;
+        tp.jobs0_feeds[tp.n_jobs0++] = TAIL_NONE;
     }
-    for (const TreeJob& j : plan.jobs[1]) tp.jobs1[tp.n_jobs1++] = rebased(j);
+    // which nested container (if any) a unit's root is an input of: its output chunk lies inside that container's input block
+    std::vector<TreeJob> nested;
+    for (const TreeJob& j : plan.jobs[1]) nested.push_back(rebased(j));
+    std::vector<u32> deps(nested.size(), 0);
+    auto feeds_of = [&](const TreeJob& unit) -> u32 {
+        for (size_t k = 0; k < nested.size(); k++)
+            if (unit.out_off >= nested[k].in_off && unit.out_off < nested[k].in_off + 32ull * nested[k].n) return (u32)k;
+        return TAIL_NONE;
+    };
+    for (u32 f = 0; f < tp.n_fields; f++) {
+        tp.fields[f].feeds = feeds_of(tp.fields[f].job);
+        if (tp.fields[f].feeds != TAIL_NONE) deps[tp.fields[f].feeds]++;
+    }
+    for (u32 j = 0; j < tp.n_jobs0; j++) {
+        tp.jobs0_feeds[j] = feeds_of(tp.jobs0[j]);
+        if (tp.jobs0_feeds[j] != TAIL_NONE) deps[tp.jobs0_feeds[j]]++;
+    }
+    // a nested container nobody feeds (all of its inputs are gathered chunks) is a unit of its own; the others keep their order
+    std::vector<u32> remap(nested.size(), TAIL_NONE);
+    for (size_t k = 0; k < nested.size(); k++) {
+        if (deps[k] == 0) {
+            tp.jobs0[tp.n_jobs0] = nested[k];
+            tp.jobs0_feeds[tp.n_jobs0++] = TAIL_NONE;
+        } else {
+            remap[k] = tp.n_jobs1;
+            tp.jobs1[tp.n_jobs1] = nested[k];
+            tp.jobs1_deps[tp.n_jobs1++] = deps[k];
+        }
+    }
+    u32 direct = 0;
+    for (u32 f = 0; f < tp.n_fields; f++) {
+        if (tp.fields[f].feeds != TAIL_NONE) tp.fields[f].feeds = remap[tp.fields[f].feeds];
+        if (tp.fields[f].feeds == TAIL_NONE) direct++;
+    }
+    for (u32 j = 0; j < tp.n_jobs0; j++) {
+        if (tp.jobs0_feeds[j] != TAIL_NONE) tp.jobs0_feeds[j] = remap[tp.jobs0_feeds[j]];
+        if (tp.jobs0_feeds[j] == TAIL_NONE) direct++;
+    }
     tp.job2 = rebased(plan.jobs[2][0]);
-    tp.units_a = units_a;
-    tp.units_b = 1 + units_main;  // group A's last arrival + the critical field
+    tp.final_parties = direct + tp.n_jobs1;
     tp.root_off = small_off + 32ull * plan.root_chunk;
     tp.froots_off = small_off;  // chunks 0 .. 31 of the small buffer are the roots of the state's fields (proofs: ssz_proof.hip)
     tp.d_root = d_root;
     tp.d_field_roots = d_field_roots;
     tp.counters = d_counters;
     tp.poison = d_poison;
-    if (units_a == 0) {  // cannot happen with the forks this plan knows (there are always leaf containers)
-        set_last_error("state plan without small fields");
-        return ECGPU_ERR_BAD_ARG;
-    }
     ECG_HIP_CHECK(hipMemcpyAsync(d_tail, &tp, sizeof(TailPlan), hipMemcpyHostToDevice, sa));
     ECG_HIP_CHECK(hipEventRecord(ax.done[0], sa));
     ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[0], 0));
