@@ -215,12 +215,14 @@ __global__ void __launch_bounds__(64) k_bench12(const Fp* in, Fp* out) {
     m.t.y = g.c1.c0;
     m.t.z = g.c1.c1;
     m.active = 1;
+    m.npx = fp_neg_lazy<2>(m.px);
+    slot_store_point(0, m.t);
     for (int i = 0; i < ITERS / 16; i++) {
         if (OP == 0) fp12_sqr(f, f);
         if (OP == 1) fp12_mul(f, f, g);
-        if (OP == 2) fp12_mul_by_line(f, g.c0.c0, g.c0.c1, g.c0.c2);
+        if (OP == 2) fp12_mul_by_line<2>(f, g.c0.c0, g.c0.c1, g.c0.c2);
         if (OP == 3) fp12_cyclotomic_sqr(f, f);
-        if (OP == 4) miller_dbl_step(f, m);
+        if (OP == 4) miller_dbl_step(f, m, 0);  // running point in the lane slots (LDS)
         if (OP == 5) {  // fp12_mul with everything inlined, operands in registers
             Fp6 t0, t1, mm;
             fp6_mul(t0, f.c0, g.c0);
