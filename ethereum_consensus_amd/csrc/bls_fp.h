@@ -475,32 +475,27 @@ ECG_HD_NOINLINE Fp fp_sqr(Fp a) {
 // small-constant multiples
 ECG_HD Fp fp_mul3(const Fp& a) { return fp_add(fp_dbl(a), a); }
 
-// a^e for a public 384-bit exponent (12 LE words), 4-bit fixed window.  The window's table entry is read BEFORE the four
-// squarings that precede its use, and those are inlined: the table lives in the private segment (dynamic index), a load issued
-// right in front of the product was an exposed trip to memory per window -- 90 per exponentiation, five exponentiations per
-// message -- and every out-of-line routine starts by waiting for ALL outstanding memory operations (the calling convention's
-// s_waitcnt 0), so a load cannot be hidden behind a call.
-ECG_HD_NOINLINE Fp fp_pow(Fp a, const u32* e) {
+// a^((p-3)/4), the one exponent the pipeline raises to (square roots and inverse square roots: fp_sqrt_inv,
+// fp2_sqrt_with_norm_root): sliding windows of up to 5 bits over the odd powers a, a^3 .. a^31 along the generated
+// schedule blsc::POW_PM3D4_SCHED -- 376 squarings + 81 products (the 4-bit fixed window took 376 + 104).  The window's table
+// entry is read BEFORE the squarings that precede its use, and those are inlined: the table lives in the private segment
+// (dynamic index), a load issued right in front of the product was an exposed trip to memory per window, and every
+// out-of-line routine starts by waiting for ALL outstanding memory operations (the calling convention's s_waitcnt 0), so a
+// load cannot be hidden behind a call.
+ECG_HD_NOINLINE Fp fp_pow_pm3d4(Fp a) {
     Fp tab[16];
-    tab[0] = fp_one();
-    tab[1] = a;
-    for (int i = 2; i < 16; i++) tab[i] = fp_mul(tab[i - 1], a);
-    Fp r = fp_one();
-    bool started = false;
-    for (int w = 95; w >= 0; w--) {
-        const u32 nib = (e[w >> 3] >> ((w & 7) * 4)) & 15;
-        const Fp m = ecg_priv_load(tab[nib]);
-        if (started) {
-            // inlined: a call would wait for the load above at its entry (the ABI's s_waitcnt 0)
-            for (int k = 0; k < 4; k++) {
-                ECG_COUNT_SQR();
-                r = fp_sqr_body(r);
-            }
+    tab[0] = a;
+    const Fp a2 = fp_sqr(a);
+    for (int i = 1; i < 16; i++) tab[i] = fp_mul(tab[i - 1], a2);
+    Fp r = ecg_priv_load(tab[blsc::POW_PM3D4_SCHED[0][1]]);
+    for (int w = 1; w < blsc::POW_PM3D4_STEPS; w++) {
+        const u32 nsq = blsc::POW_PM3D4_SCHED[w][0], k = blsc::POW_PM3D4_SCHED[w][1];
+        const Fp m = ecg_priv_load(tab[k & 15]);
+        for (u32 q = 0; q < nsq; q++) {
+            ECG_COUNT_SQR();
+            r = fp_sqr_body(r);  // inlined: a call would wait for the load above at its entry (the ABI's s_waitcnt 0)
         }
-        if (nib) {
-            r = started ? fp_mul(r, m) : m;
-            started = true;
-        }
+        if (k != 255) r = fp_mul(r, m);
     }
     return r;
 }
@@ -628,7 +623,7 @@ ECG_HD_NOINLINE Fp fp_inv(const Fp& a_in) {  // 0 -> 0
 // Square root for p = 3 mod 4.  Returns true and s with s^2 == a when a is a square.
 // Also hands back t = a^((p-3)/4): when a is a non-zero square, t == 1/s.
 ECG_HD bool fp_sqrt_inv(const Fp& a, Fp& s, Fp& inv_s) {
-    inv_s = fp_pow(a, blsc::EXP_PM3D4);
+    inv_s = fp_pow_pm3d4(a);
     s = fp_mul(inv_s, a);
     return fp_eq(fp_sqr(s), a);
 }
@@ -794,7 +789,7 @@ ECG_HD Fp2 fp2_mul_xi_lazy(const Fp2& a) { return Fp2{fp_sub_lazy_k<K>(a.c0, a.c
 // around one: the lanes of a wave stay together.  Any root; false if r^2 != a.
 ECG_HD bool fp2_sqrt_with_norm_root(const Fp2& a, const Fp& s, Fp2& r) {
     const Fp d = fp_mul(fp_add(a.c0, s), blsc::INV2);
-    const Fp t = fp_pow(d, blsc::EXP_PM3D4);
+    const Fp t = fp_pow_pm3d4(d);
     const Fp c = fp_mul(t, d);
     const Fp ha1t = fp_mul(fp_mul(a.c1, blsc::INV2), t);  // a1 t / 2
     const bool first = fp_eq(fp_sqr(c), d);

@@ -123,9 +123,10 @@ ECG_HD_NOINLINE void map_to_curve_g2(J2& r_out, const Fp2& u_in, const Fp2& tv2_
     Fp2 gx1 = fp2_add(fp2_add(fp2_mulx(fp2_sqrx(x1), x1), fp2_mulx(blsc::SSWU_A, x1)), blsc::SSWU_B);
     // Exactly one of gx1, gx2 = g(Z u^2 x1) = (Z u^2)^3 gx1 is a square.  Decide on the NORM of gx1 (one Fp
     // exponentiation, which is also the norm root a square gx1 needs), derive the norm root of gx2 from it when gx1 is
-    // not a square -- norm(gx2) = m^3 n1 with m = norm(Z u^2); n1 and m are then both non-residues, s^2 = -n1,
-    // v = m^((p+1)/4) has v^2 = -m, so (m s v)^2 = m^3 n1 -- and take ONE Fp2 root of the chosen value.  Every lane
-    // of a wave runs the same 3 exponentiations (+1 for the lanes on gx2) instead of up to 6 on divergent paths.
+    // not a square -- norm(gx2) = m^3 n1 with m = norm(Z u^2) = 5 norm(u)^2; n1 is then a non-residue, s^2 = -n1, and
+    // v = sqrt(-5) norm(u) has v^2 = -m (a constant: -5 is a residue, 5 and -1 are not), so (m s v)^2 = m^3 n1 -- and
+    // take ONE Fp2 root of the chosen value.  Every lane of a wave runs the same 2 exponentiations, whichever of gx1, gx2
+    // its message lands on, instead of up to 6 on divergent paths.
     const Fp2 x2 = fp2_mulx(tv1, x1);
     const Fp2 gx2 = fp2_add(fp2_add(fp2_mulx(fp2_sqrx(x2), x2), fp2_mulx(blsc::SSWU_A, x2)), blsc::SSWU_B);
     const Fp n1 = fp_add(fp_sqr(gx1.c0), fp_sqr(gx1.c1));
@@ -133,8 +134,7 @@ ECG_HD_NOINLINE void map_to_curve_g2(J2& r_out, const Fp2& u_in, const Fp2& tv2_
     const bool sq1 = fp_sqrt(n1, sn);  // sn = n1^((p+1)/4) either way
     if (!sq1) {
         const Fp m = fp_add(fp_sqr(tv1.c0), fp_sqr(tv1.c1));
-        Fp v;
-        (void)fp_sqrt(m, v);
+        const Fp v = fp_mul(blsc::SQRT_M5, fp_add(fp_sqr(u.c0), fp_sqr(u.c1)));
         sn = fp_mul(fp_mul(m, sn), v);
     }
     Fp2 x = sq1 ? x1 : x2, y;

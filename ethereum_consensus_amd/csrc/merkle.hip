@@ -162,15 +162,8 @@ __global__ void __launch_bounds__(TILE_LANES) k_tree_tiles1(TileDesc d, const Ze
     run_tile(d, zt);
 }
 
-__global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u32 n, u8* dst, u64 chk_off, u32 chk_expect, u32* flag) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && flag && chk_off != ~0ull) {
-        u32 w[1];
-        load_bytes_le<1>(w, src, chk_off, src_total);
-        if (w[0] != chk_expect) *flag = 1u;
-    }
-    if (i >= n) return;
-    GatherDesc g = desc[i];
+// one gathered chunk: n_bytes of the encoding, zero-padded to the 32 bytes of the chunk
+__device__ __forceinline__ void gather_chunk(const u8* src, u64 src_total, const GatherDesc& g, u8* dst) {
     u32 d[8];
     u64 lim = g.src_off + g.n_bytes;
     if (lim > src_total) lim = src_total;
@@ -182,6 +175,16 @@ __global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u
     u32* q = reinterpret_cast<u32*>(dst + 32ull * g.dst_chunk);
 #pragma unroll
     for (int k = 0; k < 8; k++) q[k] = d[k];
+}
+__global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u32 n, u8* dst, u64 chk_off, u32 chk_expect, u32* flag) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && flag && chk_off != ~0ull) {
+        u32 w[1];
+        load_bytes_le<1>(w, src, chk_off, src_total);
+        if (w[0] != chk_expect) *flag = 1u;
+    }
+    if (i >= n) return;
+    gather_chunk(src, src_total, desc[i], dst);
 }
 
 // The fused tail of a BeaconState root: see merkle_driver.h TailPlan.
@@ -196,6 +199,16 @@ __device__ __forceinline__ bool tail_last_arrival(u32* counter, u32 parties) {
     const bool last = ticket == parties - 1;
     if (last) __threadfence();  // acquire: the other parties' results
     return last;
+}
+// the gathered chunks among the `n` chunks at byte offset `off` of the job buffer, fetched by the workgroup about to hash them
+__device__ __forceinline__ void tail_gather(const TailPlan& P, u8* buf, u64 off, u32 n) {
+    if (off < P.small_off) return;  // a finishing job's inputs are nodes of a workspace
+    const u64 c0 = (off - P.small_off) >> 5;
+    for (u32 i = threadIdx.x; i < P.n_gathers; i += blockDim.x) {
+        const GatherDesc g = P.gathers[i];
+        if (g.dst_chunk >= c0 && g.dst_chunk < c0 + n) gather_chunk(P.src, P.src_total, g, buf + P.small_off);
+    }
+    __syncthreads();
 }
 __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u8* buf, const ZeroTable* zt) {
     const TailPlan& P = *pl;
@@ -216,20 +229,28 @@ __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u
     } else {
         const u32 j = blockIdx.x - P.n_tile_wgs;
         const TreeJob job = P.jobs0[j];
+        tail_gather(P, buf, job.in_off, job.n);
         run_tree_job(job, buf, zt);
         feeds = P.jobs0_feeds[j];
     }
     if (feeds != TAIL_NONE) {  // an input of a nested container: its last input to arrive computes it
         if (!tail_last_arrival(&P.counters[P.n_fields + feeds], P.jobs1_deps[feeds])) return;
         const TreeJob job = P.jobs1[feeds];
+        tail_gather(P, buf, job.in_off, job.n);
         run_tree_job(job, buf, zt);
     }
     if (!tail_last_arrival(&P.counters[P.n_fields + P.n_jobs1], P.final_parties)) return;
     const TreeJob top = P.job2;
+    tail_gather(P, buf, P.froots_off, 32);  // all 32 chunk slots of the state container: the unused ones are zero descriptors
     run_tree_job(top, buf, zt);
     __syncthreads();
     const u32 t = threadIdx.x;
-    const bool bad = *P.poison != 0;
+    bool bad = false;
+    if (P.chk_off != ~0ull) {
+        u32 w[1];
+        load_bytes_le<1>(w, P.src, P.chk_off, P.src_total);
+        bad = w[0] != P.chk_expect;
+    }
     if (t < 8) reinterpret_cast<u32*>(P.d_root)[t] = bad ? 0xffffffffu : reinterpret_cast<const u32*>(buf + P.root_off)[t];
     if (P.d_field_roots) reinterpret_cast<u32*>(P.d_field_roots)[t] = reinterpret_cast<const u32*>(buf + P.froots_off)[t];  // 32 x 32 B = 256 dwords
 }
@@ -319,7 +340,7 @@ int launch_tiles(hipStream_t s, const TileDesc* d_descs, u32 n_desc, u32 n_wg) {
 
 int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes, u64 n0, u32 depth, bool mix,
                      u64 mix_len, u8* d_out, u8* ws, u64* hash_count, TreeJob* deferred, const u8* job_base, bool background,
-                     hipEvent_t after_wide_passes, TileDesc* deferred_tile, u32* deferred_tile_wgs) {
+                     hipEvent_t after_wide_passes, TileDesc* deferred_tile, u32* deferred_tile_wgs, int phase) {
     if (depth > 64) {
         set_last_error("limit too large");
         return ECGPU_ERR_BAD_ARG;
@@ -333,10 +354,17 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
     u8* bufA = ws;
     u8* bufB = ws + half;
     const u8* cur = d_in;
+    const bool describe = phase != MERKLEIZE_LAUNCH, launch = phase != MERKLEIZE_DESCRIBE;
+    if (phase != MERKLEIZE_ALL && !(deferred && (deferred_tile || !sc.tile))) {
+        set_last_error("merkleize_device: a tree described and launched separately needs its tail deferred");
+        return ECGPU_ERR_BAD_ARG;
+    }
     for (const PassStep& p : sc.passes) {
         u8* out = (cur == bufA) ? bufB : bufA;
         int rc;
-        if (p.first) {
+        if (!launch) {
+            rc = ECGPU_SUCCESS;
+        } else if (p.first) {
             // with an `after_wide_passes` event the chip-filling leaf pass goes out in two halves and the event sits
             // between them, so that whatever waits for it overlaps the second half and the tree's tail
             const bool split = after_wide_passes && p.n_out >= (1u << 17);
@@ -362,7 +390,7 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
         if (rc) return rc;
         cur = out;
     }
-    if (after_wide_passes) ECG_HIP_CHECK(hipEventRecord(after_wide_passes, s));
+    if (after_wide_passes && launch) ECG_HIP_CHECK(hipEventRecord(after_wide_passes, s));
     if (sc.tile) {
         // one workgroup per 1024 nodes
         u8* out = (cur == bufA) ? bufB : bufA;
@@ -377,14 +405,16 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
         td.first_wg = 0;
         const u32 n_wg = (u32)((sc.tile_n_in + TILE_NODES - 1) / TILE_NODES);
         if (deferred_tile) {
-            *deferred_tile = td;
-            *deferred_tile_wgs = n_wg;
+            if (describe) {
+                *deferred_tile = td;
+                *deferred_tile_wgs = n_wg;
+            }
         } else {
             int rc = launch_tiles_inline(s, td, n_wg);
             if (rc) return rc;
         }
         cur = out;
-    } else if (deferred_tile_wgs) {
+    } else if (deferred_tile_wgs && describe) {
         *deferred_tile_wgs = 0;
     }
     // finishing job: <= 512 nodes at job_level (or the empty tree) -> climb -> mix-in -> d_out
@@ -400,13 +430,13 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
     if (deferred) {
         job.in_off = (u64)((uintptr_t)jbase - (uintptr_t)job_base);
         job.out_off = (u64)((uintptr_t)d_out - (uintptr_t)job_base);
-        *deferred = job;
+        if (describe) *deferred = job;
     } else {
         ProfScope ps("merkle_tree_job", s);
         hipLaunchKernelGGL(k_tree_job1, dim3(1), dim3(JOB_BLOCK), 0, s, job, jbase, device_zero_table());
     }
     ECG_HIP_CHECK(hipGetLastError());
-    if (hash_count) *hash_count += sc.hashes;
+    if (hash_count && describe) *hash_count += sc.hashes;
     return ECGPU_SUCCESS;
 }
 

@@ -29,10 +29,14 @@ size_t merkle_ws_bytes(u64 n0);
 // (chip-filling) passes are enqueued, i.e. where the tree's latency-bound tail begins.
 // With `deferred_tile` set as well, the tile stage is not launched either: its descriptor (first_wg left 0) and workgroup
 // count are returned (*deferred_tile_wgs = 0: the tree has no tile stage) for the fused tail of a BeaconState root.
+// `phase`: MERKLEIZE_DESCRIBE fills the deferred descriptors and the hash count and launches nothing (the caller needs them
+// before it enqueues anything: state_deneb.hip uploads its whole plan in front of the passes); MERKLEIZE_LAUNCH enqueues
+// the passes of the same tree and touches neither the descriptors nor the count.
+enum { MERKLEIZE_ALL = 0, MERKLEIZE_DESCRIBE = 1, MERKLEIZE_LAUNCH = 2 };
 int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes, u64 n0, u32 depth,
                      bool mix, u64 mix_len, u8* d_out, u8* ws, u64* hash_count, TreeJob* deferred = nullptr,
                      const u8* job_base = nullptr, bool background = false, hipEvent_t after_wide_passes = nullptr,
-                     TileDesc* deferred_tile = nullptr, u32* deferred_tile_wgs = nullptr);
+                     TileDesc* deferred_tile = nullptr, u32* deferred_tile_wgs = nullptr, int phase = MERKLEIZE_ALL);
 
 // Batched small trees: jobs live in device memory at d_jobs.
 int launch_tree_jobs(hipStream_t s, const TreeJob* d_jobs, u32 n_jobs, u8* d_buf);
@@ -54,6 +58,9 @@ int launch_gather(hipStream_t s, const u8* d_src, u64 src_total, const GatherDes
 // one runs it; every unit that feeds the state container directly, and every nested container, takes a ticket of the state
 // container, and the last one computes it and writes the root.  No workgroup ever waits for another (no spinning, nothing to
 // deadlock): whoever arrives last carries on.
+// The chunks that are COPIED out of the encoding (basic fields, the members of the small containers: GatherDesc) are fetched
+// by the unit that hashes them, right before it does -- there is no gather launch in front of the tail, and the check of the
+// payload header's extra_data offset (the _dev entry, whose host never sees the bytes) is made by the unit that writes the root.
 constexpr u32 TAIL_NONE = 0xffffffffu;
 struct TailField {
     TileDesc tile;
@@ -76,7 +83,12 @@ struct TailPlan {
     u8* d_root;
     u8* d_field_roots;                  // may be null
     u32* counters;                      // [n_fields] tile tickets, [n_jobs1] nested containers, [1] the state container; zero before the launch
-    const u32* poison;                  // *poison != 0: the root is written as 32 x 0xFF (launch_gather's check failed)
+    const u8* src;                      // the SSZ encoding and its length: source of the gathered chunks
+    u64 src_total;
+    const GatherDesc* gathers;
+    u32 n_gathers, chk_expect;
+    u64 small_off;                      // byte offset of the small-chunk buffer (GatherDesc::dst_chunk counts from there)
+    u64 chk_off;                        // != ~0: the little-endian u32 at src + chk_off must equal chk_expect, else the root is 32 x 0xFF
 };
 int launch_state_tail(hipStream_t s, const TailPlan* d_plan, u32 n_wgs, u8* d_buf);
 

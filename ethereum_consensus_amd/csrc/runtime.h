@@ -54,6 +54,20 @@ struct AuxStreams {
     int init();
 };
 
+// A ring of pinned host slots for small descriptor blocks that travel to the device in front of a launch chain (the plan of a
+// BeaconState root): the copy is truly asynchronous (pageable memory would go through the runtime's staging path), and a
+// slot is rewritten only after the copy that read it has completed (an event per slot; a host running more than
+// UPLOAD_SLOTS calls ahead of the device waits here).
+constexpr int UPLOAD_SLOTS = 8;
+struct UploadRing {
+    u8* p = nullptr;
+    size_t slot_bytes = 0;
+    hipEvent_t copied[UPLOAD_SLOTS] = {};
+    int next = 0;
+    int acquire(size_t bytes, u8** slot, hipEvent_t* ev);  // the caller fills *slot, enqueues the copy and records *ev after it
+    void release();
+};
+
 struct ThreadCtx {
     hipStream_t own_stream = nullptr;
     // ONE set of three auxiliary streams per host thread.  State roots use st[0] (tile stages, batched jobs) and st[1]
@@ -64,6 +78,7 @@ struct ThreadCtx {
     AuxStreams aux;
     std::map<hipStream_t, Arena> arenas;
     PinnedBuf staging;      // host-pinned staging for small H2D/D2H payloads
+    UploadRing uploads;
     u64 last_hash64 = 0;
     hipStream_t stream_or_own(ecgpu_stream_t s);
     Arena& arena(hipStream_t s) { return arenas[s]; }

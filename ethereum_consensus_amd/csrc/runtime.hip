@@ -105,6 +105,7 @@ void ThreadCtx::release() {
     arenas.clear();
     if (staging.p) (void)hipHostFree(staging.p);
     staging = PinnedBuf();
+    uploads.release();
     if (aux.ready) {
         (void)hipEventDestroy(aux.fork);
         for (int i = 0; i < N_AUX_STREAMS; i++) {
@@ -256,6 +257,34 @@ int PinnedBuf::reserve(size_t bytes) {
     ECG_HIP_CHECK(hipHostMalloc((void**)&p, want, hipHostMallocDefault));
     cap = want;
     return ECGPU_SUCCESS;
+}
+
+int UploadRing::acquire(size_t bytes, u8** slot, hipEvent_t* ev) {
+    if (bytes > slot_bytes) {
+        release();
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        ECG_HIP_CHECK(hipHostMalloc((void**)&p, want * UPLOAD_SLOTS, hipHostMallocDefault));
+        slot_bytes = want;
+        for (int i = 0; i < UPLOAD_SLOTS; i++) ECG_HIP_CHECK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+    } else {
+        ECG_HIP_CHECK(hipEventSynchronize(copied[next]));  // never recorded: returns at once
+    }
+    *slot = p + slot_bytes * next;
+    *ev = copied[next];
+    next = (next + 1) % UPLOAD_SLOTS;
+    return ECGPU_SUCCESS;
+}
+void UploadRing::release() {
+    if (!p) return;
+    for (int i = 0; i < UPLOAD_SLOTS; i++) {
+        (void)hipEventSynchronize(copied[i]);
+        (void)hipEventDestroy(copied[i]);
+        copied[i] = nullptr;
+    }
+    (void)hipHostFree(p);
+    p = nullptr;
+    slot_bytes = 0;
+    next = 0;
 }
 
 // ---- profiling ------------------------------------------------------------------------------

@@ -38,47 +38,36 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         }
     }
     // ---- device buffers --------------------------------------------------------------------------
+    // Everything the root needs from the host -- the tail's plan, its zeroed tickets, the gather descriptors and the (zeroed)
+    // small-chunk buffer -- is ONE block, uploaded by one copy from a pinned slot in front of the passes.  (Round 3 first put
+    // the five small operations of the previous schedule -- two descriptor uploads, two memsets, the gather launch -- on an
+    // auxiliary stream under the passes: 1.09 -> 1.07 ms when nothing else had created streams, 1.19 ms in a process that had,
+    // where the auxiliary stream shares a hardware queue with the caller's: the driver's bench.  One stream, one copy, no
+    // gather launch -- the tail's units fetch the chunks they hash -- does not depend on that.)
     Arena& ar = c->arena(s);
     ar.reset();
     size_t need = 8192;
     for (auto& b : plan.bigs) need += merkle_ws_bytes(b.n0) + 512;
     const size_t small_bytes = 32ull * plan.n_small_chunks;
-    need += small_bytes + plan.gathers.size() * sizeof(GatherDesc) + sizeof(TailPlan) + 2048;
+    const size_t n_counters = TAIL_MAX_FIELDS + TAIL_MAX_JOBS1 + 4;
+    auto up256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t off_counters = up256(sizeof(TailPlan)), off_gath = off_counters + up256(n_counters * sizeof(u32)),
+                 off_small = off_gath + up256(plan.gathers.size() * sizeof(GatherDesc)), block_bytes = off_small + up256(small_bytes);
+    need += block_bytes + 2048;
     int rc = ar.reserve(need);
     if (rc) return rc;
-    u8* d_small = ar.take(small_bytes);
-    GatherDesc* d_gath = (GatherDesc*)ar.take(plan.gathers.size() * sizeof(GatherDesc));
-    TailPlan* d_tail = (TailPlan*)ar.take(sizeof(TailPlan));
-    u32* d_counters = (u32*)ar.take((TAIL_MAX_FIELDS + TAIL_MAX_JOBS1 + 4) * sizeof(u32));  // tickets (fields, nested, state), the poison flag
-    if (!d_small || !d_gath || !d_tail || !d_counters) return ECGPU_ERR_OOM;
-    u32* d_poison = d_counters + TAIL_MAX_FIELDS + TAIL_MAX_JOBS1 + 3;
-    // The small operations -- descriptor uploads, clearing the chunk buffer and the tickets, the gather kernel -- go to an
-    // auxiliary stream that starts where the caller's stream stands now (everything that wrote the encoding or still reads this
-    // arena is before that point) and joins it again in front of the tail: they run underneath the wide passes instead of in
-    // front of them (five dependent stream operations, ~30 us of a 1 ms root).
-    AuxStreams& ax = c->aux;
-    rc = ax.init();
-    if (rc) return rc;
-    hipStream_t sa = ax.st[0];
-    ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
-    ECG_HIP_CHECK(hipStreamWaitEvent(sa, ax.fork, 0));
-    // descriptors travel through pageable memory: hipMemcpyAsync stages them before returning,
-    // so the host vectors may die at the end of this call while the stream is still running.
-    ECG_HIP_CHECK(hipMemcpyAsync(d_gath, plan.gathers.data(), plan.gathers.size() * sizeof(GatherDesc),
-                                 hipMemcpyHostToDevice, sa));
-    ECG_HIP_CHECK(hipMemsetAsync(d_small, 0, small_bytes, sa));
-    ECG_HIP_CHECK(hipMemsetAsync(d_counters, 0, (TAIL_MAX_FIELDS + TAIL_MAX_JOBS1 + 4) * sizeof(u32), sa));
+    u8* d_block = ar.take(block_bytes);
+    if (!d_block) return ECGPU_ERR_OOM;
+    TailPlan* d_tail = (TailPlan*)d_block;
+    u32* d_counters = (u32*)(d_block + off_counters);  // tickets: fields, nested containers, the state container
+    GatherDesc* d_gath = (GatherDesc*)(d_block + off_gath);
+    u8* d_small = d_block + off_small;
     // The device entry never sees the payload header on the host: the extra_data offset word the host entries check
     // (state_plan.h) is compared on the device, and a mismatch poisons the root (32 x 0xFF; include/ecgpu.h).
     const bool dev_check = fork >= FORK_BELLATRIX && !h_payload_fixed && plan.payload_header_off != ~0ull;
-    rc = launch_gather(sa, d_ssz, n_bytes, d_gath, (u32)plan.gathers.size(), d_small,
-                       dev_check ? plan.payload_header_off + PAYLOAD_EXTRA_DATA_OFFSET_WORD : ~0ull, (u32)payload_header_fixed(fork), d_poison);
-    if (rc) return rc;
-    for (const StatePlan::ExtChunk& e : plan.ext_chunks)  // phase0: roots computed by the generic planner (pageable copy: staged before return)
-        ECG_HIP_CHECK(hipMemcpyAsync(d_small + 32ull * e.dst_chunk, ext_roots + e.src_off, 32, hipMemcpyHostToDevice, sa));
     u64 hc = plan.small_hashes;
-    // Schedule (round 3): ONE stream.  The wide passes first -- the validator registry, 93 % of the hashes, and whatever other
-    // field is too wide for a tile stage --, then ONE launch for everything that is left: the tile stages of all fields, their
+    // Schedule (round 3): ONE stream.  The plan first (every tree is DESCRIBED here and launched further down), then the wide
+    // passes -- the validator registry, 93 % of the hashes, and whatever other field is too wide for a tile stage --, then ONE launch for everything that is left: the tile stages of all fields, their
     // finishing jobs, the leaf containers, the nested containers and the state container, chained by arrival tickets inside the
     // kernel (merkle_driver.h TailPlan).  Round 2 overlapped the other 13 fields with the validator pass on two auxiliary streams:
     // their latency-bound workgroups cost the chip-filling pass 25 % (0.62 -> 0.78 ms) and the tail was ~6 dependent launches
@@ -91,6 +80,7 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     std::vector<size_t> order{biggest};
     for (size_t i = 0; i < plan.bigs.size(); i++)
         if (i != biggest) order.push_back(i);
+    std::vector<u8*> wss;
     for (size_t i : order) {
         const BigField& b = plan.bigs[i];
         u8* ws = ar.take(merkle_ws_bytes(b.n0));
@@ -98,8 +88,9 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         TreeJob dj;
         TileDesc td;
         u32 n_tiles = 0;
+        wss.push_back(ws);
         rc = merkleize_device(s, b.kind, fptr[i], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk, ws, &hc, &dj, ar.base,
-                              i != biggest, nullptr, &td, &n_tiles);
+                              i != biggest, nullptr, &td, &n_tiles, MERKLEIZE_DESCRIBE);
         if (rc) return rc;
         if (n_tiles) {
             if (tp.n_fields >= TAIL_MAX_FIELDS) return ECGPU_ERR_BAD_ARG;
@@ -172,10 +163,34 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     tp.d_root = d_root;
     tp.d_field_roots = d_field_roots;
     tp.counters = d_counters;
-    tp.poison = d_poison;
-    ECG_HIP_CHECK(hipMemcpyAsync(d_tail, &tp, sizeof(TailPlan), hipMemcpyHostToDevice, sa));
-    ECG_HIP_CHECK(hipEventRecord(ax.done[0], sa));
-    ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[0], 0));
+    tp.src = d_ssz;
+    tp.src_total = n_bytes;
+    tp.gathers = d_gath;
+    tp.n_gathers = (u32)plan.gathers.size();
+    tp.small_off = small_off;
+    tp.chk_off = dev_check ? plan.payload_header_off + PAYLOAD_EXTRA_DATA_OFFSET_WORD : ~0ull;
+    tp.chk_expect = (u32)payload_header_fixed(fork);
+    // the block: plan, zero tickets, descriptors, zero chunks (+ phase0: the two list roots the generic planner computed)
+    u8* h_block;
+    hipEvent_t copied;
+    rc = c->uploads.acquire(block_bytes, &h_block, &copied);
+    if (rc) return rc;
+    memset(h_block, 0, block_bytes);
+    memcpy(h_block, &tp, sizeof(TailPlan));
+    if (!plan.gathers.empty()) memcpy(h_block + off_gath, plan.gathers.data(), plan.gathers.size() * sizeof(GatherDesc));
+    for (const StatePlan::ExtChunk& e : plan.ext_chunks) memcpy(h_block + off_small + 32ull * e.dst_chunk, ext_roots + e.src_off, 32);
+    ECG_HIP_CHECK(hipMemcpyAsync(d_block, h_block, block_bytes, hipMemcpyHostToDevice, s));
+    ECG_HIP_CHECK(hipEventRecord(copied, s));
+    // the wide passes, then the one launch for everything that is left
+    for (size_t k = 0; k < order.size(); k++) {
+        const BigField& b = plan.bigs[order[k]];
+        TreeJob dj;
+        TileDesc td;
+        u32 n_tiles = 0;
+        rc = merkleize_device(s, b.kind, fptr[order[k]], b.bytes, b.n0, b.depth, b.mix, b.mix_len, d_small + 32ull * b.out_chunk, wss[k], nullptr, &dj,
+                              ar.base, order[k] != biggest, nullptr, &td, &n_tiles, MERKLEIZE_LAUNCH);
+        if (rc) return rc;
+    }
     rc = launch_state_tail(s, d_tail, tp.n_tile_wgs + tp.n_jobs0, ar.base);
     if (rc) return rc;
     c->last_hash64 = hc;
