@@ -188,6 +188,20 @@ __global__ void k_gather(const u8* src, u64 src_total, const GatherDesc* desc, u
 }
 
 // The fused tail of a BeaconState root: see merkle_driver.h TailPlan.
+#if defined(ECG_TAIL_TRACE)
+// development build (tools/build_variant.sh tailtrace "-DECG_TAIL_TRACE" merkle.hip; tools/tail_trace_probe.py): 100 MHz timestamps
+// of the tail's milestones: [0] first workgroup starts  [1] first tile of the critical field starts  [2] its last tile arrives
+// [3] its finishing job done ([6], [7]: shader clock at [2], [3])  [4] last arrival at the state container  [5] root written
+// [8 + f] finishing job of field f done  [40 + j] unit j (no tile stage) done
+__device__ unsigned long long g_tail_trace[128];
+#define TAIL_TRACE_MIN(i) do { if (threadIdx.x == 0) atomicMin(&g_tail_trace[i], (unsigned long long)wall_clock64()); } while (0)
+#define TAIL_TRACE_SET(i) do { __syncthreads(); if (threadIdx.x == 0) g_tail_trace[i] = (unsigned long long)wall_clock64(); } while (0)
+#define TAIL_TRACE_CLK(i) do { if (threadIdx.x == 0) g_tail_trace[i] = (unsigned long long)clock64(); } while (0)
+#else
+#define TAIL_TRACE_MIN(i) ((void)0)
+#define TAIL_TRACE_SET(i) ((void)0)
+#define TAIL_TRACE_CLK(i) ((void)0)
+#endif
 __device__ __forceinline__ bool tail_last_arrival(u32* counter, u32 parties) {
     __shared__ u32 ticket;
     __syncthreads();  // the unit's result has been stored (by lane 0) before this
@@ -213,6 +227,7 @@ __device__ __forceinline__ void tail_gather(const TailPlan& P, u8* buf, u64 off,
 __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u8* buf, const ZeroTable* zt) {
     const TailPlan& P = *pl;
     u32 feeds;
+    TAIL_TRACE_MIN(0);
     if (blockIdx.x < P.n_tile_wgs) {
         u32 f = 0;
         for (u32 i = 1; i < P.n_fields; i++)
@@ -221,16 +236,27 @@ __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u
         // every wave here is a dependent chain of hash64; the critical field's gets issue priority where chains share a SIMD
         if (P.fields[f].prio) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(1);
+        if (P.fields[f].prio) TAIL_TRACE_MIN(1);
         run_tile(d, zt);
         if (!tail_last_arrival(&P.counters[f], P.fields[f].n_tiles)) return;
+        if (P.fields[f].prio) {
+            TAIL_TRACE_SET(2);
+            TAIL_TRACE_CLK(6);
+        }
         const TreeJob job = P.fields[f].job;
         run_tree_job(job, buf, zt);
+        if (P.fields[f].prio) {
+            TAIL_TRACE_SET(3);
+            TAIL_TRACE_CLK(7);
+        }
+        TAIL_TRACE_SET(8 + f);
         feeds = P.fields[f].feeds;
     } else {
         const u32 j = blockIdx.x - P.n_tile_wgs;
         const TreeJob job = P.jobs0[j];
         tail_gather(P, buf, job.in_off, job.n);
         run_tree_job(job, buf, zt);
+        TAIL_TRACE_SET(40 + j);
         feeds = P.jobs0_feeds[j];
     }
     if (feeds != TAIL_NONE) {  // an input of a nested container: its last input to arrive computes it
@@ -240,6 +266,7 @@ __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u
         run_tree_job(job, buf, zt);
     }
     if (!tail_last_arrival(&P.counters[P.n_fields + P.n_jobs1], P.final_parties)) return;
+    TAIL_TRACE_SET(4);
     const TreeJob top = P.job2;
     tail_gather(P, buf, P.froots_off, 32);  // all 32 chunk slots of the state container: the unused ones are zero descriptors
     run_tree_job(top, buf, zt);
@@ -253,6 +280,7 @@ __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u
     }
     if (t < 8) reinterpret_cast<u32*>(P.d_root)[t] = bad ? 0xffffffffu : reinterpret_cast<const u32*>(buf + P.root_off)[t];
     if (P.d_field_roots) reinterpret_cast<u32*>(P.d_field_roots)[t] = reinterpret_cast<const u32*>(buf + P.froots_off)[t];  // 32 x 32 B = 256 dwords
+    TAIL_TRACE_SET(5);
 }
 
 // crypto::hash: one lane per message (latency path; the batch form is what a caller should use)
@@ -459,6 +487,11 @@ int launch_gather(hipStream_t s, const u8* d_src, u64 src_total, const GatherDes
 int launch_state_tail(hipStream_t s, const TailPlan* d_plan, u32 n_wgs, u8* d_buf) {
     if (n_wgs == 0) return ECGPU_ERR_BAD_ARG;
     ProfScope ps("merkle_state_tail", s);
+#if defined(ECG_TAIL_TRACE)
+    void* tr = nullptr;
+    ECG_HIP_CHECK(hipGetSymbolAddress(&tr, HIP_SYMBOL(g_tail_trace)));
+    ECG_HIP_CHECK(hipMemsetAsync(tr, 0xff, sizeof(g_tail_trace), s));
+#endif
     hipLaunchKernelGGL(k_state_tail, dim3(n_wgs), dim3(TILE_LANES), 0, s, d_plan, d_buf, device_zero_table());
     ECG_HIP_CHECK(hipGetLastError());
     return ECGPU_SUCCESS;
@@ -494,6 +527,13 @@ static int merkleize_host(LeafKind kind, const u8* h_in, u64 in_bytes, u64 n0, u
 using namespace ecg;
 
 extern "C" {
+
+#if defined(ECG_TAIL_TRACE)
+int ecgpu_debug_tail_trace(uint64_t* out) {  // after a synchronize: the milestones of the last k_state_tail launch
+    ECG_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_trace), 128 * sizeof(uint64_t)));
+    return ECGPU_SUCCESS;
+}
+#endif
 
 int ecgpu_merkleize(const uint8_t* data, uint64_t n_bytes, uint64_t limit_chunks, int mix_in_len, uint64_t len,
                     uint8_t root[32]) {
