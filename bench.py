@@ -179,7 +179,7 @@ def run_merkle(args, L, torch, dist, rank, world):
     nl = ctypes.c_uint64(0)
     L.ecgpu_prof_read(dom, ctypes.byref(ms), ctypes.byref(nl))
     L.ecgpu_prof_enable(0)
-    kern_ms = ms.value / max(args.steps, 1)  # per state: the pass is issued as two half-range launches
+    kern_ms = ms.value / max(args.steps, 1)  # per state: one launch of the pass
     # algorithmic bytes of the dominant kernel per state: 121 B read per validator + one
     # 32-byte node written per lane (2^D validators per lane, D from the schedule)
     lanes = n >> max(1, min(6, n.bit_length() - 1 - 18))
@@ -196,7 +196,7 @@ def run_merkle(args, L, torch, dist, rank, world):
                   "traffic": (pmc_traffic("k_merkle_pass<2, ValidatorLeaves>") or {}).get("bytes_per_launch"),
                   "traffic_detail": pmc_traffic("k_merkle_pass<2, ValidatorLeaves>"),
                   "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches_timed": int(nl.value),
-                  "launch_note": "per state root: the validator pass goes out as two half-range launches; bytes and ms are their sum",
+                  "launch_note": "one launch of the validator pass per state root",
                   "valu_int": {"unit": "G hash64/s", "achieved": val_hashes / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0,
                                "peak": HASH64_PEAK_GHS,
                                "frac": (val_hashes / (kern_ms * 1e-3) / 1e9 / HASH64_PEAK_GHS) if kern_ms else 0.0,
@@ -256,7 +256,8 @@ def cpu_baseline_bls(sample, budget_s: float = 20.0):
     several times this restatement."""
     from oracle import cbls
     pks, msgs, sigs, want = sample
-    nthr = cbls.host_threads()
+    eff = effective_cores()
+    nthr = max(1, min(cbls.host_threads(), eff["cores_effective"]))  # the threads the box grants, not the 256 it shows
     # calibrate on one thread, then size the all-thread sample for ~budget_s / 2 of wall time
     m1 = min(len(want), 256)
     t0 = time.time()
@@ -275,10 +276,9 @@ def cpu_baseline_bls(sample, budget_s: float = 20.0):
     st = cbls.fast_aggregate_verify_batch_k1(pks[:48 * m], msgs[:32 * m], sigs[:96 * m], nthr)
     dt_n = time.time() - t0
     assert st == want[:m], "C++ restatement disagrees with the statuses known by construction"
-    eff = effective_cores()
     speedup = (m / dt_n) / rate1
-    # the threads used are the affinity mask's; what the box GRANTS is the cgroup quota, and where that is not readable the
-    # measured speed-up over one thread says it (round 2 printed "cores": 256 beside an 8.9x speed-up)
+    # the threads used are as many as the cgroup quota grants; where that is not readable they are the affinity mask's and the
+    # measured speed-up over one thread says what was granted (round 2 printed "cores": 256 beside an 8.9x speed-up)
     granted = eff["cores_effective"] if eff["cgroup_quota_cores"] is not None else min(eff["affinity"], max(1, int(speedup + 0.999)))
     return {"value": m / dt_n, "unit": "sigs/s", "cores": nthr, "cores_effective": granted, "host": eff,
             "measured_parallel_speedup": speedup, "kind": "port",
