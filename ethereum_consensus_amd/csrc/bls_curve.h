@@ -55,6 +55,13 @@ template <int K>
 ECG_HD Fp f_neg_lazy(const Fp& a) { return fp_neg_lazy<K>(a); }
 template <int K>
 ECG_HD Fp2 f_neg_lazy(const Fp2& a) { return Fp2{fp_neg_lazy<K>(a.c0), fp_neg_lazy<K>(a.c1)}; }
+// the square of a lazy value < K p; a - 2b in [0, 2p)
+template <int K>
+ECG_HD Fp f_sqr_lazy(const Fp& a) { return fp_sqr(a); }
+template <int K>
+ECG_HD Fp2 f_sqr_lazy(const Fp2& a) { return fp2_sqr_lazy<K>(a); }
+ECG_HD Fp f_sub_dbl(const Fp& a, const Fp& b) { return fp_sub_dbl(a, b); }
+ECG_HD Fp2 f_sub_dbl(const Fp2& a, const Fp2& b) { return fp2_sub_dbl(a, b); }
 template <int KB0, int KB1>
 ECG_HD Fp f_sp2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1) { return fp_sumprod2(a0, b0, a1, b1); }
 template <int KB0, int KB1>
@@ -126,10 +133,12 @@ ECG_HD void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
 #else
 // Doubling (a = 0), the dbl-2009-l quantities regrouped so that no modular addition touches a product:
 //   A = X^2, B = Y^2, D = 4 X B, E = 3A (lazy),
-//   X3 = E^2 - 2D = E E + (8p - 4X)(2B),   Y3 = E (D - X3) - 8 B^2 = E (D - X3 + 2p) + (8p - 4B)(2B),   Z3 = (2Y) Z
-// 2 squarings, 2 products, 2 sums of two products over 10 lazy operands (the textbook form: 5 squarings, 2 products and
-// 14 modular additions / doublings).  Bounds (units of p^2, per coefficient; Fp2 doubles them): E E 36 + (8)(4) 32 = 68;
-// E (D - X3) 24 + 32 = 56.  inf -> inf (Z3 = 0); y == 0 -> inf.  r may alias p.
+//   X3 = E^2 - 2D (one squaring of the lazy E, one correction into [0, 2p)),
+//   Y3 = E (D - X3) - 8 B^2 = E (D - X3 + 2p) + (8p - 4B)(2B),   Z3 = (2Y) Z
+// 3 squarings, 2 products, 1 sum of two products over lazy operands (the textbook form: 5 squarings, 2 products and 14 modular
+// additions / doublings).  Round 3: X3 was the sum of two products E E + (8p - 4X)(2B) -- 1 716 multiplies and 2 380
+// instructions in Fp2 where the squaring and the correction take 702 and 1 310.  Bounds (units of p^2, per coefficient; Fp2
+// doubles them): E E 36; E (D - X3) 24 + 32 = 56.  inf -> inf (Z3 = 0); y == 0 -> inf.  r may alias p.
 template <class F>
 ECG_HD void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
     const F A = f_sqr(p.x);
@@ -138,8 +147,8 @@ ECG_HD void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
     const F D = f_mul(X4, B);
     const F E = f_add_lazy(f_add_lazy(A, A), A);                 // < 6p
     const F B2 = f_add_lazy(B, B), B4 = f_add_lazy(B2, B2);      // < 4p, < 8p
-    const F n4X = f_neg_lazy<8>(X4), n4B = f_neg_lazy<8>(B4);    // 8p - 4X, 8p - 4B
-    const F X3 = f_sp2<6, 4>(E, E, n4X, B2);
+    const F n4B = f_neg_lazy<8>(B4);                             // 8p - 4B
+    const F X3 = f_sub_dbl(f_sqr_lazy<6>(E), D);
     const F Y3 = f_sp2<4, 4>(E, f_sub_lazy<2>(D, X3), n4B, B2);
     const F Z3 = f_mul(f_add_lazy(p.y, p.y), p.z);
     r.x = X3;

@@ -344,6 +344,30 @@ ECG_HD Fp fp_sub_lazy_k(const Fp& a, const Fp& b) {
     return s;
 }
 
+// a - 2b mod p in [0, 2p) for a, b < 2p (X3 = E^2 - 2D of a point doubling): the difference, in (-4p, 2p), gets 4p added back
+// when it is negative, then one conditional subtraction of 2p -- ~140 instructions against two modular operations' 208.
+ECG_HD Fp fp_sub_dbl(const Fp& a, const Fp& b) {
+    constexpr FpConst p4 = fp_p_times(4);
+    Fp d;
+    int32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        int32_t t = (int32_t)a.l[i] - (int32_t)(b.l[i] << 1) + bw;
+        d.l[i] = (u32)t & FP_MASK;
+        bw = t >> 30;
+    }
+    const u32 m = (u32)bw;  // all ones: negative
+    Fp r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        u32 t = d.l[i] + (p4.l[i] & m) + c;
+        r.l[i] = t & FP_MASK;
+        c = t >> 30;
+    }
+    return fp_cond_sub(r, blsc::P2);
+}
+
 // Sum of N products with ONE Montgomery reduction: (a_0 b_0 + ... + a_{N-1} b_{N-1}) / R mod p, result < 2p whenever
 // the integer sum is < R p = 632 p^2 (operands are lazy sums / lazy negations; every caller states its bound).
 // This is how the tower spends multiplier time instead of linear operations: on gfx950 a 104-instruction modular
@@ -756,6 +780,14 @@ ECG_HD Fp2 fp2_sqr(const Fp2& a) {
     return Fp2{fp_sumprod<1>(s, d), fp_sumprod<1>(x, y)};
 }
 #endif
+// the same square for lazy components < K p (K <= 8: (a0 + a1)(a0 - a1 + K p) < 16p * 16p, a0 (2 a1) < 8p * 16p)
+template <int K>
+ECG_HD Fp2 fp2_sqr_lazy(const Fp2& a) {
+    const Fp s[1] = {fp_add_lazy(a.c0, a.c1)}, d[1] = {fp_sub_lazy_k<K>(a.c0, a.c1)};
+    const Fp x[1] = {a.c0}, y[1] = {fp_add_lazy(a.c1, a.c1)};
+    return Fp2{fp_sumprod<1>(s, d), fp_sumprod<1>(x, y)};
+}
+ECG_HD Fp2 fp2_sub_dbl(const Fp2& a, const Fp2& b) { return Fp2{fp_sub_dbl(a.c0, b.c0), fp_sub_dbl(a.c1, b.c1)}; }
 ECG_HD Fp2 fp2_inv(const Fp2& a) {
     Fp d = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
     return Fp2{fp_mul(a.c0, d), fp_neg(fp_mul(a.c1, d))};

@@ -104,9 +104,9 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
 // T <- 2T, f <- f * line_{T,T}(P); T = running point of pair k, read from the lane slots where it is used.
 // The dbl-2009-l quantities regrouped as in jac_dbl_inl (bls_curve.h) so that no modular addition touches a product:
 //   A = X^2, B = Y^2, ZZ = Z^2, E = 3A (lazy), D = (4X) B,
-//   X3 = E E + (8p - 4X)(2B),  Y3 = E (D - X3 + 2p) + (8p - 4B)(2B),  Z3 = (2Y) Z,
+//   X3 = E^2 - 2D (squaring of the lazy E + one correction),  Y3 = E (D - X3 + 2p) + (8p - 4B)(2B),  Z3 = (2Y) Z,
 //   line: l0 = E X + (4p - 2B) (a lazy sum: < 6p), l1 = (E ZZ)(2p - xP), l2 = (Z3 ZZ) yP
-// 3 squarings, 5 products, 2 sums of two products and 4 Fp products over lazy operands; the textbook form above costs 6
+// 4 squarings, 5 products, 1 sum of two products and 4 Fp products over lazy operands; the textbook form above costs 6
 // squarings, 5 products and 15 Fp2 modular additions / doublings (30 x ~105 instructions per step, 126 steps per check).
 ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, const MillerPair& m, int k) {
     const int sx = 6 * k, sy = sx + 2, sz = sx + 4;
@@ -130,8 +130,8 @@ ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, const MillerPair& m, int k) {
         const Fp2 X2 = fp2_add_lazy(X, X), X4 = fp2_add_lazy(X2, X2);  // < 8p
         const Fp2 D = fp2_mulx(X4, B);
         const Fp2 B4 = fp2_add_lazy(B2, B2);  // < 8p
-        const Fp2 n4X = f_neg_lazy<8>(X4), n4B = f_neg_lazy<8>(B4);
-        X3 = f_sp2<6, 4>(E, E, n4X, B2);
+        const Fp2 n4B = f_neg_lazy<8>(B4);
+        X3 = fp2_sub_dbl(fp2_sqr_lazy<6>(E), D);  // E^2 - 2D: a squaring and a correction instead of a sum of two products
         Y3 = f_sp2<4, 4>(E, f_sub_lazy<2>(D, X3), n4B, B2);
     }
     slot_store2(sx, X3);

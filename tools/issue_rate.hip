@@ -77,6 +77,21 @@ __global__ void __launch_bounds__(64) k_mad_u64_u32(u32* out) {
     }
     out[blockIdx.x * 64 + threadIdx.x] = (u32)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
 }
+// the same with an s_nop 0 after every eight multiply-adds (counted as eight instructions): what the hazard recogniser's s_nop after
+// an inline-asm statement costs
+__global__ void __launch_bounds__(64) k_mad_u64_u32_nop(u32* out) {
+    u64 a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    u32 b = blockIdx.x * 2654435761u + 12345u, c = threadIdx.x * 40503u + 7u;
+    for (int t = 0; t < TRIPS; t++) {
+        REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_mad_u64_u32 %2, vcc, %8, %9, %2\n\t"
+                          "v_mad_u64_u32 %3, vcc, %8, %9, %3\n\tv_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_mad_u64_u32 %5, vcc, %8, %9, %5\n\t"
+                          "v_mad_u64_u32 %6, vcc, %8, %9, %6\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7\n\ts_nop 0"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                          : "v"(b), "v"(c)
+                          : "vcc");)
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = (u32)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
 // the SHA-256 round mix: 4 alignbit + 2 bitop3 + 2 add3 per eight instructions (roughly the hash64 inner loop's blend)
 __global__ void __launch_bounds__(64) k_sha_mix(u32* out) {
     u32 a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
@@ -122,7 +137,7 @@ int main() {
                           {"v_and_b32", k_and_b32},         {"v_bitop3_b32", k_bitop3_b32},   {"v_alignbit_b32", k_alignbit_b32},
                           {"v_lshrrev_b32", k_lshrrev_b32}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_perm_b32", k_perm_b32},
                           {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_lo_u32", k_mul_lo_u32},   {"v_mul_hi_u32", k_mul_hi_u32},
-                          {"v_mad_u64_u32", k_mad_u64_u32}, {"sha256 round mix", k_sha_mix},  {"v_add3 dependent", k_dep_add3}};
+                          {"v_mad_u64_u32", k_mad_u64_u32}, {"8 mad + s_nop", k_mad_u64_u32_nop}, {"sha256 round mix", k_sha_mix},  {"v_add3 dependent", k_dep_add3}};
     for (const Case& c : cases) {
         printf("%-18s", c.name);
         for (int wps = 1; wps <= 8; wps *= 2) {
