@@ -368,6 +368,38 @@ ECG_HD Fp fp_sub_dbl(const Fp& a, const Fp& b) {
     return fp_cond_sub(r, blsc::P2);
 }
 
+// x < KIN p (limbs normalized, the top limb carrying the excess) -> the same residue below KOUT p, by conditional subtractions of
+// KOUT 2^k p, k descending from the smallest k with KOUT 2^(k+1) >= KIN: after the step for C the value is below C.
+template <int KIN, int KOUT>
+ECG_HD Fp fp_reduce_below(const Fp& x) {
+    if constexpr (KIN <= KOUT) {
+        return x;
+    } else {
+        constexpr int k = KIN <= 2 * KOUT ? 0 : KIN <= 4 * KOUT ? 1 : KIN <= 8 * KOUT ? 2 : KIN <= 16 * KOUT ? 3 : -1;
+        static_assert(k >= 0, "fp_reduce_below: more than four steps");
+        constexpr FpConst c = fp_p_times(KOUT << k);
+        return fp_reduce_below<(KOUT << k), KOUT>(fp_cond_sub(x, c.l));
+    }
+}
+// 3t + 2z (S > 0) or 3t - 2z (S < 0) mod p, below KOUT p, for t < KT p and z < KZ p: the linear step that follows every Fp4
+// squaring of a Granger-Scott / Karabina cyclotomic squaring.  As t + 2 (t +- z): one lazy addition / subtraction, one pass for
+// the doubling and the sum, and the conditional subtractions -- against three modular operations (312 instructions) before.
+template <int S, int KT, int KZ, int KOUT>
+ECG_HD Fp fp_gs_lin(const Fp& t, const Fp& z) {
+    Fp d;
+    if constexpr (S > 0) d = fp_add_lazy(t, z);  // < (KT + KZ) p
+    else d = fp_sub_lazy_k<KZ>(t, z);            // t - z + KZ p < (KT + KZ) p
+    Fp r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        const u32 v = (d.l[i] << 1) + t.l[i] + c;
+        r.l[i] = i + 1 < FP_N ? (v & FP_MASK) : v;
+        c = v >> 30;
+    }
+    return fp_reduce_below<KT + 2 * (KT + KZ), KOUT>(r);
+}
+
 // Sum of N products with ONE Montgomery reduction: (a_0 b_0 + ... + a_{N-1} b_{N-1}) / R mod p, result < 2p whenever
 // the integer sum is < R p = 632 p^2 (operands are lazy sums / lazy negations; every caller states its bound).
 // This is how the tower spends multiplier time instead of linear operations: on gfx950 a 104-instruction modular

@@ -239,6 +239,10 @@ ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
         if (RUNS[s].compressed) {
             Fp2 z2 = acc.c1.c0, z3 = acc.c0.c2, z4 = acc.c0.c1, z5 = acc.c1.c2;
             for (u32 k = 0; k < n; k++) fp12_cyclotomic_sqr_compressed(z2, z3, z4, z5);
+            z2 = fp2_below_2p(z2);  // the run kept its coefficients below 4p (bls_tower.h)
+            z3 = fp2_below_2p(z3);
+            z4 = fp2_below_2p(z4);
+            z5 = fp2_below_2p(z5);
             Fp2 z0, z1;
             fp12_cyclotomic_decompress(z0, z1, z2, z3, z4, z5);
             acc.c0.c0 = z0;
@@ -248,7 +252,8 @@ ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
             acc.c1.c1 = z1;
             acc.c1.c2 = z5;
         } else {
-            for (u32 k = 0; k < n; k++) fp12_cyclotomic_sqr_inl(acc, acc);
+            for (u32 k = 0; k < n; k++) fp12_cyclotomic_sqr_run(acc, acc);
+            fp12_cyc_normalize(acc);
         }
         if (s < 5) fp12_mul_by_slots_inl(acc, acc);
     }

@@ -267,11 +267,13 @@ ECG_HD_NOINLINE void fp12_frob(Fp12& r, const Fp12& a) {
 // Fp4 squaring (a + b s)^2, s^2 = xi: c0 = a^2 + xi b^2, c1 = 2ab as four sums of products over lazy operands --
 //   c0.re = (ar + ai)(ar - ai) + (br + bi)(br - bi) - 2 br bi      c0.im = 2 ar ai + (br + bi)(br - bi) + 2 br bi
 //   c1.re = 2 ar br - 2 ai bi                                      c1.im = 2 ar bi + 2 ai br
-// 10 half-products, 4 reductions.  Components of a, b < 2p; every lazy operand < 4p: sums below 40 p^2.
+// 10 half-products, 4 reductions.  Components of a, b < K p (K = 2 or 4); every lazy operand < 2 K p: sums below
+// (4 + 4 + 2) K^2 p^2 = 160 p^2 at K = 4.
+template <int K>
 ECG_HD void fp4_sqr(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
-    const Fp sa = fp_add_lazy(a.c0, a.c1), da = fp_sub_lazy_k<2>(a.c0, a.c1);
-    const Fp sb = fp_add_lazy(b.c0, b.c1), db = fp_sub_lazy_k<2>(b.c0, b.c1);
-    const Fp b2r = fp_add_lazy(b.c0, b.c0), nbi = fp_neg_lazy<2>(b.c1);
+    const Fp sa = fp_add_lazy(a.c0, a.c1), da = fp_sub_lazy_k<K>(a.c0, a.c1);
+    const Fp sb = fp_add_lazy(b.c0, b.c1), db = fp_sub_lazy_k<K>(b.c0, b.c1);
+    const Fp b2r = fp_add_lazy(b.c0, b.c0), nbi = fp_neg_lazy<K>(b.c1);
     const Fp a2r = fp_add_lazy(a.c0, a.c0), a2i = fp_add_lazy(a.c1, a.c1);
     {
         const Fp x[3] = {sa, sb, b2r}, y[3] = {da, db, nbi};
@@ -284,25 +286,28 @@ ECG_HD void fp4_sqr(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
     c1.c0 = fp_sumprod2(a2r, b.c0, a2i, nbi);
     c1.c1 = fp_sumprod2(a2r, b.c1, a2i, b.c0);
 }
-ECG_HD void fp12_cyclotomic_sqr_inl(Fp12& r, const Fp12& f) {
+// The linear step z' = 3t +- 2z of every coefficient (t: the Fp4 squaring's output, < 2p) in one pass and two conditional
+// subtractions (fp_gs_lin) instead of three modular operations: a RUN of squarings keeps its coefficients below 4p -- which the
+// Fp4 squaring's lazy operands absorb -- and whoever ends the run brings them below 2p (fp12_cyc_normalize).  Round 3: the
+// linear steps were 26 % of a squaring's instructions.
+template <int S, int KT = 2>
+ECG_HD Fp2 fp2_gs_lin(const Fp2& t, const Fp2& z) {
+    return Fp2{fp_gs_lin<S, KT, 4, 4>(t.c0, z.c0), fp_gs_lin<S, KT, 4, 4>(t.c1, z.c1)};
+}
+ECG_HD Fp2 fp2_below_2p(const Fp2& a) { return Fp2{fp_cond_sub(a.c0, blsc::P2), fp_cond_sub(a.c1, blsc::P2)}; }  // a < 4p
+// coefficients < 4p in, < 4p out
+ECG_HD void fp12_cyclotomic_sqr_run(Fp12& r, const Fp12& f) {
     Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
     Fp2 t0, t1, t2, t3;
-    fp4_sqr(t0, t1, z0, z1);
-    z0 = fp2_sub(t0, z0);
-    z0 = fp2_add(fp2_dbl(z0), t0);
-    z1 = fp2_add(t1, z1);
-    z1 = fp2_add(fp2_dbl(z1), t1);
-    fp4_sqr(t0, t1, z2, z3);
-    fp4_sqr(t2, t3, z4, z5);
-    z4 = fp2_sub(t0, z4);
-    z4 = fp2_add(fp2_dbl(z4), t0);
-    z5 = fp2_add(t1, z5);
-    z5 = fp2_add(fp2_dbl(z5), t1);
-    t0 = fp2_mul_xi(t3);
-    z2 = fp2_add(t0, z2);
-    z2 = fp2_add(fp2_dbl(z2), t0);
-    z3 = fp2_sub(t2, z3);
-    z3 = fp2_add(fp2_dbl(z3), t2);
+    fp4_sqr<4>(t0, t1, z0, z1);
+    z0 = fp2_gs_lin<-1>(t0, z0);
+    z1 = fp2_gs_lin<+1>(t1, z1);
+    fp4_sqr<4>(t0, t1, z2, z3);
+    fp4_sqr<4>(t2, t3, z4, z5);
+    z4 = fp2_gs_lin<-1>(t0, z4);
+    z5 = fp2_gs_lin<+1>(t1, z5);
+    z2 = fp2_gs_lin<+1, 4>(fp2_mul_xi_lazy<2>(t3), z2);  // xi t3: components < 4p
+    z3 = fp2_gs_lin<-1>(t2, z3);
     r.c0.c0 = z0;
     r.c0.c1 = z4;
     r.c0.c2 = z3;
@@ -310,24 +315,33 @@ ECG_HD void fp12_cyclotomic_sqr_inl(Fp12& r, const Fp12& f) {
     r.c1.c1 = z1;
     r.c1.c2 = z5;
 }
+ECG_HD void fp12_cyc_normalize(Fp12& a) {  // coefficients < 4p -> < 2p
+    a.c0.c0 = fp2_below_2p(a.c0.c0);
+    a.c0.c1 = fp2_below_2p(a.c0.c1);
+    a.c0.c2 = fp2_below_2p(a.c0.c2);
+    a.c1.c0 = fp2_below_2p(a.c1.c0);
+    a.c1.c1 = fp2_below_2p(a.c1.c1);
+    a.c1.c2 = fp2_below_2p(a.c1.c2);
+}
+// one squaring, coefficients < 2p in and out
+ECG_HD void fp12_cyclotomic_sqr_inl(Fp12& r, const Fp12& f) {
+    fp12_cyclotomic_sqr_run(r, f);
+    fp12_cyc_normalize(r);
+}
 // Karabina's compressed squaring ("Squaring in cyclotomic subgroups", Math. Comp. 2013): the four coefficients z2 .. z5 of an
 // element of the cyclotomic subgroup determine the other two, and squaring THEM is two of the three Fp4 squarings above --
-// with the coefficient naming of fp12_cyclotomic_sqr_inl the update of z2 .. z5 does not read z0, z1 at all.  A run of k
+// with the coefficient naming of fp12_cyclotomic_sqr_run the update of z2 .. z5 does not read z0, z1 at all.  A run of k
 // squarings between two products costs 2k Fp4 squarings + one decompression (an Fp2 inversion, 3 squarings, 4 products)
 // instead of 3k: worth it for the runs of 32 and 16 in the exponent |x| (bls_pairing.h fp12_cyc_pow_x).
+// Coefficients < 4p in and out (a run; fp2_below_2p before the decompression).
 ECG_HD void fp12_cyclotomic_sqr_compressed(Fp2& z2, Fp2& z3, Fp2& z4, Fp2& z5) {
     Fp2 t0, t1, t2, t3;
-    fp4_sqr(t0, t1, z2, z3);
-    fp4_sqr(t2, t3, z4, z5);
-    z4 = fp2_sub(t0, z4);
-    z4 = fp2_add(fp2_dbl(z4), t0);
-    z5 = fp2_add(t1, z5);
-    z5 = fp2_add(fp2_dbl(z5), t1);
-    t0 = fp2_mul_xi(t3);
-    z2 = fp2_add(t0, z2);
-    z2 = fp2_add(fp2_dbl(z2), t0);
-    z3 = fp2_sub(t2, z3);
-    z3 = fp2_add(fp2_dbl(z3), t2);
+    fp4_sqr<4>(t0, t1, z2, z3);
+    fp4_sqr<4>(t2, t3, z4, z5);
+    z4 = fp2_gs_lin<-1>(t0, z4);
+    z5 = fp2_gs_lin<+1>(t1, z5);
+    z2 = fp2_gs_lin<+1, 4>(fp2_mul_xi_lazy<2>(t3), z2);
+    z3 = fp2_gs_lin<-1>(t2, z3);
 }
 // z0, z1 from z2 .. z5:  z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2),  z0 = xi (2 z1^2 + z2 z5 - 3 z3 z4) + 1;  for z2 = 0:
 // z1 = 2 z4 z5 / z3 (the same z0 formula; z3 = 0 as well: the element is 1, and 1 / 0 = 0 here gives exactly that).  Both
