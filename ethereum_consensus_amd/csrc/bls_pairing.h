@@ -84,8 +84,9 @@ ECG_HD void slot_store_fp12(const Fp12& a) {
 struct MillerPair {
     Fp px, py;  // P in E1 affine
     Fp npx;     // 2p - px: the minus sign of the line's w^2 coefficient as a product operand
+    Fp n3px;    // 3 (2p - px) (lazy, < 6p): the doubling step's
     Fp2 qx, qy; // Q in E2 affine
-    J2 t;       // running point: the caller's initial value; miller_loop keeps the live one in the lane slots
+    J2 t;       // running point (HOMOGENEOUS projective: x = X/Z, y = Y/Z): the caller's initial value; miller_loop keeps the live one in the lane slots
     u32 active; // 0: P or Q is infinity, the pair contributes 1
 };
 
@@ -94,6 +95,7 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
     m.px = p.x;
     m.py = p.y;
     m.npx = fp_neg_lazy<2>(p.x);
+    m.n3px = fp_add_lazy(fp_add_lazy(m.npx, m.npx), m.npx);
     m.qx = q.x;
     m.qy = q.y;
     m.t.x = q.x;
@@ -102,61 +104,69 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
 }
 
 // T <- 2T, f <- f * line_{T,T}(P); T = running point of pair k, read from the lane slots where it is used.
-// The dbl-2009-l quantities regrouped as in jac_dbl_inl (bls_curve.h) so that no modular addition touches a product:
-//   A = X^2, B = Y^2, ZZ = Z^2, E = 3A (lazy), D = (4X) B,
-//   X3 = E^2 - 2D (squaring of the lazy E + one correction),  Y3 = E (D - X3 + 2p) + (8p - 4B)(2B),  Z3 = (2Y) Z,
-//   line: l0 = E X + (4p - 2B) (a lazy sum: < 6p), l1 = (E ZZ)(2p - xP), l2 = (Z3 ZZ) yP
-// 4 squarings, 5 products, 1 sum of two products and 4 Fp products over lazy operands; the textbook form above costs 6
-// squarings, 5 products and 15 Fp2 modular additions / doublings (30 x ~105 instructions per step, 126 steps per check).
+// Homogeneous projective coordinates on the twist E': y^2 = x^3 + b', b' = 4 xi (Costello-Lange-Naehrig 2010; Aranha et al.
+// 2011, eq. 10, scaled by 4 so that nothing is halved):
+//   B = Y^2, J = X^2, H = 2 Y Z, E = 3 b' Z^2 = 3 xi (2Z)^2 (brought below 2p: an operand of the four terms below), F = 3E,
+//   X3 = (2 X Y)(B - F),   Y3 = (B + F)^2 - 12 E^2 = B (B + 6E) + E (-3E),   Z3 = (4B) H,
+//   line (the tangent scaled by Z^2; any Fp2 factor dies in the final exponentiation): l0 = B - E, l1 = -3 J xP, l2 = H yP.
+// 3 squarings, 4 products, 1 sum of two products, 4 Fp products over lazy operands.  Round 3 used Jacobian coordinates until
+// its last day (4 squarings, 5 products, 1 sum of two products, 4 Fp products: the Jacobian line needs E Z^2 and Z3 Z^2 as
+// products of their own).
 ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, const MillerPair& m, int k) {
     const int sx = 6 * k, sy = sx + 2, sz = sx + 4;
-    const Fp2 A = fp2_sqrx(slot_load2(sx));
-    const Fp2 E = fp2_add_lazy(fp2_add_lazy(A, A), A);  // < 6p
-    const Fp2 ZZ = fp2_sqrx(slot_load2(sz));
-    const Fp2 l1 = fp2_mul_fp(fp2_mulx(E, ZZ), m.npx);
-    Fp2 Z3;
+    Fp2 H, E;
+    {
+        const Fp2 Z = slot_load2(sz);
+        {
+            const Fp2 Y = slot_load2(sy);
+            H = fp2_mulx(fp2_add_lazy(Y, Y), Z);
+        }
+        const Fp2 xc = fp2_mul_xi_lazy<2>(fp2_sqr_lazy<4>(fp2_add_lazy(Z, Z)));  // xi (2Z)^2, components < 4p
+        E.c0 = fp_reduce_below<12, 2>(fp_add_lazy(fp_add_lazy(xc.c0, xc.c0), xc.c0));
+        E.c1 = fp_reduce_below<12, 2>(fp_add_lazy(fp_add_lazy(xc.c1, xc.c1), xc.c1));
+    }
+    Fp2 B, XY2, l1;
     {
         const Fp2 Y = slot_load2(sy);
-        Z3 = fp2_mulx(fp2_add_lazy(Y, Y), slot_load2(sz));
-    }
-    slot_store2(sz, Z3);
-    const Fp2 l2 = fp2_mul_fp(fp2_mulx(Z3, ZZ), m.py);
-    const Fp2 B = fp2_sqrx(slot_load2(sy));
-    const Fp2 B2 = fp2_add_lazy(B, B);  // < 4p
-    const Fp2 l0 = fp2_add_lazy(fp2_mulx(E, slot_load2(sx)), f_neg_lazy<4>(B2));  // < 6p
-    Fp2 X3, Y3;
-    {
+        B = fp2_sqrx(Y);
         const Fp2 X = slot_load2(sx);
-        const Fp2 X2 = fp2_add_lazy(X, X), X4 = fp2_add_lazy(X2, X2);  // < 8p
-        const Fp2 D = fp2_mulx(X4, B);
-        const Fp2 B4 = fp2_add_lazy(B2, B2);  // < 8p
-        const Fp2 n4B = f_neg_lazy<8>(B4);
-        X3 = fp2_sub_dbl(fp2_sqr_lazy<6>(E), D);  // E^2 - 2D: a squaring and a correction instead of a sum of two products
-        Y3 = f_sp2<4, 4>(E, f_sub_lazy<2>(D, X3), n4B, B2);
+        XY2 = fp2_mulx(fp2_add_lazy(X, X), Y);
+        l1 = fp2_mul_fp(fp2_sqrx(X), m.n3px);
     }
-    slot_store2(sx, X3);
-    slot_store2(sy, Y3);
-    fp12_mul_by_line<6>(f, l0, l1, l2);
+    const Fp2 l2 = fp2_mul_fp(H, m.py);
+    {
+        const Fp2 B2 = fp2_add_lazy(B, B);
+        slot_store2(sz, fp2_mulx(fp2_add_lazy(B2, B2), H));  // Z3 = (4B) H
+    }
+    const Fp2 l0 = f_sub_lazy<2>(B, E);  // < 4p
+    {
+        const Fp2 F = fp2_add_lazy(fp2_add_lazy(E, E), E);  // 3E < 6p
+        slot_store2(sx, fp2_mulx(XY2, f_sub_lazy<6>(B, F)));  // X3 = (2XY)(B - F + 6p)
+        // Y3 = B (B + 6E) + E (6p - 3E): bounds (units of p^2 per coefficient, Fp2 doubles them) 2 * 14 + 2 * 6 = 40
+        slot_store2(sy, f_sp2<14, 6>(B, fp2_add_lazy(fp2_add_lazy(B, F), F), E, f_neg_lazy<6>(F)));
+    }
+    fp12_mul_by_line<4>(f, l0, l1, l2);
 }
 
-// T <- T + Q, f <- f * line_{T,Q}(P)
+// T <- T + Q (Q affine), f <- f * line_{T,Q}(P): the mixed addition in the same coordinates (madd-1998-cmo with both signs turned),
+//   theta = Y - yQ Z, lambda = X - xQ Z, C = theta^2, D = lambda^2, E = lambda D, F = Z C, G = X D, A = E + F - 2G,
+//   X3 = lambda A, Y3 = theta (G - A) - E Y, Z3 = Z E,   line: l0 = theta xQ - lambda yQ, l1 = -theta xP, l2 = lambda yP.
+// Five steps per pair and check: modular linear operations as they come.
 ECG_HD void miller_add_step_inl(Fp12& f, const MillerPair& m, int k) {
     const J2 T = slot_load_point(k);
-    Fp2 Z1Z1 = fp2_sqrx(T.z);
-    Fp2 U2 = fp2_mulx(m.qx, Z1Z1);
-    Fp2 S2 = fp2_mulx(fp2_mulx(m.qy, T.z), Z1Z1);
-    Fp2 H = fp2_sub(U2, T.x);
-    Fp2 HH = fp2_sqrx(H);
-    Fp2 I = fp2_dbl(fp2_dbl(HH));
-    Fp2 J = fp2_mulx(H, I);
-    Fp2 rr = fp2_dbl(fp2_sub(S2, T.y));
-    Fp2 V = fp2_mulx(T.x, I);
-    Fp2 X3 = fp2_sub(fp2_sub(fp2_sqrx(rr), J), fp2_dbl(V));
-    Fp2 Y3 = fp2_sub(fp2_mulx(rr, fp2_sub(V, X3)), fp2_dbl(fp2_mulx(T.y, J)));
-    Fp2 Z3 = fp2_sub(fp2_sub(fp2_sqrx(fp2_add(T.z, H)), Z1Z1), HH);
-    Fp2 l0 = fp2_sub(fp2_mulx(rr, m.qx), fp2_mulx(m.qy, Z3));
-    Fp2 l1 = fp2_mul_fp(rr, m.npx);
-    Fp2 l2 = fp2_mul_fp(Z3, m.py);
+    const Fp2 th = fp2_sub(T.y, fp2_mulx(m.qy, T.z));
+    const Fp2 la = fp2_sub(T.x, fp2_mulx(m.qx, T.z));
+    const Fp2 D = fp2_sqrx(la);
+    const Fp2 E = fp2_mulx(la, D);
+    const Fp2 F = fp2_mulx(T.z, fp2_sqrx(th));
+    const Fp2 G = fp2_mulx(T.x, D);
+    const Fp2 A = fp2_sub(fp2_add(E, F), fp2_dbl(G));
+    const Fp2 X3 = fp2_mulx(la, A);
+    const Fp2 Y3 = fp2_sub(fp2_mulx(th, fp2_sub(G, A)), fp2_mulx(E, T.y));
+    const Fp2 Z3 = fp2_mulx(T.z, E);
+    const Fp2 l0 = fp2_sub(fp2_mulx(th, m.qx), fp2_mulx(la, m.qy));
+    const Fp2 l1 = fp2_mul_fp(th, m.npx);
+    const Fp2 l2 = fp2_mul_fp(la, m.py);
     slot_store_point(k, J2{X3, Y3, Z3});
     fp12_mul_by_line<2>(f, l0, l1, l2);
 }

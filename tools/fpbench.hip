@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64) k_bench12(const Fp* in, Fp* out) {
     m.t.y = g.c1.c0;
     m.t.z = g.c1.c1;
     m.active = 1;
-    m.npx = fp_neg_lazy<2>(m.px);
+    m.npx = fp_neg_lazy<2>(m.px); m.n3px = fp_add_lazy(fp_add_lazy(m.npx, m.npx), m.npx);
     slot_store_point(0, m.t);
     for (int i = 0; i < ITERS / 16; i++) {
         if (OP == 0) fp12_sqr(f, f);
