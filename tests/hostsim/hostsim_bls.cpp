@@ -317,6 +317,29 @@ u64 hs_sumprod_raw(int n, const u32* a, const u32* b, u32* out) {
     }
     return g_ecg_column_overflows;
 }
+// the linear helpers of round 3 on raw limbs (13 x 30 bits, the top limb carrying the excess of a lazy value)
+// op: 0 fp_sub_dbl(a, b)  1 fp_gs_lin<+1,2,4,4>  2 fp_gs_lin<-1,2,4,4>  3 fp_gs_lin<+1,4,4,4>  4 fp_reduce_below<12,2>(a)
+//     5 fp_reduce_below<20,4>(a)  6 fp_reduce_below<14,4>(a)  7 fp_cond_sub(a, 2p)
+int hs_fp_lin_raw(int op, const u32* a, const u32* b, u32* out) {
+    Fp x, y, r;
+    for (int i = 0; i < 13; i++) {
+        x.l[i] = a[i];
+        y.l[i] = b ? b[i] : 0;
+    }
+    switch (op) {
+        case 0: r = fp_sub_dbl(x, y); break;
+        case 1: r = fp_gs_lin<+1, 2, 4, 4>(x, y); break;
+        case 2: r = fp_gs_lin<-1, 2, 4, 4>(x, y); break;
+        case 3: r = fp_gs_lin<+1, 4, 4, 4>(x, y); break;
+        case 4: r = fp_reduce_below<12, 2>(x); break;
+        case 5: r = fp_reduce_below<20, 4>(x); break;
+        case 6: r = fp_reduce_below<14, 4>(x); break;
+        case 7: r = fp_cond_sub(x, blsc::P2); break;
+        default: return -1;
+    }
+    for (int i = 0; i < 13; i++) out[i] = r.l[i];
+    return 0;
+}
 u64 hs_column_overflows() { return g_ecg_column_overflows; }
 
 void hs_census_reset() { g_ecg_fp_mul_count = g_ecg_fp_sqr_count = g_ecg_fp_mad_count = 0; }

@@ -95,6 +95,43 @@ def _sumprod(avals, bvals):
     return ov, sum(int(out[i]) << (30 * i) for i in range(13))
 
 
+def _lin_raw(op, a, b=None):
+    arr = ctypes.c_uint32 * 13
+    out = arr()
+    rc = lib().hs_fp_lin_raw(op, arr(*_limbs(a)), arr(*_limbs(b)) if b is not None else None, out)
+    assert rc == 0
+    assert all(int(out[i]) < (1 << 30) for i in range(12)), "limbs must come back normalised"
+    return sum(int(out[i]) << (30 * i) for i in range(13))
+
+
+def test_linear_helpers_at_the_edges_of_their_ranges():
+    """fp_sub_dbl (X3 = E^2 - 2D of a doubling), fp_gs_lin (3t +- 2z of a cyclotomic squaring) and fp_reduce_below: the right
+    residue, inside the promised interval, for operands at both ends of theirs -- the parity tests only ever feed them random
+    values."""
+    r = random.Random(91)
+
+    def edge(k):  # values around the ends of [0, k p)
+        vals = [0, 1, 2, P - 1, P, P + 1, k * P - 1, k * P - 2, (k * P) // 2, (k - 1) * P, (k - 1) * P + 1, (k - 1) * P - 1]
+        vals += [r.randrange(k * P) for _ in range(12)]
+        vals += [k * P - 1 - r.randrange(1 << 64) for _ in range(4)] + [r.randrange(1 << 64) for _ in range(4)]
+        vals += [sum(0x3FFFFFFF << (30 * i) for i in range(12)) % (k * P)]  # saturated low limbs
+        return [v for v in vals if 0 <= v < k * P]
+
+    for a in edge(2):
+        for b in edge(2):
+            res = _lin_raw(0, a, b)
+            assert res < 2 * P and res % P == (a - 2 * b) % P
+    for op, sign, kt in ((1, 1, 2), (2, -1, 2), (3, 1, 4)):
+        for t in edge(kt):
+            for z in edge(4):
+                res = _lin_raw(op, t, z)
+                assert res < 4 * P and res % P == (3 * t + sign * 2 * z) % P
+    for op, kin, kout in ((4, 12, 2), (5, 20, 4), (6, 14, 4), (7, 4, 2)):
+        for a in edge(kin):
+            res = _lin_raw(op, a)
+            assert res < kout * P and res % P == a % P
+
+
 def test_sum_of_products_lazy_bounds_and_column_headroom():
     """fp_sumprod<N>: one Montgomery reduction for N products of lazy operands.  Result < 2p and == sum a b / R whenever
     the sum is below R p (632 p^2); the 64-bit columns never overflow, even for saturated 30-bit limbs."""
