@@ -1,13 +1,13 @@
 // Optimal-ate pairing check on BLS12-381 for the gfx950 BLS path: the e(pk, H(m)) == e(g1, sig)
 // equation blst evaluates for /root/reference/ethereum-consensus/src/crypto/bls.rs:71,106,126.
 //
-// Miller loop over |x| = 0xd201000000010000 on the M-twist with inversion-free Jacobian steps; all
-// pairs of one product share the accumulator squaring.  Line through the untwisted T evaluated at
-// P = (xP, yP), times w^3 and times an Fp2 factor (both killed by the final exponentiation):
-//     doubling:  (E X - 2 Y^2) + (-E Z^2 xP) w^2 + (Z3 Z^2 yP) w^3       E = 3 X^2, Z3 = 2 Y Z
-//     addition:  (r xQ - yQ Z3) + (-r xP) w^2 + (Z3 yP) w^3              r = 2 (yQ Z^3 - Y), Z3 = 2 Z H
+// Miller loop over |x| = 0xd201000000010000 on the M-twist with inversion-free steps in homogeneous projective
+// coordinates (x = X/Z, y = Y/Z); all pairs of one product share the accumulator squaring.  Line through the untwisted T
+// evaluated at P = (xP, yP), times w^3 and times an Fp2 factor (both killed by the final exponentiation):
+//     doubling:  (Y^2 - 3 b' Z^2) + (-3 X^2 xP) w^2 + (2 Y Z yP) w^3                                    b' = 4 xi
+//     addition:  (theta xQ - lambda yQ) + (-theta xP) w^2 + (lambda yP) w^3    theta = Y - yQ Z, lambda = X - xQ Z
 // i.e. the sparse shape fp12_mul_by_line multiplies by.  Final exponentiation: easy part, then
-// 3 (p^4 - p^2 + 1)/r = (x-1)^2 (x+p) (x^2 + p^2 - 1) + 3 with Granger-Scott cyclotomic squarings.
+// 3 (p^4 - p^2 + 1)/r = (x-1)^2 (x+p) (x^2 + p^2 - 1) + 3 with Granger-Scott / Karabina cyclotomic squarings.
 #pragma once
 #include "bls_curve.h"
 
@@ -109,9 +109,9 @@ ECG_HD void miller_pair_init(MillerPair& m, const A1& p, const A2& q) {
 //   B = Y^2, J = X^2, H = 2 Y Z, E = 3 b' Z^2 = 3 xi (2Z)^2 (brought below 2p: an operand of the four terms below), F = 3E,
 //   X3 = (2 X Y)(B - F),   Y3 = (B + F)^2 - 12 E^2 = B (B + 6E) + E (-3E),   Z3 = (4B) H,
 //   line (the tangent scaled by Z^2; any Fp2 factor dies in the final exponentiation): l0 = B - E, l1 = -3 J xP, l2 = H yP.
-// 3 squarings, 4 products, 1 sum of two products, 4 Fp products over lazy operands.  Round 3 used Jacobian coordinates until
-// its last day (4 squarings, 5 products, 1 sum of two products, 4 Fp products: the Jacobian line needs E Z^2 and Z3 Z^2 as
-// products of their own).
+// 3 squarings, 4 products, 1 sum of two products, 4 Fp products over lazy operands.  (Jacobian coordinates, until late in
+// round 3: 4 squarings, 5 products, 1 sum of two products, 4 Fp products -- the Jacobian line needs E Z^2 and Z3 Z^2 as
+// products of their own.)
 ECG_MILLER_DBL_FN void miller_dbl_step(Fp12& f, const MillerPair& m, int k) {
     const int sx = 6 * k, sy = sx + 2, sz = sx + 4;
     Fp2 H, E;
