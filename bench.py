@@ -214,10 +214,10 @@ R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 # of N products with one reduction 169 N + 182, see csrc/bls_fp.h.  The census used is the one of the build that RAN
 # (ecgpu_bls_tower(): 1 = sums of products, 2 = compact-code G2 stage kernels; tools/bls_op_census.py prints these tuples).
 BLS_OPS_BY_BUILD = {
-    1: {"bls_pk_validate": (461, 812, 65520), "bls_sig": (170, 756, 458744), "bls_h2c": (361, 1520, 1076572),
+    1: {"bls_pk_validate": (441, 807, 65520), "bls_sig": (170, 756, 434434), "bls_h2c": (361, 1520, 1076572),
         "bls_pairing": (588, 22, 6592154)},
     # compact-code build of the G2 stages (boxes with slow instruction fetch); the pairing check runs on the lane groups there
-    2: {"bls_pk_validate": (461, 812, 65520), "bls_sig": (1428, 756, 0), "bls_h2c": (3311, 1520, 7920), "bls_pairing": (588, 22, 6592154)},
+    2: {"bls_pk_validate": (441, 807, 65520), "bls_sig": (1428, 756, 0), "bls_h2c": (3311, 1520, 7920), "bls_pairing": (588, 22, 6592154)},
 }
 BLS_OPS = BLS_OPS_BY_BUILD[1]
 PAIRING_KERNEL_BY_BUILD = {1: "k_pairing", 2: "k_pairing"}
