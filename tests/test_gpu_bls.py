@@ -621,6 +621,9 @@ def config2_workload(gpu, tmp_path_factory):
     ("calls", "auto", 65536, 2, "vm3"),     # a box with slow instruction fetch: compact G2 stage kernels + lane groups at every size
     ("sums", "auto", 4096, 1, "vm3"),       # a small batch as dispatched by default: two-lane message stage + lane groups
     ("calls", "auto", 4096, 2, "vm3"),      # ... and on the compact-code build (k_h2c_map_calls / k_h2c_finish_calls, k_sig_calls)
+    ("sums", "lane", 65535, 1, "lane"),     # a ragged batch on the lane kernel: the last wave is one lane short (lane slots, statuses)
+    ("sums", "auto", 24576, 1, "vm3"),      # the default dispatch on either side of ECGPU_VM_MAX: the last size of the lane groups ...
+    ("sums", "auto", 24577, 1, "lane"),     # ... and the first of the lane kernel (385 waves, the last with one lane)
 ])
 def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, tower, pairing, n, want_tower, want_path):
     """The whole status vector of SURVEY.md 8(d) config 2 -- every fault class: wrong message, swapped key, signature outside
