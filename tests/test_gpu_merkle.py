@@ -127,6 +127,32 @@ def test_beacon_state_root_vs_python_oracle(gpu, preset, n):
     assert oracle_state_root_fast(f, preset) == want
 
 
+@pytest.mark.parametrize("n", [70_001, 300_001, 600_000])
+def test_beacon_state_root_of_ragged_mid_sized_registries(gpu, n):
+    """mainnet states between the small ones above and the 2^20 of config 3: registries that end inside a tile and inside a
+    lane's subtree, lists whose last chunk is partial, tile counts that are not powers of two -- the arrival tickets of the fused
+    tail count exactly these.  Against the C restatement (oracle/c/sha256_merkle.c over the oracle's own type tree)."""
+    from ethereum_consensus_amd import synthetic as S
+    f = S.state_fields(n, "mainnet", seed=n % 97, n_votes=n % 11, n_hist_roots=n % 5, n_hist_summaries=n % 7, extra_data=b"y" * (n % 33))
+    enc = S.serialize_state(f)
+    want = oracle_state_root_fast(f, "mainnet")
+    assert gpu.hash_tree_root_beacon_state_deneb(enc, 0) == want
+    # the device-resident entry (the one bench.py times), twice back to back on one stream: the second root's upload must not
+    # disturb the first one's tail (one arena, a ring of pinned plan slots)
+    import torch
+    L = gpu._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    d = torch.frombuffer(bytearray(enc), dtype=torch.uint8).cuda()
+    fixed = int(L.ecgpu_beacon_state_deneb_fixed_size(0))
+    fixed_part = ctypes.create_string_buffer(bytes(enc[:fixed]), fixed)
+    outs = [torch.zeros(32, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    for o in outs:
+        rc = L.ecgpu_htr_beacon_state_deneb_dev(d.data_ptr(), len(enc), fixed_part, 0, o.data_ptr(), st)
+        assert rc == 0, (rc, L.ecgpu_last_error())
+    torch.cuda.synchronize()
+    assert [bytes(o.cpu().numpy()) for o in outs] == [want, want]
+
+
 def test_beacon_state_root_full_size(gpu):
     """config 3: mainnet preset, 2^20 validators (BASELINE.json configs[2])."""
     from ethereum_consensus_amd import synthetic as S
