@@ -256,6 +256,12 @@ def test_multi_scalar_multiplication_by_buckets(gpu):
         ks[3] = 0
         ks[5] = (1 << bits) - 1
         assert (0, M.g1_multi_scalar_mul(pks[:m], ks, bits)) == cbls.g1_msm(pks[:m], ks), (bits, m)
+    # buckets full of ONE point (every lane's partial sum the same: the tree adds equal points, i.e. doubles) and of a point
+    # and its negative (partial sums and buckets at infinity)
+    neg = lambda pk: bytes([pk[0] ^ 0x20]) + pk[1:]  # the other root: flip the ZCash sign bit
+    same = [pks[40]] * 2100 + [pks[41], neg(pks[41])] * 1050
+    ks = [0x1234567 + (i % 3) for i in range(2100)] + [0xABCDEF] * 2100
+    assert (0, M.g1_multi_scalar_mul(same, ks, 32)) == cbls.g1_msm(same, ks)
     bad = list(pks[:6000])
     bad[5990] = syn.off_subgroup_public_key(3)
     with pytest.raises(M.BLSTError):
