@@ -225,6 +225,20 @@ ECG_HD void fp12_mul_by_slots_inl(Fp12& r, const Fp12& a) {
     fp12_karatsuba_combine(r.c0, r.c1, m, t0, t1);
 }
 
+// r = a * b for two values in the caller's private segment, the second operand through the lane slots: the out-of-line
+// product of bls_tower.h holds both operands and its Fp6 temporaries in registers and spills (217 scratch instructions per
+// call); this one reads b from LDS coefficient by coefficient, as the exponentiations by x do.  The slots must be free (they
+// are between two exponentiations).  r may alias a or b.
+ECG_HD_NOINLINE void fp12_mul_slots(Fp12& r, const Fp12& a, const Fp12& b) {
+    {
+        const Fp12 y = ecg_priv_load(b);
+        slot_store_fp12(y);
+    }
+    Fp12 x = ecg_priv_load(a);
+    fp12_mul_by_slots_inl(x, x);
+    ecg_priv_store(r, x);
+}
+
 // a^x for a in the cyclotomic subgroup (x < 0: conjugate)
 ECG_HD_NOINLINE void fp12_cyc_pow_x(Fp12& r, const Fp12& a) {
     // The running value is register-resident (squaring and product are inlined) and never passes through memory inside the
@@ -278,30 +292,30 @@ ECG_HD_NOINLINE void final_exponentiation(Fp12& r, const Fp12& f) {
     // easy part: (p^6 - 1)(p^2 + 1)
     fp12_conj(t, f0);
     fp12_inv(u, f0);
-    fp12_mul(t, t, u);
+    fp12_mul_slots(t, t, u);
     fp12_frob(u, t);
     fp12_frob(u, u);
-    fp12_mul(t, u, t);
+    fp12_mul_slots(t, u, t);
     // hard part
     fp12_cyc_pow_x(a, t);
     fp12_conj(u, t);
-    fp12_mul(a, a, u);  // t^(x-1)
+    fp12_mul_slots(a, a, u);  // t^(x-1)
     fp12_cyc_pow_x(b, a);
     fp12_conj(u, a);
-    fp12_mul(a, b, u);  // t^((x-1)^2)
+    fp12_mul_slots(a, b, u);  // t^((x-1)^2)
     fp12_cyc_pow_x(b, a);
     fp12_frob(u, a);
-    fp12_mul(b, b, u);  // a^(x+p)
+    fp12_mul_slots(b, b, u);  // a^(x+p)
     fp12_cyc_pow_x(c, b);
     fp12_cyc_pow_x(c, c);
     fp12_frob(u, b);
     fp12_frob(u, u);
-    fp12_mul(c, c, u);
+    fp12_mul_slots(c, c, u);
     fp12_conj(u, b);
-    fp12_mul(c, c, u);  // b^(x^2 + p^2 - 1)
+    fp12_mul_slots(c, c, u);  // b^(x^2 + p^2 - 1)
     fp12_cyclotomic_sqr(u, t);
-    fp12_mul(u, u, t);  // t^3
-    fp12_mul(c, c, u);
+    fp12_mul_slots(u, u, t);  // t^3
+    fp12_mul_slots(c, c, u);
     ecg_priv_store(r, c);
 }
 
