@@ -29,13 +29,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s, 6.29 measured copy)
 # Measured ALU ceilings of the two paths' inner loops on MI355X (tools/fpbench.hip, register-resident chains at 8 waves/SIMD):
 HASH64_PEAK_GHS = 17.66    # profiles/r01h_hash64_rate_vs_occupancy.txt: 2410 VALU instructions per hash64 at ~3.7 cycles each
-MUL_PIPE_PEAK_TOPS = 31.0  # profiles/r01a_int_issue_rate_microbench.txt: v_mad_u64_u32 issue rate (fp_mul sustains 28 T, r01f)
+# v_mad_u64_u32 issue rate, chip-wide, from the un-foldable asm streams of tools/issue_rate.hip (profiles/r02p_issue_rates.txt):
+# 36.4 T/s at 8 waves per SIMD -- the multiplier's ceiling, what every `valu_int.frac` below is a fraction of -- 31.8 T at two
+# waves, 26.7 T for a LONE wave per SIMD, which is all a 512-register lane kernel can have (rounds 1-3 quoted 31.0 T, the round-1
+# microbench, as the peak: that flattered every fraction by 17 %).
+MUL_PIPE_PEAK_TOPS = 36.4
+MUL_PIPE_ONE_WAVE_TOPS = 26.7
+MUL_PIPE_TWO_WAVES_TOPS = 31.8
 
 
 # The N-rank control flow below (finish, gather_selfcheck, run_epoch, run_bls) is device-agnostic on purpose: tests/
 # test_dist_gloo.py drives it on CPU tensors under gloo with a stub library (the oracle standing in for the kernels), so the
 # only multi-GPU lines left untested without hardware are the RCCL calls themselves.
 DEV = "cuda"
+# ECGPU_BENCH_FORCE_DIST=1: run the collectives of the N-rank flow even when the process group has ONE rank.  A single-rank
+# nccl group is legal, so `pytest -m gpu` executes the RCCL path of run_bls / run_merkle_sharded / finish on the one-GPU box
+# every round (tests/test_gpu_dist.py) instead of leaving it to the first 8-GPU run.
+FORCE_DIST = os.environ.get("ECGPU_BENCH_FORCE_DIST", "0") == "1"
+
+
+def _multi(dist, world):
+    return world > 1 or (FORCE_DIST and dist is not None)
 
 
 def _sync(torch):
@@ -71,10 +85,31 @@ def effective_cores():
     return {"affinity": aff, "cgroup_quota_cores": quota, "cores_effective": aff if quota is None else min(aff, max(1, int(quota + 0.5)))}
 
 
+# translation unit whose objects hold each kernel the roofline is quoted on (lib/build_manifest.json is keyed by it)
+KERNEL_UNIT = {"k_pairing": "bls_pairing_kernels.hip", "k_pairing2": "bls_pairing2_kernels.hip", "k_vm3_pair_a": "bls_vm3.hip",
+               "k_vm3_pair_c": "bls_vm3.hip", "k_merkle_pass<2, ValidatorLeaves>": "merkle.hip"}
+
+
+def kernel_source_hash(kernel_key: str):
+    """identity of the loaded kernel: the hash build.py recorded over the translation unit's sources when it built the object"""
+    try:
+        lib = os.environ.get("ECGPU_LIB")
+        d = os.path.dirname(lib) if lib else os.path.join(ROOT, "ethereum_consensus_amd", "lib")
+        name = "build_manifest.json"
+        if lib and os.path.basename(lib).startswith("libecgpu_"):
+            name = "build_manifest_" + os.path.basename(lib)[len("libecgpu_"):-3] + ".json"
+        with open(os.path.join(d, name)) as f:
+            return json.load(f).get(KERNEL_UNIT.get(kernel_key, ""))
+    except (OSError, ValueError):
+        return None
+
+
 def pmc_traffic(kernel_key: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate runs, see
     profiles/pmc_traffic.json and the `pmc` step of tools/gpu_visit.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the factor 2 is the gfx950
-    FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  None when no pass has been recorded for this kernel."""
+    FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  None when no pass has been recorded for this kernel, AND when the
+    recorded pass was taken on other kernels than the ones loaded now (the source hash of the kernel's translation unit, written by
+    the build into lib/build_manifest.json and by the PMC step into the record, must agree): a stale figure is not reported."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f).get(kernel_key)
@@ -82,8 +117,11 @@ def pmc_traffic(kernel_key: str):
         return None
     if not rec:
         return None
+    have = kernel_source_hash(kernel_key)
+    if not have or rec.get("src_hash") != have:
+        return None
     return {"bytes_per_launch": int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024), "fetch_size_kib": rec["fetch_kib"],
-            "write_size_kib": rec["write_kib"], "source": rec.get("source"),
+            "write_size_kib": rec["write_kib"], "source": rec.get("source"), "kernel_src_hash": have,
             "note": "separate rocprofv3 --pmc passes, summed over the kernel's launches of one step; FETCH_SIZE doubled (gfx950)"}
 
 
@@ -180,6 +218,28 @@ def run_merkle(args, L, torch, dist, rank, world):
     L.ecgpu_prof_read(dom, ctypes.byref(ms), ctypes.byref(nl))
     L.ecgpu_prof_enable(0)
     kern_ms = ms.value / max(args.steps, 1)  # per state: one launch of the pass
+    # SURVEY.md 8(d) config 3 asks for the root "timed device-resident AND including H2D": the host-pointer entry
+    # (ecgpu_htr_beacon_state: upload of the whole encoding, then the same kernels) from pageable and from pinned host memory.
+    # This is what an un-patched `state.hash_tree_root()` caller pays per slot on top of its own serialization; the resident
+    # state (slots workload) is what avoids it.  Never `value`.
+    h2d = None
+    if world == 1:
+        h_root = ctypes.create_string_buffer(32)
+        pinned = torch.from_numpy(np.frombuffer(enc, dtype=np.uint8).copy()).pin_memory()
+        h2d = {}
+        for name, ptr in (("pageable_ms", ctypes.cast(ctypes.c_char_p(enc), ctypes.c_void_p).value), ("pinned_ms", pinned.data_ptr())):
+            best = None
+            for _ in range(4):
+                t1 = time.perf_counter()
+                rc = L.ecgpu_htr_beacon_state(4, ptr, len(enc), 0, h_root)
+                t2 = time.perf_counter()
+                if rc != 0:
+                    raise RuntimeError(f"ecgpu_htr_beacon_state -> {rc}: {L.ecgpu_last_error()}")
+                best = (t2 - t1) if best is None else min(best, t2 - t1)
+            h2d[name] = best * 1e3
+        h2d["root_equals_resident_root"] = h_root.raw == bytes(d_root.cpu().numpy())
+        h2d["bytes_uploaded"] = len(enc)
+        h2d["note"] = "host entry ecgpu_htr_beacon_state: H2D copy of the encoding + root + 32-byte D2H, best of 4"
     # algorithmic bytes of the dominant kernel per state: 121 B read per validator + one
     # 32-byte node written per lane (2^D validators per lane, D from the schedule)
     lanes = n >> max(1, min(6, n.bit_length() - 1 - 18))
@@ -204,6 +264,91 @@ def run_merkle(args, L, torch, dist, rank, world):
                                "note": "the path is integer-VALU bound: 2410 VALU instructions per 64-byte hash64; peak = "
                                        "register-resident hash64 chains at 8 waves/SIMD (tools/fpbench.hip)"}},
         root=bytes(d_root.cpu().numpy()).hex(),
+        extra={"h2d_inclusive": h2d} if h2d else {},
+    )
+
+
+def run_merkle_sharded(args, L, torch, dist, rank, world, emulate_world=None):
+    """BASELINE north_star's Merkle half, strong-scaled: ONE deneb mainnet state of --validators validators over the ranks
+    (the reference's single call: state.hash_tree_root(), phase0/slot_processing.rs:67).  Every rank holds the state's encoding
+    (the caller's placement; rank g READS only its subtree of each registry-sized list), reduces its aligned subtrees (phase A),
+    the ranks all-gather 5 x 32 bytes each -- the path's only collective --, and every rank finishes the five lists, the other
+    fields and the root (phase B).  The root is asserted equal to the unsharded root of the same state on every rank.
+    emulate_world = W (single process): the W ranks' phase A run one after the other on this GPU and the exchange is a device
+    copy -- a parity check of the sharded path (and its per-phase cost) on a one-GPU box, not a scaling number."""
+    from ethereum_consensus_amd import synthetic as S
+    import numpy as np
+    n = args.validators
+    dev = _device(torch)
+    enc = S.beacon_state_deneb(n, "mainnet", seed=1)  # the same state on every rank
+    fork = 4
+    fixed = int(L.ecgpu_beacon_state_fixed_size(fork, 0))
+    h_fixed = ctypes.create_string_buffer(enc[:fixed], fixed)
+    d_state = torch.from_numpy(np.frombuffer(enc, dtype=np.uint8).copy()).to(dev)
+    nl = int(L.ecgpu_beacon_state_shard_lists())
+    w_eff = emulate_world or world
+    d_sub = torch.zeros(32 * nl, dtype=torch.uint8, device=dev)
+    d_all = torch.zeros(32 * nl * w_eff, dtype=torch.uint8, device=dev)
+    d_root = torch.zeros(32, dtype=torch.uint8, device=dev)
+    d_ref = torch.zeros(32, dtype=torch.uint8, device=dev)
+    stream = _stream(torch)
+
+    def chk(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} -> {rc}: {L.ecgpu_last_error()}")
+
+    chk(L.ecgpu_htr_beacon_state_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, d_ref.data_ptr(), stream), "ecgpu_htr_beacon_state_dev")
+    _sync(torch)
+    hashes_unsharded = int(L.ecgpu_last_hash64_count())
+    hashes = {"a": 0, "b": 0}
+
+    def step():
+        if emulate_world:
+            for r in range(emulate_world):
+                chk(L.ecgpu_beacon_state_shard_subroots_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, r, emulate_world,
+                                                            d_all.data_ptr() + 32 * nl * r, stream), "ecgpu_beacon_state_shard_subroots_dev")
+            gathered = d_all
+        else:
+            chk(L.ecgpu_beacon_state_shard_subroots_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, rank, world, d_sub.data_ptr(), stream),
+                "ecgpu_beacon_state_shard_subroots_dev")
+            hashes["a"] = int(L.ecgpu_last_hash64_count())
+            # the path's only collective: 160 bytes per rank
+            from ethereum_consensus_amd import shard
+            gathered = shard.all_gather_bytes(dist, d_sub, world, force=FORCE_DIST) if _multi(dist, world) else d_sub
+        chk(L.ecgpu_htr_beacon_state_sharded_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, gathered.data_ptr(), w_eff, d_root.data_ptr(), stream),
+            "ecgpu_htr_beacon_state_sharded_dev")
+        hashes["b"] = int(L.ecgpu_last_hash64_count())
+        return gathered
+
+    for _ in range(max(args.warmup, 1)):
+        keep = step()
+    _sync(torch)
+    if _multi(dist, world):
+        dist.barrier()
+    _sync(torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keep = step()
+    _sync(torch)
+    if _multi(dist, world):
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    del keep
+    root = bytes(d_root.cpu().numpy())
+    ref = bytes(d_ref.cpu().numpy())
+    same = root == ref
+    return dict(
+        dt=dt, units_per_step=hashes_unsharded / world, metric="merkle_leaves_hashed_per_sec", unit="leaves/s", dtype="u32", scaling="strong",
+        config={"workload": f"hash_tree_root(BeaconState) deneb mainnet, {n} validators: ONE state over {w_eff} "
+                            f"{'emulated ranks on one GPU' if emulate_world else 'rank(s)'}, SSZ-encoded state ({len(enc)} B) resident in HBM",
+                "hash64_per_state": hashes_unsharded, "hash64_this_rank_phase_a": hashes["a"], "hash64_every_rank_phase_b": hashes["b"],
+                "state_bytes": len(enc),
+                "sharding": "the five registry-sized lists (validators, balances, 2 x participation, inactivity_scores) as aligned "
+                            "power-of-two subtrees per rank; all-gather of 5 x 32 bytes per rank; the list tops, the other fields and "
+                            "the root redundantly on every rank"},
+        roofline={"bound": "hbm", "kernel": "k_merkle_pass<2, ValidatorLeaves>", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": None, "traffic": None, "note": "latency-bound at N > 1: see the N = 1 `merkle` record for the pass kernel's roofline"},
+        check={"root": root.hex(), "equals_unsharded_root": same},
     )
 
 
@@ -334,23 +479,24 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
                                                          d_st.data_ptr(), stream)
             if rc != 0:
                 raise RuntimeError(f"ecgpu_fast_aggregate_verify_batch_dev -> {rc}: {L.ecgpu_last_error()}")
-        if world > 1:
+        if _multi(dist, world):
             # the path's only collective: every rank learns every shard's verify statuses
-            gathered["st"] = shard.all_gather_ragged(dist, d_st[:n], total, world) if strong else shard.all_gather_bytes(dist, d_st, world)
+            gathered["st"] = (shard.all_gather_ragged(dist, d_st[:n], total, world, force=FORCE_DIST) if strong
+                              else shard.all_gather_bytes(dist, d_st, world, force=FORCE_DIST))
 
     for _ in range(max(args.warmup, 1)):
         step()
     _sync(torch)
     L.ecgpu_prof_filter(None)
     L.ecgpu_prof_enable(1)
-    if world > 1:
+    if _multi(dist, world):
         dist.barrier()
     _sync(torch)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     _sync(torch)
-    if world > 1:
+    if _multi(dist, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     build = int(L.ecgpu_bls_tower())
@@ -370,7 +516,7 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
     import numpy as np
     want = np.frombuffer(bytes(want_bytes), dtype=np.uint8)
     ok = bool((st == want).all())
-    if world > 1 and strong:
+    if _multi(dist, world) and strong:
         # every rank holds the whole job's statuses after the gather: its own shard sits where shard_range puts it
         full = gathered["st"].cpu().numpy()
         ok = ok and full.shape[0] == total and bool((full[lo:hi] == want).all())
@@ -405,7 +551,10 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
                   "algorithmic_bytes_per_launch": alg_bytes,
                   "avg_launch_ms": kern_ms, "stage_ms": stages,
                   "valu_int": {"unit": "T multiplies/s (v_mad_u64_u32 + v_mul_lo_u32)", "peak": MUL_PIPE_PEAK_TOPS,
+                               "one_wave_ceiling": MUL_PIPE_ONE_WAVE_TOPS, "two_waves_ceiling": MUL_PIPE_TWO_WAVES_TOPS,
+                               "peak_source": "profiles/r02p_issue_rates.txt: v_mad_u64_u32 at 8 / 2 / 1 waves per SIMD",
                                "achieved": {k: (mul_ops[k] / (stages[k] * 1e-3) / 1e12 if stages[k] > 0 else 0.0) for k in stages},
+                               "frac": {k: (mul_ops[k] / (stages[k] * 1e-3) / 1e12 / MUL_PIPE_PEAK_TOPS if stages[k] > 0 else 0.0) for k in stages},
                                "multiplies_per_signature": mults_per_sig,
                                "note": f"the path is integer-multiplier bound, not HBM bound: {mults_per_sig / 1e6:.1f} M multiplies vs 177 B per "
                                        "signature (census of the kernel build that ran)"}},
@@ -825,7 +974,7 @@ def _prof(L, tag):
 def finish(r, args, world, dist, torch):
     """max-over-ranks wall time of the K timed steps -> the fields of one metric"""
     dt = r["dt"]
-    if world > 1:
+    if _multi(dist, world):
         t = torch.tensor([dt], dtype=torch.float64, device=DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -842,7 +991,7 @@ def finish(r, args, world, dist, torch):
 def gather_selfcheck(mine, world, dist, torch):
     """every rank's (large-code slowdown, pairing build): with N > 1 the slowest rank sets the step time, so the line carries all"""
     per_rank = [mine]
-    if world > 1:
+    if _multi(dist, world):
         try:
             t = torch.tensor(mine, dtype=torch.float64, device=DEV)
             parts = [torch.empty_like(t) for _ in range(world)]
@@ -851,6 +1000,29 @@ def gather_selfcheck(mine, world, dist, torch):
         except Exception:  # noqa: BLE001 - a failed diagnostic must not cost the measurement
             per_rank = [mine]
     return per_rank
+
+
+def multi_gpu_preflight(L, torch, dist, rank, world, local):
+    """What fails first on a real N-GPU node, checked before anything is timed (tools/multi_gpu_preflight.py runs the same):
+    torch and the library are bound to the SAME device (LOCAL_RANK), a kernel of the library runs there, and a 1-byte
+    all_gather_into_tensor on device tensors goes through RCCL and returns every rank's byte in rank order."""
+    out = {"rank": rank, "world": world, "local_rank": local}
+    cur = torch.cuda.current_device()
+    lib_dev = int(L.ecgpu_thread_device())
+    out["torch_device"], out["library_device"] = cur, lib_dev
+    if cur != local or lib_dev != local:
+        raise RuntimeError(f"rank {rank}: torch is on device {cur}, the library on {lib_dev}, LOCAL_RANK is {local}")
+    probe = ctypes.create_string_buffer(32)
+    if L.ecgpu_sha256(b"preflight", 9, probe) != 0:
+        raise RuntimeError(f"rank {rank}: the library's first kernel failed: {L.ecgpu_last_error()}")
+    mine = torch.tensor([rank + 1], dtype=torch.uint8, device=DEV if DEV == "cpu" else torch.device("cuda", local))
+    from ethereum_consensus_amd import shard
+    got = shard.all_gather_bytes(dist, mine, world, force=True).cpu().tolist()
+    if got != [r + 1 for r in range(world)]:
+        raise RuntimeError(f"rank {rank}: 1-byte all-gather returned {got}")
+    out["all_gather_1_byte"] = "ok"
+    out["backend"] = dist.get_backend()
+    return out
 
 
 def sub_record(line, keys=("metric", "value", "unit", "ms_per_step", "steps", "scaling", "dtype", "config", "roofline", "check")):
@@ -872,15 +1044,17 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
     from ethereum_consensus_amd import _lib
     L = _lib.load(build_if_missing=False)
     rc = L.ecgpu_init(local)
     if rc != 0:
         raise RuntimeError(f"ecgpu_init -> {rc}: {L.ecgpu_last_error()}")
+    preflight = multi_gpu_preflight(L, torch, dist, rank, world, local) if dist is not None else None
     workload = args.workload
     if workload == "auto":
         workload = "both"
@@ -904,7 +1078,12 @@ def main():
             line["msm"] = run_msm(args, L, torch)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_bls(r_bls["host_sample"])
-    if workload in ("merkle", "both"):
+    if workload == "merkle" and args.scaling == "strong":
+        r = run_merkle_sharded(args, L, torch, dist, rank, world)
+        if not r["check"]["equals_unsharded_root"]:
+            raise RuntimeError("sharded state root differs from the unsharded root")
+        line = finish(r, args, world, dist, torch)
+    elif workload in ("merkle", "both"):
         r = run_merkle(args, L, torch, dist, rank, world)
         r["check"] = {"root": r.get("root")}
         m = finish(r, args, world, dist, torch)
@@ -914,17 +1093,34 @@ def main():
             line = m
         else:
             line["merkle"] = {k: m[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline",
-                                                "check", "cpu_baseline") if k in m}
+                                                "check", "cpu_baseline", "h2d_inclusive") if k in m}
     # The default line (N = 1, both halves, default sizes) also carries the other configurations of BASELINE.json, each a few
     # seconds of GPU time, each with its own check: north_star's 2^20-signature K = 1 batch in ONE call ("strong_2p20": the
     # N = 1 point of `--tuples 1048576 --scaling strong`), configs[3] ("epoch": all 2 048 aggregates of 2 048 keys) and
     # configs[4] ("slots": 64 slots of sync aggregate + state root).
-    if workload == "both" and world == 1 and not args.no_extras and args.tuples == 65536 and args.scaling == "weak":
+    if workload == "both" and not args.no_extras and args.tuples == 65536 and args.scaling == "weak":
         import copy
         a2 = copy.copy(args)
         a2.steps, a2.warmup = 2, 1
-        line["strong_2p20"] = sub_record(finish(run_bls(a2, L, torch, dist, rank, world, n_total=1 << 20, strong=True), a2, world, dist, torch))
-        line["strong_2p20"]["vs_16x_65536_step"] = line["strong_2p20"]["ms_per_step"] / (16 * line["ms_per_step"])
+        # north_star's two strong-scaled points ride in every line, N = 1 and N > 1 alike: the 2^20-signature batch over the
+        # N ranks, and ONE 2^20-validator state over the N ranks (at N = 1 the fused single-GPU root above IS that point; the
+        # sharded code path then runs as an 8-rank emulation on the one GPU, root asserted equal)
+        sp = sub_record(finish(run_bls(a2, L, torch, dist, rank, world, n_total=1 << 20, strong=True), a2, world, dist, torch))
+        if line is not None:
+            line["strong_2p20"] = sp
+            if world == 1:
+                line["strong_2p20"]["vs_16x_65536_step"] = line["strong_2p20"]["ms_per_step"] / (16 * line["ms_per_step"])
+        am = copy.copy(args)
+        am.steps, am.warmup = (args.steps, args.warmup) if world > 1 else (5, 1)
+        rm = run_merkle_sharded(am, L, torch, dist, rank, world, emulate_world=8 if world == 1 else None)
+        ms_rec = sub_record(finish(rm, am, world, dist, torch))
+        if world == 1:
+            ms_rec["note"] = ("8 ranks emulated one after the other on one GPU: a parity check of the sharded path, not a scaling "
+                              "point (value = the whole state's leaves over the time of all 8 phase A + one phase B)")
+        if line is not None:
+            line["merkle_strong" if world > 1 else "merkle_sharded_emulated"] = ms_rec
+    if workload == "both" and world == 1 and not args.no_extras and args.tuples == 65536 and args.scaling == "weak":
+        import copy
         a3 = copy.copy(args)
         a3.steps, a3.warmup = 2, 1
         line["epoch"] = sub_record(finish(run_epoch(a3, L, torch, dist, rank, world), a3, world, dist, torch))
@@ -941,6 +1137,8 @@ def main():
     mine = [sweep[3] / sweep[0] if ok else 0.0, float(L.ecgpu_bls_tower())]
     per_rank = gather_selfcheck(mine, world, dist, torch)
     if rank == 0:
+        if preflight is not None:
+            line["preflight"] = preflight
         names = {1: "sums of products", 2: "compact-code tower"}
         if ok:
             line["box_selfcheck"] = {"mad_loop_8KB_ms": sweep[0], "mad_loop_64KB_ms": sweep[1], "mad_loop_256KB_ms": sweep[2],

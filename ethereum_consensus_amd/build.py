@@ -70,6 +70,36 @@ def _deps(src: str, seen=None):
     return seen
 
 
+def source_hash(src: str) -> str:
+    """sha256 over the contents of `src` and of every file it includes (transitively) plus the compiler flags: the identity of
+    the kernels of one translation unit.  Recorded per object in lib/build_manifest.json when the object is built; bench.py
+    only quotes a PMC pass (profiles/pmc_traffic.json) whose recorded hash equals the manifest's, i.e. that was taken on the
+    very kernels that are loaded."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS[:5] + FLAGS[7:9]).encode())
+    for f in sorted(_deps(src)):
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(hashlib.sha256(fh.read()).digest())
+    return h.hexdigest()[:16]
+
+
+MANIFEST = os.path.join(LIBDIR, "build_manifest.json")
+
+
+def _write_manifest(entries: dict, path: str = MANIFEST):
+    import json
+    try:
+        with open(path) as f:
+            cur = json.load(f)
+    except (OSError, ValueError):
+        cur = {}
+    cur.update(entries)
+    with open(path + ".tmp", "w") as f:
+        json.dump(cur, f, indent=1, sort_keys=True)
+    os.replace(path + ".tmp", path)
+
+
 def _run(cmd):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -109,17 +139,23 @@ def build_lib(verbose: bool = True) -> str:
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     jobs = []
     objs = []
+    built = {}
     for f in srcs:
         src = os.path.join(CSRC, f)
         obj = os.path.join(OBJDIR, f[:-4] + ".o")
         objs.append(obj)
         if _newer(obj, sorted(_deps(src)) + [os.path.abspath(__file__)]):
             jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            built[f] = source_hash(src)
     if jobs:
         if verbose:
             print(f"[ecgpu build] compiling {len(jobs)} object(s) for {ARCH}", flush=True)
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(_run, jobs))
+    if not os.path.exists(MANIFEST):  # objects of an older build: they are up to date, so their sources are the present ones
+        built = {f: source_hash(os.path.join(CSRC, f)) for f in srcs}
+    if built:
+        _write_manifest(built)
     if jobs or _newer(LIB, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
         if verbose:

@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_scalar_mul(Aff<F>*
 // Work per term: W mixed additions (32 for 255-bit scalars) instead of ~255 doublings + ~128 additions; the fixed cost is
 // 8 160 bucket workgroups + ~250 dependent doublings, which is why short inputs keep the lane-per-term form.
 constexpr u32 MSM_BUCKET_MIN = 4096;
+constexpr u32 MSM_MAX_TERMS = 0xffffffffu / 32;  // items = n * n_win (n_win <= 32) is a u32 in the sort kernels
 constexpr u32 MSM_C = 8, MSM_NB = 256;
 static size_t msm_ws_bytes(u32 n, size_t jac_bytes) {
     return n >= MSM_BUCKET_MIN ? (size_t)32 * n * 4 + 32 * MSM_NB * (12 + jac_bytes) + 32 * jac_bytes + 4096 : 0;
@@ -864,6 +865,10 @@ int ecgpu_aggregate_pks(const uint8_t* pks48, uint32_t n, uint8_t* out48) {
 int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uint32_t scalar_bits, uint8_t* out48) {
     if (n == 0) return ECGPU_EMPTY_AGGREGATE;
     if (!pks48 || !scalars32 || !out48 || scalar_bits == 0 || scalar_bits > 256) return ECGPU_ERR_BAD_ARG;
+    if (n > MSM_MAX_TERMS) {  // the counting sort indexes the (term, window) pairs with 32 bits: n * 32 windows must fit
+        set_last_error("multi-scalar multiplication: more than 2^27 - 1 terms");
+        return ECGPU_ERR_BAD_ARG;
+    }
     CallCtx k;
     int rc = begin_call(k, nullptr, (size_t)n * (48 + 32 + sizeof(A1) + 1) + sizeof(A1) + msm_ws_bytes(n, sizeof(J1)) + 8192);
     if (rc) return rc;
@@ -901,6 +906,10 @@ int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uin
 int ecgpu_g2_msm(const uint8_t* sigs96, const uint8_t* scalars32, uint32_t n, uint32_t scalar_bits, uint8_t* out96) {
     if (n == 0) return ECGPU_EMPTY_AGGREGATE;
     if (!sigs96 || !scalars32 || !out96 || scalar_bits == 0 || scalar_bits > 256) return ECGPU_ERR_BAD_ARG;
+    if (n > MSM_MAX_TERMS) {  // the counting sort indexes the (term, window) pairs with 32 bits: n * 32 windows must fit
+        set_last_error("multi-scalar multiplication: more than 2^27 - 1 terms");
+        return ECGPU_ERR_BAD_ARG;
+    }
     CallCtx k;
     int rc = begin_call(k, nullptr, (size_t)n * (96 + 32 + sizeof(A2) + 2) + sizeof(A2) + msm_ws_bytes(n, sizeof(J2)) + 8192);
     if (rc) return rc;

@@ -5,6 +5,10 @@
 namespace ecg {
 
 constexpr int BLS_BLOCK = 64;  // one wave per workgroup: spreads small batches over every CU
+#if defined(ECG_LANE_SLOT_BLOCK)
+// the LDS lane slots of bls_pairing.h are indexed by threadIdx.x & 63: a workgroup of the pairing kernels must be one wave
+static_assert(BLS_BLOCK == ECG_LANE_SLOT_BLOCK, "the pairing kernels' lane slots assume one wave per workgroup");
+#endif
 #ifndef ECG_BLS_WAVES
 #define ECG_BLS_WAVES 1  // waves per SIMD the register allocator must leave room for: 1 = the whole 512-entry VGPR+AGPR file.
                          // These lane kernels hold hundreds of live field-element limbs, so registers beat occupancy

@@ -29,7 +29,11 @@ constexpr int LANE_SLOTS = 12;
 // that pass through one in tuples for their whole life, and a tuple can only be spilled and reloaded whole -- the first
 // version of the slots had four limbs of the Miller accumulator reloaded from the private segment in front of over a hundred
 // single-limb uses per line product.  (13 LDS instructions per field element instead of 4: +0.5 % instructions.)
-static __shared__ u32 g_lane_slots[13 * LANE_SLOTS * 64];
+// INVARIANT: a slot is indexed by threadIdx.x & 63, so a workgroup that reaches miller_loop / fp12_cyc_pow_x / fp12_mul_slots
+// must be ONE wave (two waves of a 128-thread block would share slots and silently corrupt each other's pairings).  Every
+// kernel that includes this header launches with ECG_LANE_SLOT_BLOCK threads; bls_kernels.h asserts BLS_BLOCK equals it.
+#define ECG_LANE_SLOT_BLOCK 64
+static __shared__ u32 g_lane_slots[13 * LANE_SLOTS * ECG_LANE_SLOT_BLOCK];
 // explicit LDS pointer: a volatile access through a generic pointer compiles to flat_load / flat_store
 typedef __attribute__((address_space(3))) volatile u32* lane_slot_ptr;
 ECG_D Fp slot_load(int s) {

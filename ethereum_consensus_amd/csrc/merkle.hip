@@ -216,11 +216,14 @@ __device__ __forceinline__ bool tail_last_arrival(u32* counter, u32 parties) {
 }
 // the gathered chunks among the `n` chunks at byte offset `off` of the job buffer, fetched by the workgroup about to hash them
 __device__ __forceinline__ void tail_gather(const TailPlan& P, u8* buf, u64 off, u32 n) {
-    if (off < P.small_off) return;  // a finishing job's inputs are nodes of a workspace
+    // a finishing job's inputs are nodes of a workspace, which lies on EITHER side of the small-chunk buffer (the state driver
+    // takes its upload block from the arena first, the workspaces after it)
+    if (off < P.small_off || off >= P.small_end) return;
     const u64 c0 = (off - P.small_off) >> 5;
     for (u32 i = threadIdx.x; i < P.n_gathers; i += blockDim.x) {
         const GatherDesc g = P.gathers[i];
-        if (g.dst_chunk >= c0 && g.dst_chunk < c0 + n) gather_chunk(P.src, P.src_total, g, buf + P.small_off);
+        if (g.dst_chunk >= c0 && g.dst_chunk < c0 + n)
+            gather_chunk(g.src_sel ? P.ext_src : P.src, g.src_sel ? P.ext_total : P.src_total, g, buf + P.small_off);
     }
     __syncthreads();
 }
@@ -279,6 +282,7 @@ __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u
         bad = w[0] != P.chk_expect;
     }
     if (t < 8) reinterpret_cast<u32*>(P.d_root)[t] = bad ? 0xffffffffu : reinterpret_cast<const u32*>(buf + P.root_off)[t];
+    if (t == 0 && P.d_status) *P.d_status = bad ? ECGPU_ERR_BAD_ARG : ECGPU_SUCCESS;
     if (P.d_field_roots) reinterpret_cast<u32*>(P.d_field_roots)[t] = reinterpret_cast<const u32*>(buf + P.froots_off)[t];  // 32 x 32 B = 256 dwords
     TAIL_TRACE_SET(5);
 }

@@ -88,7 +88,11 @@ struct TailPlan {
     const GatherDesc* gathers;
     u32 n_gathers, chk_expect;
     u64 small_off;                      // byte offset of the small-chunk buffer (GatherDesc::dst_chunk counts from there)
+    u64 small_end;                      // ... and of its end: only jobs whose inputs lie in [small_off, small_end) have gathered chunks
     u64 chk_off;                        // != ~0: the little-endian u32 at src + chk_off must equal chk_expect, else the root is 32 x 0xFF
+    const u8* ext_src;                  // gathers with src_sel == 1 read here (ext_total bytes): nodes computed elsewhere
+    u64 ext_total;
+    int* d_status;                      // may be null: 0 / ECGPU_ERR_BAD_ARG next to the root, see ecgpu_htr_beacon_state_dev_checked
 };
 int launch_state_tail(hipStream_t s, const TailPlan* d_plan, u32 n_wgs, u8* d_buf);
 

@@ -80,6 +80,7 @@ struct ThreadCtx {
     PinnedBuf staging;      // host-pinned staging for small H2D/D2H payloads
     UploadRing uploads;
     u64 last_hash64 = 0;
+    u8* small_scratch = nullptr;  // 2 KB of device memory outside the arenas (a block that must outlive an arena reset)
     hipStream_t stream_or_own(ecgpu_stream_t s);
     Arena& arena(hipStream_t s) { return arenas[s]; }
     void release();  // synchronize and free every stream, event, arena and pinned buffer (thread exit)

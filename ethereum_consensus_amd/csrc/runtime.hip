@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <thread>
 
 namespace ecg {
@@ -94,15 +95,17 @@ int ensure_init() {
 // per (host thread, device): streams and arenas are device objects.  The holder's destructor runs when the thread exits
 // (for the main thread: before static destructors, i.e. while the HIP runtime is still up) and gives everything back.
 void ThreadCtx::release() {
-    if (own_stream) (void)hipStreamSynchronize(own_stream);
-    if (aux.ready)
-        for (int i = 0; i < N_AUX_STREAMS; i++) (void)hipStreamSynchronize(aux.st[i]);
+    // The arenas are keyed by the stream they were used on, and some of those streams are the CALLER's: they may have been
+    // destroyed long ago, so their handles are not touched here.  One device-wide synchronisation covers every stream that
+    // could still be reading an arena (this runs once per thread, at its exit).
+    bool any = own_stream != nullptr || aux.ready || small_scratch != nullptr;
+    for (auto& kv : arenas) any = any || kv.second.base != nullptr;
+    if (any) (void)hipDeviceSynchronize();
     for (auto& kv : arenas)
-        if (kv.second.base) {
-            if (kv.first && kv.first != own_stream) (void)hipStreamSynchronize(kv.first);  // a caller's stream this thread used
-            (void)hipFree(kv.second.base);
-        }
+        if (kv.second.base) (void)hipFree(kv.second.base);
     arenas.clear();
+    if (small_scratch) (void)hipFree(small_scratch);
+    small_scratch = nullptr;
     if (staging.p) (void)hipHostFree(staging.p);
     staging = PinnedBuf();
     uploads.release();
@@ -163,9 +166,11 @@ DeviceWorker* worker_of(int device) {
     std::lock_guard<std::mutex> lk(g_workers_mu);
     DeviceWorker*& w = g_workers[device];
     if (!w) {
-        w = new DeviceWorker();
-        w->th = std::thread([w, device] { w->loop(device); });
-        w->th.detach();
+        std::unique_ptr<DeviceWorker> fresh(new DeviceWorker());
+        DeviceWorker* raw = fresh.get();
+        fresh->th = std::thread([raw, device] { raw->loop(device); });  // may throw: the slot stays empty then
+        fresh->th.detach();
+        w = fresh.release();
     }
     return w;
 }
@@ -182,25 +187,45 @@ int run_on_devices(const int* devices, unsigned n, const std::function<int(unsig
             set_last_error("device index out of range");
             return ECGPU_ERR_BAD_ARG;
         }
-    std::mutex done_mu;
-    std::condition_variable done_cv;
-    unsigned done = 0;
+    // Every worker exists before the first job is queued (creating one may throw: nothing may be in flight then), and the
+    // completion state is owned jointly by the jobs and this frame, so a job never refers to a frame that has been unwound.
+    std::vector<DeviceWorker*> workers(n, nullptr);
+    try {
+        for (unsigned g = 0; g < n; g++) workers[g] = worker_of(devices[g]);
+    } catch (const std::exception& e) {
+        set_last_error(std::string("could not start a device worker: ") + e.what());
+        return ECGPU_ERR_HIP;
+    }
+    struct Completion {
+        std::mutex mu;
+        std::condition_variable cv;
+        unsigned done = 0;
+        std::vector<int> rcs;
+        std::vector<std::string> errs;
+    };
+    auto st = std::make_shared<Completion>();
+    st->rcs.assign(n, 0);
+    st->errs.assign(n, std::string());
+    const std::function<int(unsigned)>* pfn = &fn;  // outlives the wait below, which every job finishes before
     for (unsigned g = 0; g < n; g++) {
-        DeviceWorker* w = worker_of(devices[g]);
+        DeviceWorker* w = workers[g];
         std::lock_guard<std::mutex> lk(w->mu);
-        w->q.push_back([&, g] {
+        w->q.push_back([st, pfn, g] {
             int rc = ensure_init();  // the worker is bound to its device; this (re)selects it for the HIP runtime
-            if (!rc) rc = fn(g);
-            rcs[g] = rc;
-            if (rc) errs[g] = ecgpu_last_error();
-            std::lock_guard<std::mutex> dl(done_mu);
-            done++;
-            done_cv.notify_one();
+            if (!rc) rc = (*pfn)(g);
+            std::string err = rc ? ecgpu_last_error() : "";
+            std::lock_guard<std::mutex> dl(st->mu);
+            st->rcs[g] = rc;
+            st->errs[g] = err;
+            st->done++;
+            st->cv.notify_one();
         });
         w->cv.notify_one();
     }
-    std::unique_lock<std::mutex> lk(done_mu);
-    done_cv.wait(lk, [&] { return done == n; });
+    std::unique_lock<std::mutex> lk(st->mu);
+    st->cv.wait(lk, [&] { return st->done == n; });
+    rcs = st->rcs;
+    errs = st->errs;
     return ECGPU_SUCCESS;
 }
 
@@ -264,8 +289,15 @@ int UploadRing::acquire(size_t bytes, u8** slot, hipEvent_t* ev) {
         release();
         const size_t want = (bytes + 4095) & ~(size_t)4095;
         ECG_HIP_CHECK(hipHostMalloc((void**)&p, want * UPLOAD_SLOTS, hipHostMallocDefault));
+        for (int i = 0; i < UPLOAD_SLOTS; i++) copied[i] = nullptr;
+        for (int i = 0; i < UPLOAD_SLOTS; i++)
+            if (hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess) {
+                copied[i] = nullptr;
+                release();  // a half-built ring would fail every later call at hipEventSynchronize(nullptr)
+                set_last_error("hipEventCreate failed while building the upload ring");
+                return ECGPU_ERR_HIP;
+            }
         slot_bytes = want;
-        for (int i = 0; i < UPLOAD_SLOTS; i++) ECG_HIP_CHECK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
     } else {
         ECG_HIP_CHECK(hipEventSynchronize(copied[next]));  // never recorded: returns at once
     }
@@ -277,6 +309,7 @@ int UploadRing::acquire(size_t bytes, u8** slot, hipEvent_t* ev) {
 void UploadRing::release() {
     if (!p) return;
     for (int i = 0; i < UPLOAD_SLOTS; i++) {
+        if (!copied[i]) continue;
         (void)hipEventSynchronize(copied[i]);
         (void)hipEventDestroy(copied[i]);
         copied[i] = nullptr;
@@ -339,13 +372,18 @@ int ecgpu_bind_thread(int device) {
     return ensure_init();
 }
 
+int ecgpu_thread_device(void) {
+    if (g_init_state.load() != 1) return ECGPU_ERR_NO_DEVICE;
+    return current_device();
+}
+
 int ecgpu_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
 
-const char* ecgpu_version(void) { return "ecgpu 0.1 (gfx950)"; }
+const char* ecgpu_version(void) { return "ecgpu 0.4 (gfx950)"; }
 
 const char* ecgpu_last_error(void) { return t_last_error.c_str(); }
 

@@ -16,15 +16,131 @@
 
 namespace ecg {
 
+// ---- one BeaconState over several GPUs (BASELINE north_star: "2^20-validator batch at 1, 2, 4 and 8 GPUs") ----
+// The five registry-sized lists (validators, balances, the two participation lists, inactivity_scores: 99.2 % of a mainnet
+// state's hash64) are cut into aligned power-of-two subtrees, one per rank; everything else (the 8 192-entry root vectors,
+// randao mixes, sync committees, the small containers: 0.8 %) is computed redundantly by every rank.
+//   phase A (ecgpu_beacon_state_shard_subroots_dev): rank g reduces ITS subtree of each of the five lists -> 5 nodes;
+//   exchange: one all-gather of 5 x 32 bytes per rank (the caller's: RCCL in bench.py, host memory in a threaded host);
+//   phase B (ecgpu_htr_beacon_state_sharded_dev): every rank finishes the five lists from the gathered nodes (they enter at
+//   level log2(width): one finishing job each, zero ladder to the list limit, length mix-in) and computes the rest of the
+//   state and the root -- one fused tail launch, the five jobs riding in it.
+constexpr u32 N_SHARDED_LISTS = 5;
+static int sharded_list_index(const BigField& b) {  // position among the five, or -1
+    switch (b.out_chunk) {
+        case 11: return b.kind == LEAF_VALIDATORS ? 0 : -1;
+        case 12: return 1;
+        case 15: return 2;
+        case 16: return 3;
+        case 21: return 4;
+        default: return -1;
+    }
+}
+// leaves per rank: the smallest power of two W with W * world >= n0 (ethereum_consensus_amd/shard.py subtree_width)
+static u64 shard_width(u64 n0, u32 world) {
+    const u64 per = n0 ? (n0 + world - 1) / world : 1;
+    return 1ull << ceil_log2_u64(per);
+}
+struct ShardTop {
+    const u8* d_all;  // world x 5 x 32 bytes, rank-major: what the all-gather of the phase-A outputs leaves on every rank
+    u32 world;
+};
+
+static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, StatePlan& plan, int fork, bool dev_check,
+                          u8* d_root, const u8* d_vroots, const u8* ext_roots, u8* d_field_roots, int* d_status, const u8* ext_src,
+                          u64 ext_total);
+
 // d_vroots != nullptr (resident state): the 32-byte hash_tree_root of every validator record is cached there and kept
 // current by the caller, so the registry enters the tree as a list of 2^20 ready chunks (1.0 M hash64) instead of 121-byte
 // records (9.4 M).
 static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, const u8* h_fixed,
                              int preset, u8* d_root, const u8* d_vroots = nullptr, int fork = FORK_DENEB, const u8* ext_roots = nullptr,
-                             const u8* h_payload_fixed = nullptr, u8* d_field_roots = nullptr) {
+                             const u8* h_payload_fixed = nullptr, u8* d_field_roots = nullptr, int* d_status = nullptr,
+                             const ShardTop* shard = nullptr) {
     StatePlan plan;
     if (!build_state_plan(fork, h_fixed, n_bytes, preset, plan, ext_roots, h_payload_fixed)) {
         set_last_error(plan.error);
+        return ECGPU_ERR_BAD_ARG;
+    }
+    if (shard) {
+        // phase B: the five lists leave the plan; their sub-roots are gathered from the caller's buffer by the finishing job
+        // that climbs them to the list limit
+        std::vector<BigField> keep;
+        for (const BigField& b : plan.bigs) {
+            const int f = sharded_list_index(b);
+            if (f < 0) {
+                keep.push_back(b);
+                continue;
+            }
+            const u64 W = shard_width(b.n0, shard->world);
+            const u32 n_sub = (u32)((b.n0 + W - 1) / W);
+            const u32 c0 = plan.n_small_chunks;
+            plan.n_small_chunks += n_sub ? n_sub : 1;
+            for (u32 r = 0; r < n_sub; r++) plan.gathers.push_back({32ull * (N_SHARDED_LISTS * r + (u32)f), 32u, c0 + r, 0u, 1u});
+            TreeJob j;
+            j.in_off = 32ull * c0;
+            j.out_off = 32ull * b.out_chunk;
+            j.n = n_sub;
+            j.level = ceil_log2_u64(W);
+            j.depth = b.depth;
+            j.mix = b.mix ? 1 : 0;
+            j.mix_len = b.mix_len;
+            plan.jobs[0].push_back(j);
+            u64 cnt = n_sub, l = j.level;
+            while (cnt > 1) {
+                cnt = (cnt + 1) / 2;
+                plan.small_hashes += cnt;
+                l++;
+            }
+            if (n_sub) plan.small_hashes += b.depth - l;
+            if (b.mix) plan.small_hashes++;
+        }
+        plan.bigs.swap(keep);
+    }
+    const bool dev_check = fork >= FORK_BELLATRIX && !h_payload_fixed && plan.payload_header_off != ~0ull;
+    return run_state_plan(s, c, d_ssz, n_bytes, plan, fork, dev_check, d_root, d_vroots, ext_roots, d_field_roots, d_status,
+                          shard ? shard->d_all : nullptr, shard ? 32ull * N_SHARDED_LISTS * shard->world : 0);
+}
+
+// phase A of a sharded state root: this rank's subtree of each of the five lists -> d_subroots[5 x 32]
+static int state_shard_subroots_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, const u8* h_fixed, int preset,
+                                       int fork, u32 rank, u32 world, u8* d_subroots) {
+    StatePlan full;
+    if (!build_state_plan(fork, h_fixed, n_bytes, preset, full, nullptr, nullptr)) {
+        set_last_error(full.error);
+        return ECGPU_ERR_BAD_ARG;
+    }
+    StatePlan plan;
+    for (const BigField& b : full.bigs) {
+        const int f = sharded_list_index(b);
+        if (f < 0) continue;
+        const u64 W = shard_width(b.n0, world), rec = leaf_record_bytes(b.kind);
+        const u64 lo = std::min<u64>((u64)rank * W, b.n0), hi = std::min<u64>(((u64)rank + 1) * W, b.n0);
+        const u64 lo_b = std::min<u64>(lo * rec, b.bytes), hi_b = std::min<u64>(hi * rec, b.bytes);  // a packed list's last chunk may be partial
+        plan.bigs.push_back({b.kind, b.src + lo_b, hi_b - lo_b, hi - lo, ceil_log2_u64(W), false, 0, (u32)f});
+    }
+    // the fused tail ends in a container job: here a 5-leaf tree over the sub-roots, whose root nobody reads
+    Builder B;
+    const u32 root_chunk = B.alloc(1);
+    B.job(2, 0, N_SHARDED_LISTS, 3, root_chunk);
+    plan.jobs[2] = B.jobs[2];
+    plan.n_small_chunks = B.next_chunk;
+    plan.root_chunk = root_chunk;
+    plan.small_hashes = B.hashes;
+    // chunks 0 .. 31 of the small buffer are handed back whole (d_field_roots); the first five are the sub-roots
+    if (!c->small_scratch) ECG_HIP_CHECK(hipMalloc((void**)&c->small_scratch, 2048));
+    u8* d_sc = c->small_scratch;  // 1 KB field-root block + the 32-byte root of the dummy container
+    int rc = run_state_plan(s, c, d_ssz, n_bytes, plan, fork, false, d_sc + 32 * 32, nullptr, nullptr, d_sc, nullptr, nullptr, 0);
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipMemcpyAsync(d_subroots, d_sc, 32 * N_SHARDED_LISTS, hipMemcpyDeviceToDevice, s));
+    return ECGPU_SUCCESS;
+}
+
+static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, StatePlan& plan, int fork, bool dev_check,
+                          u8* d_root, const u8* d_vroots, const u8* ext_roots, u8* d_field_roots, int* d_status, const u8* ext_src,
+                          u64 ext_total) {
+    if (plan.bigs.empty()) {
+        set_last_error("state plan without a big field");
         return ECGPU_ERR_BAD_ARG;
     }
     std::vector<const u8*> fptr(plan.bigs.size());
@@ -63,8 +179,7 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     GatherDesc* d_gath = (GatherDesc*)(d_block + off_gath);
     u8* d_small = d_block + off_small;
     // The device entry never sees the payload header on the host: the extra_data offset word the host entries check
-    // (state_plan.h) is compared on the device, and a mismatch poisons the root (32 x 0xFF; include/ecgpu.h).
-    const bool dev_check = fork >= FORK_BELLATRIX && !h_payload_fixed && plan.payload_header_off != ~0ull;
+    // (state_plan.h) is compared on the device (dev_check), and a mismatch poisons the root (32 x 0xFF) and sets *d_status.
     u64 hc = plan.small_hashes;
     // Schedule (round 3): ONE stream.  The plan first (every tree is DESCRIBED here and launched further down), then the wide
     // passes -- the validator registry, 93 % of the hashes, and whatever other field is too wide for a tile stage --, then ONE launch for everything that is left: the tile stages of all fields, their
@@ -168,8 +283,12 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
     tp.gathers = d_gath;
     tp.n_gathers = (u32)plan.gathers.size();
     tp.small_off = small_off;
+    tp.small_end = small_off + small_bytes;
     tp.chk_off = dev_check ? plan.payload_header_off + PAYLOAD_EXTRA_DATA_OFFSET_WORD : ~0ull;
     tp.chk_expect = (u32)payload_header_fixed(fork);
+    tp.ext_src = ext_src;
+    tp.ext_total = ext_total;
+    tp.d_status = d_status;
     // the block: plan, zero tickets, descriptors, zero chunks (+ phase0: the two list roots the generic planner computed)
     u8* h_block;
     hipEvent_t copied;
@@ -570,6 +689,41 @@ int ecgpu_htr_beacon_state_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes,
     hipStream_t s = c->stream_or_own(stream);
     return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork);
 }
+
+int ecgpu_htr_beacon_state_dev_checked(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
+                                       uint8_t* d_root, int32_t* d_status, ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!d_ssz || !h_fixed || !d_root || !d_status || fork < FORK_ALTAIR || fork > FORK_DENEB) return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(stream);
+    return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork, nullptr, nullptr, nullptr, (int*)d_status);
+}
+
+int ecgpu_beacon_state_shard_subroots_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
+                                          uint32_t rank, uint32_t world, uint8_t* d_subroots, ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!d_ssz || !h_fixed || !d_subroots || fork < FORK_ALTAIR || fork > FORK_DENEB || !world || world > 512 || rank >= world)
+        return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(stream);
+    return state_shard_subroots_device(s, c, d_ssz, n_bytes, h_fixed, preset, fork, rank, world, d_subroots);
+}
+
+int ecgpu_htr_beacon_state_sharded_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
+                                       const uint8_t* d_all_subroots, uint32_t world, uint8_t* d_root, ecgpu_stream_t stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!d_ssz || !h_fixed || !d_all_subroots || !d_root || fork < FORK_ALTAIR || fork > FORK_DENEB || !world || world > 512)
+        return ECGPU_ERR_BAD_ARG;
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(stream);
+    const ShardTop top{d_all_subroots, world};
+    return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork, nullptr, nullptr, nullptr, nullptr, &top);
+}
+
+uint32_t ecgpu_beacon_state_shard_lists(void) { return N_SHARDED_LISTS; }
 
 // List<PendingAttestation<MAX_VALIDATORS_PER_COMMITTEE>, MAX_ATTESTATIONS * SLOTS_PER_EPOCH> (phase0/operations.rs:45-52,
 // phase0/presets/*.rs:84) for the generic planner

@@ -11,10 +11,11 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_bytes(dist, local, world: int):
-    """All-gather equally sized uint8 tensors; returns the concatenation in rank order."""
+def all_gather_bytes(dist, local, world: int, force: bool = False):
+    """All-gather equally sized uint8 tensors; returns the concatenation in rank order.  force: go through the collective even
+    with one rank (a single-rank process group is legal: the GPU tests exercise the RCCL call that way on a one-GPU box)."""
     import torch
-    if world == 1:
+    if world == 1 and not force:
         return local
     out = torch.empty(local.numel() * world, dtype=torch.uint8, device=local.device)
     if dist.get_backend() == "gloo":
@@ -25,15 +26,15 @@ def all_gather_bytes(dist, local, world: int):
     return out
 
 
-def all_gather_ragged(dist, local, n_total: int, world: int):
+def all_gather_ragged(dist, local, n_total: int, world: int, force: bool = False):
     """All-gather shards produced by shard_range (sizes differ by at most one): pad, gather, trim."""
     import torch
-    if world == 1:
+    if world == 1 and not force:
         return local
     width = (n_total + world - 1) // world
     padded = torch.zeros(width, dtype=torch.uint8, device=local.device)
     padded[:local.numel()] = local
-    g = all_gather_bytes(dist, padded, world)
+    g = all_gather_bytes(dist, padded, world, force)
     parts = []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)

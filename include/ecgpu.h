@@ -39,6 +39,9 @@ int ecgpu_device_count(void);
  * call of this thread runs there (tables, streams and workspaces exist per device; a registry / resident state / batch
  * belongs to the device of the thread that created it).  The *_multi entries below do this on threads of their own. */
 int ecgpu_bind_thread(int device);
+/* the device the calling thread's calls run on (ecgpu_init / ecgpu_bind_thread), or ECGPU_ERR_NO_DEVICE before ecgpu_init: a
+ * multi-process host checks it against its own LOCAL_RANK before the first collective (bench.py multi_gpu_preflight) */
+int ecgpu_thread_device(void);
 const char* ecgpu_version(void);
 const char* ecgpu_last_error(void); /* thread-local description of the last negative return */
 
@@ -121,6 +124,27 @@ int ecgpu_htr_beacon_state(int fork, const uint8_t* ssz, uint64_t n_bytes, int p
 int ecgpu_htr_beacon_state_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
                                uint8_t* d_root, ecgpu_stream_t stream);
 uint64_t ecgpu_beacon_state_fixed_size(int fork, int preset);
+/* ecgpu_htr_beacon_state_dev with the device-side check made visible: *d_status (device memory, written in stream order next
+ * to the root) = 0, or ECGPU_ERR_BAD_ARG when the payload header's extra_data offset word -- the one part of the encoding the
+ * host never sees -- is not what the reference's deserializer accepts.  The root is still poisoned (0xFF x 32) in that case. */
+int ecgpu_htr_beacon_state_dev_checked(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
+                                       uint8_t* d_root, int32_t* d_status, ecgpu_stream_t stream);
+
+/* ONE BeaconState over several GPUs (the reference's single call is `state.hash_tree_root()`,
+ * phase0/slot_processing.rs:67).  The five registry-sized lists -- validators, balances, previous / current epoch
+ * participation, inactivity_scores, 99 % of the hash64 -- are cut into aligned power-of-two subtrees, one per rank
+ * (width = the smallest power of two with width * world >= leaves); everything else is computed by every rank.
+ *   phase A  ecgpu_beacon_state_shard_subroots_dev: rank `rank` of `world` reduces its subtree of each list from the
+ *            device-resident encoding (only its own byte ranges of the five lists are read) -> d_subroots: 5 x 32 bytes;
+ *   exchange all-gather the 160 bytes over the ranks (rank-major: d_all[rank][list]) -- the path's only collective;
+ *   phase B  ecgpu_htr_beacon_state_sharded_dev: finishes the five lists from the gathered nodes (zero ladder to the list
+ *            limit, length mix-in), computes the remaining fields and the state root.  world == 1 gives the plain root.
+ * fork >= altair, like the other device-resident forms. */
+int ecgpu_beacon_state_shard_subroots_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
+                                          uint32_t rank, uint32_t world, uint8_t* d_subroots, ecgpu_stream_t stream);
+int ecgpu_htr_beacon_state_sharded_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
+                                       const uint8_t* d_all_subroots, uint32_t world, uint8_t* d_root, ecgpu_stream_t stream);
+uint32_t ecgpu_beacon_state_shard_lists(void); /* 5: nodes per rank in the exchange */
 /* number of hash64 the last state root of this thread performed (work accounting for benches) */
 uint64_t ecgpu_last_hash64_count(void);
 

@@ -52,6 +52,48 @@ def prepare(n: int, path: str, n_samples: int = 72) -> dict:
     return {"python_oracle_s": round(t_py, 1), "cpp_oracle_s": round(t_cpp, 1), "cpp_threads": cbls.host_threads(), "samples": len(sample)}
 
 
+def prepare_mutated(n: int, path: str, every: int = 3, n_samples: int = 256, seed: int = 4) -> dict:
+    """n valid K = 1 tuples generated on the device, every `every`-th one damaged by tests/_blsmutate.py (seeded; 27 kinds of
+    damage to the encodings + wrong messages + double faults).  There is no expectation by construction here: the C++ oracle
+    judges ALL tuples, the Python oracle a sample stratified over the kinds, and the two must agree before a kernel is judged."""
+    from collections import Counter
+    from ethereum_consensus_amd import bls, synthetic as syn
+    from oracle import bls12_381 as B
+    from oracle import cbls
+    from tests import _blsmutate as M
+    skb = syn.bls_secret_keys(n)
+    msgs = syn.bls_messages(n)
+    pks = bytearray(bls.sk_to_pk_batch(skb))
+    sigs = bytearray(bls.sign_batch(skb, [msgs[32 * i:32 * i + 32] for i in range(n)]))
+    msgb = bytearray(msgs)
+    kind_of = M.mutate_tuples(pks, msgb, sigs, n, every=every, seed=seed)
+    pks, msgb, sigs = bytes(pks), bytes(msgb), bytes(sigs)
+    t0 = time.time()
+    cpp = cbls.fast_aggregate_verify_batch_k1(pks, msgb, sigs)
+    t_cpp = time.time() - t0
+    r = random.Random(seed + 1)
+    by_kind = {}
+    for i in range(0, n, every):
+        by_kind.setdefault(kind_of[i], []).append(i)
+    sample = []
+    per = max(2, n_samples // max(1, len(by_kind)) - 1)
+    for k in sorted(by_kind):
+        sample += r.sample(by_kind[k], min(per, len(by_kind[k])))
+    sample += r.sample([i for i in range(n) if kind_of[i] == 255], max(4, n_samples - len(sample)))
+    t0 = time.time()
+    py = {i: B.fast_aggregate_verify([pks[48 * i:48 * i + 48]], msgb[32 * i:32 * i + 32], sigs[96 * i:96 * i + 96]) for i in sample}
+    t_py = time.time() - t0
+    disagree = [(i, M.KINDS[kind_of[i]] if kind_of[i] != 255 else "untouched", cpp[i], py[i]) for i in py if py[i] != cpp[i]]
+    assert not disagree, disagree[:8]  # a class the oracles disagree on is UNPINNED: it must be listed in DESIGN.md 6, not tested
+    assert all(cpp[i] == 0 for i in range(n) if kind_of[i] == 255)
+    w = {"n": n, "pks": pks, "msgs": msgb, "sigs": sigs, "want": cpp, "kind_of": kind_of, "py": py, "cpp": cpp, "fault_cycle": False}
+    with open(path, "wb") as f:
+        pickle.dump(w, f)
+    hist = Counter((M.KINDS[kind_of[i]], cpp[i]) for i in range(0, n, every))
+    return {"python_oracle_s": round(t_py, 1), "cpp_oracle_s": round(t_cpp, 1), "samples": len(sample), "mutated": len(range(0, n, every)),
+            "kinds": len(by_kind), "status_by_kind": {f"{k} -> {st:#x}": c for (k, st), c in sorted(hist.items())}}
+
+
 def run(path: str, n_first: int, want_tower: int, want_path: str) -> int:
     from ethereum_consensus_amd import _lib, bls
     with open(path, "rb") as f:
@@ -70,7 +112,7 @@ def run(path: str, n_first: int, want_tower: int, want_path: str) -> int:
     out = {"n": n, "tower": tower, "path": pth, "verify_s": round(dt, 3), "mismatch_vs_construction": bad[:8], "mismatch_vs_cpp_oracle": cbad[:8],
            "mismatch_vs_python_oracle": pbad[:8], "python_samples_checked": sum(1 for i in w["py"] if i < n), "fault_classes": classes}
     ok = (not bad and not cbad and not pbad and (want_tower == 0 or tower == want_tower) and (want_path == "any" or pth == want_path)
-          and len(classes) == min(8, (n + 63) // 64))
+          and (not w.get("fault_cycle", True) or len(classes) == min(8, (n + 63) // 64)))
     out["ok"] = ok
     print(json.dumps(out))
     return 0 if ok else 1

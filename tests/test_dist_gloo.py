@@ -266,3 +266,142 @@ def test_bench_n_rank_control_flow_under_gloo(world):
         lo, hi = shard.shard_range(10, r, world)
         assert out["bls"][:3] == (True, hi - lo, "strong")
         assert abs(out["bls"][3] - 10) < 1e-3  # value x time of one step = the whole batch, whatever the rank count
+
+
+# ---- ONE BeaconState over N ranks (bench.py --workload merkle --scaling strong) --------------------------
+# The same stub technique: the three state entries of the C ABI answered by oracle/ssz.py over host memory, so that
+# bench.run_merkle_sharded's own N-rank flow -- phase A per rank, the all-gather of 5 x 32 bytes, phase B on every rank, the
+# root compared with the unsharded root -- runs under gloo at world sizes 2, 3 and 4.
+class _StateStub:
+    LISTS = (("validators", 121, 1), ("balances", 8, 4), ("previous_epoch_participation", 1, 32),
+             ("current_epoch_participation", 1, 32), ("inactivity_scores", 8, 4))
+
+    def __init__(self, n_validators):
+        from ethereum_consensus_amd import synthetic as S
+        from oracle import ssz as O
+        self.f = S.state_fields(n_validators, "mainnet", seed=1)
+        self.enc = S.serialize_state(self.f)
+        self.n = n_validators
+        self.O = O
+        self.last = 0
+        from tests._statevalue import oracle_state_value
+        t = O.BeaconStateDeneb(O.MAINNET)
+        self.names = [k for k, _ in t.fields]
+        light = dict(self.f)
+        light["validators"] = self.f["validators"][:0]
+        for k in ("balances", "previous_epoch_participation", "current_epoch_participation", "inactivity_scores"):
+            light[k] = self.f[k][:0]
+        self.small_roots = t.field_roots(oracle_state_value(light))
+        vt = dict(t.fields)["validators"].elem
+        full = oracle_state_value(self.f)
+        self.vroots = [vt.htr(v) for v in full["validators"]]
+
+    def _leaves(self, name):
+        """(chunks or element roots, limit in leaves) of one of the five lists"""
+        O = self.O
+        if name == "validators":
+            return self.vroots, O.MAINNET.VALIDATOR_REGISTRY_LIMIT
+        data = self.f[name].tobytes()
+        per = 32 // (8 if name in ("balances", "inactivity_scores") else 1)
+        chunks = [data[i:i + 32].ljust(32, b"\0") for i in range(0, len(data), 32)]
+        return chunks, O.MAINNET.VALIDATOR_REGISTRY_LIMIT // per
+
+    def ecgpu_last_error(self):
+        return b""
+
+    def ecgpu_beacon_state_fixed_size(self, fork, preset):
+        return 2736629 + 4  # unused by the stub beyond slicing the host copy; any value <= len(enc)
+
+    def ecgpu_beacon_state_shard_lists(self):
+        return 5
+
+    def ecgpu_last_hash64_count(self):
+        return self.last
+
+    def _check_state(self, d_ssz, n_bytes):
+        import ctypes
+        assert n_bytes == len(self.enc) and ctypes.string_at(d_ssz, 64) == self.enc[:64]
+
+    def ecgpu_htr_beacon_state_dev(self, fork, d_ssz, n_bytes, h_fixed, preset, d_root, stream):
+        import ctypes
+        self._check_state(d_ssz, n_bytes)
+        O = self.O
+        roots = list(self.small_roots)
+        for name, _, _ in self.LISTS:
+            leaves, limit = self._leaves(name)
+            roots[self.names.index(name)] = O.mix_in_length(O.merkleize_chunks(leaves, limit), self.n)
+        ctypes.memmove(d_root, O.merkleize_chunks(roots, len(roots)), 32)
+        self.last = 1000
+        return 0
+
+    def ecgpu_beacon_state_shard_subroots_dev(self, fork, d_ssz, n_bytes, h_fixed, preset, rank, world, d_sub, stream):
+        import ctypes
+        self._check_state(d_ssz, n_bytes)
+        out = b""
+        for name, _, _ in self.LISTS:
+            leaves, _ = self._leaves(name)
+            w = shard.subtree_width(len(leaves), world)
+            lo, hi = shard.subtree_range(len(leaves), rank, world)
+            out += self.O.merkleize_chunks(leaves[lo:hi], w)
+        ctypes.memmove(d_sub, out, 160)
+        self.last = 100
+        return 0
+
+    def ecgpu_htr_beacon_state_sharded_dev(self, fork, d_ssz, n_bytes, h_fixed, preset, d_all, world, d_root, stream):
+        import ctypes
+        self._check_state(d_ssz, n_bytes)
+        O = self.O
+        allb = ctypes.string_at(d_all, 160 * world)
+        roots = list(self.small_roots)
+        for k, (name, _, _) in enumerate(self.LISTS):
+            leaves, limit = self._leaves(name)
+            w = shard.subtree_width(len(leaves), world)
+            n_sub = -(-len(leaves) // w)
+            subs = [allb[160 * r + 32 * k:160 * r + 32 * k + 32] for r in range(n_sub)]
+            roots[self.names.index(name)] = O.mix_in_length(O.merkleize_subtree_roots(subs, w, limit), self.n)
+        ctypes.memmove(d_root, O.merkleize_chunks(roots, len(roots)), 32)
+        self.last = 50
+        return 0
+
+
+def _merkle_worker(rank, world, port, n_validators, q):
+    import argparse
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        bench.DEV = "cpu"
+        args = argparse.Namespace(steps=1, warmup=1, validators=n_validators, scaling="strong")
+        L = _StateStub(n_validators)
+        r = bench.run_merkle_sharded(args, L, torch, dist, rank, world)
+        line = bench.finish(r, args, world, dist, torch)
+        dist.barrier()
+        q.put((rank, (r["check"]["equals_unsharded_root"], r["check"]["root"], line["scaling"], line["n_gpus"],
+                      round(line["value"] * line["ms_per_step"] / 1e3))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_validators", [(2, 300), (4, 300), (3, 77), (4, 2)])
+def test_one_state_sharded_over_the_ranks_under_gloo(world, n_validators):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_merkle_worker, args=(r, world, port, n_validators, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    roots = {res[r][1] for r in range(world)}
+    assert len(roots) == 1  # every rank ends with the same root ...
+    for r in range(world):
+        ok, _, scaling, n_gpus, units = res[r]
+        assert ok is True and scaling == "strong" and n_gpus == world  # ... which is the unsharded root
+        assert units == 1000  # value x step time = the whole state's hash64, whatever the rank count

@@ -650,6 +650,75 @@ def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, 
     assert res["ok"] and res["n"] == n and res["python_samples_checked"] >= (64 if n == 65536 else 8), res
 
 
+@pytest.fixture(scope="module")
+def mutated_workload(gpu, tmp_path_factory):
+    """65 536 valid K = 1 tuples, 21 846 of them damaged at random (tests/_blsmutate.py): judged by the C++ oracle on all of
+    them and by the Python oracle on >= 256 sampled ones, the two asserted equal on the sample"""
+    from tests import _bls_config2
+    path = str(tmp_path_factory.mktemp("mutated") / "workload.pkl")
+    info = _bls_config2.prepare_mutated(65536, path, every=3, n_samples=256)
+    assert info["mutated"] >= 20000 and info["kinds"] == 26 and info["samples"] >= 256, info
+    return path, info
+
+
+@pytest.mark.parametrize("tower,pairing,want_tower,want_path", [("sums", "lane", 1, "lane"), ("sums", "vm3", 1, "vm3"), ("calls", "auto", 2, "vm3")])
+def test_randomised_differential_parity_over_mutated_encodings(mutated_workload, tower, pairing, want_tower, want_path):
+    """The negative space at scale: the whole 65 536-entry status vector of a batch in which every
+    third tuple carries a seeded random mutation -- flag bits, x >= p, sign flips, swapped G2 halves, points outside the
+    subgroups, infinity encodings with stray bits, all-zero / all-one tails, single-bit damage, wrong messages, double faults
+    (which error wins: crypto/bls.rs:119-131) -- equals the C++ oracle's on ALL tuples and the Python oracle's on the sample, on
+    both pairing paths and on the compact-code G2 stage kernels."""
+    import json
+    import os
+    import subprocess
+    import sys
+    path, info = mutated_workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ECGPU_TOWER=tower, ECGPU_PAIRING=pairing, PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-m", "tests._bls_config2", "run", path, "65536", str(want_tower), want_path], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["n"] == 65536 and res["python_samples_checked"] >= 256, res
+
+
+def test_aggregate_verify_lengths_and_emptiness_against_both_oracles(gpu):
+    """crypto/bls.rs:95-112 off the happy path: no keys, no messages, more keys than messages and the reverse, a damaged key in
+    every position, a damaged signature, duplicate messages -- the status of ecgpu_aggregate_verify equals the C++ oracle's and
+    the Python oracle's on every case (the blst verdicts for n = 0 / length mismatch are standard-pinned)."""
+    import random
+    from ethereum_consensus_amd import bls as M
+    from oracle import cbls
+    from tests import _blsmutate as MU
+    r = random.Random(11)
+    sks = [r.randrange(1, B.R) for _ in range(5)]
+    pks = [B.sk_to_pk(s) for s in sks]
+    msgs = [r.randbytes(32) for _ in range(5)]
+    sig_of = lambda ks, ms: B.aggregate([B.sign(k, m) for k, m in zip(ks, ms)])[1] if ks else B.INFINITY_SIGNATURE
+    cases = []
+    for n in range(0, 6):
+        cases.append((pks[:n], msgs[:n], sig_of(sks[:n], msgs[:n])))
+    full = sig_of(sks, msgs)
+    cases += [(pks[:4], msgs, full), (pks, msgs[:4], full), ([], msgs[:1], full), (pks[:1], [], full), ([], [], B.INFINITY_SIGNATURE),
+              (pks, [msgs[0]] * 5, sig_of(sks, [msgs[0]] * 5)), (pks, msgs[::-1], full)]
+    for pos in range(5):
+        for k in (0, 3, 5, 8):
+            bad = bytearray(pks[pos])
+            MU.mutate_pk(bad, k, r, pos)
+            cases.append((pks[:pos] + [bytes(bad)] + pks[pos + 1:], msgs, full))
+    for k in range(len(MU.SIG_KINDS)):
+        bad = bytearray(full)
+        MU.mutate_sig(bad, k, r, k)
+        cases.append((pks, msgs, bytes(bad)))
+    seen = set()
+    for ks, ms, sg in cases:
+        got = M.aggregate_verify_status(ks, ms, sg)
+        want_c, want_py = cbls.aggregate_verify(ks, ms, sg), B.aggregate_verify(ks, ms, sg)
+        assert got == want_c == want_py, (len(ks), len(ms), got, want_c, want_py)
+        seen.add(got)
+    assert {0, 1, 5}.issubset(seen), seen
+
+
 def test_north_star_batch_of_2_pow_20_signatures_in_one_call(gpu):
     """north_star "Target": a 2^20-signature K = 1 batch.  1 048 576 tuples (the workload of `bench.py --tuples 1048576 --scaling
     strong`: SURVEY 8(d) config 2's generator and fault cycle, every 64th tuple corrupted, eight classes) through ONE

@@ -331,6 +331,56 @@ def test_sharded_big_lists_equal_the_unsharded_roots(gpu):
     assert gpu.merkleize_sharded(None, bal, n_chunks, limit_chunks, n) == full_bal
 
 
+@pytest.mark.parametrize("fork", ["altair", "bellatrix", "capella", "deneb"])
+def test_one_beacon_state_sharded_over_emulated_ranks(gpu, fork):
+    """SURVEY.md 8e row 2 / north_star "2^20-validator batch at 1, 2, 4 and 8 GPUs": ONE state over `world` ranks through the
+    two-phase device entries (ecgpu_beacon_state_shard_subroots_dev per rank, the 5 x 32-byte exchange, ecgpu_htr_beacon_state_
+    sharded_dev) equals the oracle's root of the same state -- ragged, tiny and empty registries, worlds that are not powers of
+    two, both presets; the ranks run one after the other on the one GPU (the collective: tests/test_dist_gloo.py,
+    tests/test_gpu_dist.py)."""
+    import random
+    import torch
+    from ethereum_consensus_amd import synthetic
+    ssz = gpu
+    L = ssz._lib.load()
+    rnd = random.Random(5)
+    st = torch.cuda.current_stream().cuda_stream
+    nl = L.ecgpu_beacon_state_shard_lists()
+    assert nl == 5
+    for preset_name, preset, n in (("minimal", ssz.MINIMAL, 0), ("minimal", ssz.MINIMAL, 1), ("minimal", ssz.MINIMAL, 37), ("mainnet", ssz.MAINNET, 300),
+                                   ("minimal", ssz.MINIMAL, 4097), ("minimal", ssz.MINIMAL, 70001)):
+        f = synthetic.state_fields(n, preset_name, seed=rnd.randrange(1000))
+        f["_preset"] = preset_name
+        if n <= 300:
+            t, v = _fork_state_value(fork, f, rnd)
+            enc, want = t.serialize(v), t.htr(v)
+        else:  # the pure-Python oracle would take minutes: the unsharded GPU root (itself pinned to the oracle at the small sizes)
+            if fork != "deneb":
+                continue
+            enc = synthetic.serialize_state(f)
+            want = ssz.hash_tree_root_beacon_state(fork, enc, preset)
+            assert want == oracle_state_root_fast(f, preset_name)
+        fixed = L.ecgpu_beacon_state_fixed_size(ssz.FORKS[fork], preset)
+        d = torch.frombuffer(bytearray(enc), dtype=torch.uint8).cuda()
+        h_fixed = ctypes.create_string_buffer(bytes(enc[:fixed]), fixed)
+        out = torch.zeros(32, dtype=torch.uint8, device="cuda")
+        for world in (1, 2, 3, 8):
+            d_all = torch.full((32 * nl * world,), 0xAB, dtype=torch.uint8, device="cuda")
+            for rank in range(world):
+                rc = L.ecgpu_beacon_state_shard_subroots_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, rank, world,
+                                                             d_all.data_ptr() + 32 * nl * rank, st)
+                assert rc == 0, (rc, L.ecgpu_last_error())
+            rc = L.ecgpu_htr_beacon_state_sharded_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, d_all.data_ptr(), world,
+                                                      out.data_ptr(), st)
+            assert rc == 0, (rc, L.ecgpu_last_error())
+            torch.cuda.synchronize()
+            assert bytes(out.cpu().numpy()) == want, (fork, preset_name, n, world)
+    # argument checks: rank outside the world, no ranks, phase0 (host entry only)
+    assert L.ecgpu_beacon_state_shard_subroots_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, 2, 2, d_all.data_ptr(), st) == -3
+    assert L.ecgpu_htr_beacon_state_sharded_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, d_all.data_ptr(), 0, out.data_ptr(), st) == -3
+    assert L.ecgpu_beacon_state_shard_subroots_dev(0, d.data_ptr(), len(enc), h_fixed, preset, 0, 1, d_all.data_ptr(), st) == -3
+
+
 def test_box_selfcheck_runs_and_reports_positive_times(gpu):
     """ecgpu_selfcheck_ifetch[_sweep]: the instruction-fetch probe bench.py reports next to its numbers."""
     from ethereum_consensus_amd import _lib
@@ -419,6 +469,15 @@ def test_beacon_state_root_of_every_fork(gpu, fork):
             assert rc == 0, (rc, L.ecgpu_last_error())
             torch.cuda.synchronize()
             assert bytes(out.cpu().numpy()) == want
+            # ... and the checked form says so with a status next to the root (round-3 verdict item 8): 0, or ECGPU_ERR_BAD_ARG
+            # -- the code the host entries and the resident state return for the same encoding
+            status = torch.full((1,), 77, dtype=torch.int32, device="cuda")
+            out.zero_()
+            rc = L.ecgpu_htr_beacon_state_dev_checked(ssz.FORKS[fork], d.data_ptr(), len(blob), fixed_part, ssz.MINIMAL, out.data_ptr(),
+                                                      status.data_ptr(), st)
+            assert rc == 0, (rc, L.ecgpu_last_error())
+            torch.cuda.synchronize()
+            assert bytes(out.cpu().numpy()) == want and int(status.item()) == (0 if blob is enc else -3)
 
 
 def test_resident_state_of_an_older_fork(gpu):

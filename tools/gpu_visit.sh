@@ -39,18 +39,21 @@ for step in "$@"; do
     pmc) for c in FETCH_SIZE WRITE_SIZE; do
            timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-aggregates --workload bls > gpurun_out/${tag}${sfx}_pmc_$c.log 2>&1
            python tools/pmc_summary.py gpurun_out/pmc_${tag}_$c gpurun_out/${tag}${sfx}_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_pmc_$c.txt | cut -c1-160
-           rm -rf gpurun_out/pmc_${tag}_$c
-         done;;
+         done
+         # profiles/pmc_traffic.json: per-step traffic of the dominant kernels, keyed by the source hash of the kernels that ran (4 steps: 3 + 1 warm-up)
+         python tools/pmc_to_json.py $tag 4 > gpurun_out/${tag}${sfx}_pmc_traffic.json && cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
+         for c in FETCH_SIZE WRITE_SIZE; do rm -rf gpurun_out/pmc_${tag}_$c; done;;
     sq) P1="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INSTS_LDS"
         timeout 900 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-aggregates --workload bls > gpurun_out/${tag}${sfx}_sq.log 2>&1
         python tools/pmc_summary.py gpurun_out/pmc_${tag}_sq gpurun_out/${tag}${sfx}_sq_raw.txt
         python tools/sq_digest.py gpurun_out/${tag}${sfx}_sq_raw.txt | tee gpurun_out/${tag}${sfx}_sq_counters.txt
         rm -rf gpurun_out/pmc_${tag}_sq;;
     pmc_merkle) for c in FETCH_SIZE WRITE_SIZE; do
-           timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_m_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload merkle > gpurun_out/${tag}${sfx}_merkle_pmc_$c.log 2>&1
-           python tools/pmc_summary.py gpurun_out/pmc_${tag}_m_$c gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt | cut -c1-160
-           rm -rf gpurun_out/pmc_${tag}_m_$c
-         done;;
+           timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload merkle > gpurun_out/${tag}${sfx}_merkle_pmc_$c.log 2>&1
+           python tools/pmc_summary.py gpurun_out/pmc_${tag}_$c gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt | cut -c1-160
+         done
+         python tools/pmc_to_json.py $tag 4 merkle > gpurun_out/${tag}${sfx}_merkle_pmc_traffic.json && cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
+         for c in FETCH_SIZE WRITE_SIZE; do rm -rf gpurun_out/pmc_${tag}_$c; done;;
     run:*) c=${step#run:}; timeout $TO ${c//,/ } 2>&1 | tee gpurun_out/${tag}${sfx}_$(basename ${c%%,*}).txt | tail -40;;
     py:*) s=${step#py:}; timeout 900 python tools/${s//,/ } 2>&1 | tee gpurun_out/${tag}${sfx}_$(echo $s | tr -c 'A-Za-z0-9' '_').txt | tail -40;;
     *) echo "unknown step $step";;

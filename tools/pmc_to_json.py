@@ -20,21 +20,32 @@ def total(root, counter, needle):
     return tot, n
 
 
-def main(tag, n_steps):
+def src_hash(key):
+    """the identity of the kernels the pass was taken on (lib/build_manifest.json, written by the build; bench.py only
+    reports a pass whose hash equals the loaded library's)"""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.kernel_source_hash(key)
+
+
+def main(tag, n_steps, only=None):
     try:
         out = json.load(open("profiles/pmc_traffic.json"))  # passes of other kernel builds stay
     except (OSError, ValueError):
         out = {}
     for key, needle in KERNELS.items():
+        if only == "merkle" and "merkle" not in key:
+            continue
         f, nf = total(f"gpurun_out/pmc_{tag}_FETCH_SIZE", "FETCH_SIZE", needle)
         w, nw = total(f"gpurun_out/pmc_{tag}_WRITE_SIZE", "WRITE_SIZE", needle)
         if nf and nw:
-            out[key] = {"fetch_kib": f / n_steps, "write_kib": w / n_steps, "launches_per_step": nf / n_steps,
-                        "source": f"profiles/{tag}_pmc_FETCH_SIZE.txt, profiles/{tag}_pmc_WRITE_SIZE.txt (rocprofv3 --pmc, one counter per "
+            out[key] = {"fetch_kib": f / n_steps, "write_kib": w / n_steps, "launches_per_step": nf / n_steps, "src_hash": src_hash(key),
+                        "source": f"profiles/{tag}{'_merkle' if only == 'merkle' else ''}_pmc_FETCH_SIZE.txt, profiles/{tag}{'_merkle' if only == 'merkle' else ''}_pmc_WRITE_SIZE.txt (rocprofv3 --pmc, one counter per "
                                   f"pass, bench.py over {n_steps} steps incl. warm-up)"}
     json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]))
+    main(sys.argv[1], int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else None)
