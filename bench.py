@@ -86,7 +86,7 @@ def effective_cores():
 
 
 # translation unit whose objects hold each kernel the roofline is quoted on (lib/build_manifest.json is keyed by it)
-KERNEL_UNIT = {"k_pairing": "bls_pairing_kernels.hip", "k_pairing2": "bls_pairing2_kernels.hip", "k_vm3_pair_a": "bls_vm3.hip",
+KERNEL_UNIT = {"k_pairing": "bls_pairing_kernels.hip", "k_miller2": "bls_pairing2_kernels.hip", "k_finalexp": "bls_pairing_kernels.hip", "k_vm3_pair_a": "bls_vm3.hip",
                "k_vm3_pair_c": "bls_vm3.hip", "k_merkle_pass<2, ValidatorLeaves>": "merkle.hip"}
 
 
@@ -506,11 +506,19 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
     if path == 3:  # the sum-of-products lane groups ran the pairing check (ECGPU_PAIRING=vm3, or a box with slow instruction fetch)
         pairing_kernel = "k_vm3_pair_a + k_vm3_pair_c"
         ops["bls_pairing"] = (0, 0, vm3_multiplies_per_tuple())
+    if path == 5:  # Miller loop on two lanes per tuple (two waves per SIMD), final exponentiation on one: the same multiplies
+        pairing_kernel = "k_miller2 + k_finalexp"
     mults_per_sig = sum(m * 351 + s_ * 273 + x for m, s_, x in ops.values())
     stages = {}
     for tag in ops:
         ms, cnt = _prof(L, tag)
         stages[tag] = ms / max(cnt, 1)
+    pairing_parts = None
+    if path == 5:
+        pairing_parts = {}
+        for tag in ("bls_miller2", "bls_finalexp"):
+            ms, cnt = _prof(L, tag)
+            pairing_parts[tag] = ms / max(cnt, 1)
     L.ecgpu_prof_enable(0)
     st = d_st[:n].cpu().numpy()
     import numpy as np
@@ -531,6 +539,9 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
         traffic = None if not (ta and tc) else {"bytes_per_launch": ta["bytes_per_launch"] + tc["bytes_per_launch"], "parts": [ta, tc]}
     else:
         traffic = pmc_traffic(pairing_kernel)
+    if path == 5:
+        ta, tc = pmc_traffic("k_miller2"), pmc_traffic("k_finalexp")
+        traffic = None if not (ta and tc) else {"bytes_per_launch": ta["bytes_per_launch"] + tc["bytes_per_launch"], "parts": [ta, tc]}
     m_cpu = min(n, 16384)
     return dict(
         host_sample=(bytes(h_pk[:48 * m_cpu]), bytes(msgs[:32 * m_cpu]), bytes(h_sig[:96 * m_cpu]), bytes(want_bytes[:m_cpu])),
@@ -545,11 +556,12 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
                              "decompressed + subgroup-checked, every message hashed to G2, per-tuple pairing check",
                 "sharding": ("strong scaling: the batch is fixed, rank g verifies shard_range(total, g, N); ragged all-gather of the status "
                              "bytes every step") if strong else "one independent batch per GPU; all-gather of the status bytes every step"},
-        roofline={"bound": "hbm", "kernel": pairing_kernel, "kernel_build": "sum-of-products lane groups (vm3)" if path == 3 else {1: "sums of products", 2: "compact-code tower"}.get(build, "?"),
+        roofline={"bound": "hbm", "kernel": pairing_kernel, "kernel_build": ("sum-of-products lane groups (vm3)" if path == 3 else "two lanes per tuple (Miller loop) + one lane (final exponentiation)" if path == 5
+                                   else {1: "sums of products", 2: "compact-code tower"}.get(build, "?")),
                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"), "traffic_detail": traffic,
                   "algorithmic_bytes_per_launch": alg_bytes,
-                  "avg_launch_ms": kern_ms, "stage_ms": stages,
+                  "avg_launch_ms": kern_ms, "stage_ms": stages, "pairing_parts_ms": pairing_parts,
                   "valu_int": {"unit": "T multiplies/s (v_mad_u64_u32 + v_mul_lo_u32)", "peak": MUL_PIPE_PEAK_TOPS,
                                "one_wave_ceiling": MUL_PIPE_ONE_WAVE_TOPS, "two_waves_ceiling": MUL_PIPE_TWO_WAVES_TOPS,
                                "peak_source": "profiles/r02p_issue_rates.txt: v_mad_u64_u32 at 8 / 2 / 1 waves per SIMD",
@@ -1002,6 +1014,16 @@ def gather_selfcheck(mine, world, dist, torch):
     return per_rank
 
 
+def flush_c_stdio():
+    """RCCL announces itself through printf ("RCCL version : ..."); on a pipe that text sits in the C library's buffer until the
+    process exits, i.e. it would FOLLOW the one JSON line the driver reads.  Flushing the C streams first keeps the line last."""
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+
+
 def multi_gpu_preflight(L, torch, dist, rank, world, local):
     """What fails first on a real N-GPU node, checked before anything is timed (tools/multi_gpu_preflight.py runs the same):
     torch and the library are bound to the SAME device (LOCAL_RANK), a kernel of the library runs there, and a 1-byte
@@ -1149,9 +1171,12 @@ def main():
                                      "note": "2^21 multiply-adds per lane as loops over 8 KB .. 1 MB of code: instruction fetch far beyond the "
                                              "64 KB instruction cache; slowdown ~1.0 on a healthy box, 2.2 measured on a slow one "
                                              "(DESIGN.md 3.3)"}
-        print(json.dumps(line))
-    if world > 1:
+    # the process group goes first (whatever RCCL still has to say, it says before the line), then the C streams, then the line
+    if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        flush_c_stdio()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

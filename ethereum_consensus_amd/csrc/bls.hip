@@ -414,7 +414,8 @@ static const u32 g_h2c_split_max = [] {
 static size_t fav_ws_bytes(u32 n, u32 n_pks) {
     const size_t xf = vm3_xfer_bytes(n);
     const size_t maps = n <= g_h2c_split_max ? (size_t)2 * n * sizeof(J2) + 256 : 0;
-    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + xf + maps + 8192;
+    const size_t miller_values = (size_t)n * sizeof(Fp12) + 256;  // k_miller2 -> k_finalexp (not alive together with xf: the larger counts)
+    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + (xf > miller_values ? xf : miller_values) + maps + 8192;
 }
 // Which kernels run the pairing check.  The lane kernel (one lane per tuple, state in VGPRs/AGPRs + LDS lane slots + private
 // segment) has the best throughput but one tuple's check is a 24 ms dependent chain, so a batch of a few thousand tuples
@@ -426,6 +427,8 @@ static const int g_pairing_mode = [] {
     const char* e = getenv("ECGPU_PAIRING");
     if (e && !strcmp(e, "lane")) return 0;
     if (e && !strcmp(e, "vm3")) return 4;
+    if (e && !strcmp(e, "split")) return 5;   // two lanes per tuple for the Miller loop (k_miller2) + k_finalexp, every size
+    if (e && !strcmp(e, "auto1")) return 6;   // round 3's dispatch: lane groups up to ECGPU_VM_MAX tuples, the one-lane kernel above
     return 3;
 }();
 // Which build of the G2 stage kernels runs: 1 = sums of products (bls_g2_kernels.hip), 2 = the compact-code tower
@@ -455,6 +458,12 @@ static thread_local int t_last_pairing_path = 0;
 // batch size up to which the lane groups run the pairing check in auto mode.  Measured (profiles/r02g_vm3_timing.txt, healthy
 // box): lane groups 4.1 / 10.5 / 26.4 ms at 2 048 / 8 192 / 32 768 tuples, lane kernel 24 .. 25 flat (round 3): the groups win
 // up to ~24 k tuples.  On a box whose instruction fetch is slow they win at every size.
+// whether `auto` sends batches above the lane groups' range to the two-lanes-per-tuple Miller loop (round 4) or to the one-lane
+// kernel (round 3): decided by measurement, see DESIGN.md 3.3
+static const bool g_split_default = [] {
+    const char* e = getenv("ECGPU_SPLIT_DEFAULT");
+    return e ? atoi(e) != 0 : false;
+}();
 static const u32 g_vm_max_tuples = [] {
     const char* e = getenv("ECGPU_VM_MAX");
     return e ? (u32)strtoul(e, nullptr, 10) : 24576u;
@@ -577,9 +586,24 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     {
         ProfScope ps("bls_pairing", s);
         const bool slow_box = g_tower.load() == 2;  // large-code kernels crawl here: the 47 KB kernel at every size
-        const bool use_vm3 = g_pairing_mode == 4 || (g_pairing_mode == 3 && (n <= g_vm_max_tuples || slow_box));
-        t_last_pairing_path = use_vm3 ? 3 : 1;
-        if (!use_vm3) {
+        const bool use_vm3 = g_pairing_mode == 4 || ((g_pairing_mode == 3 || g_pairing_mode == 6) && (n <= g_vm_max_tuples || slow_box));
+        // two lanes per tuple for the Miller loop (bls_pair2.h): two waves per SIMD from the same batch.  Default above the
+        // lane groups' range on a healthy box since round 4 (ECGPU_PAIRING=auto1 / lane: the one-lane kernel).
+        const bool use_split = !use_vm3 && (g_pairing_mode == 5 || (g_pairing_mode == 3 && g_split_default));
+        t_last_pairing_path = use_vm3 ? 3 : use_split ? 5 : 1;
+        if (use_split) {
+            Fp12* fs = (Fp12*)ar.take((size_t)n * sizeof(Fp12));
+            if (!fs) return ECGPU_ERR_OOM;
+            {
+                ProfScope p2("bls_miller2", s);
+                hipLaunchKernelGGL(k_miller2, grid_for(2 * n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
+                                   (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, fs);
+            }
+            {
+                ProfScope p3("bls_finalexp", s);
+                hipLaunchKernelGGL(k_finalexp, grid_for(n), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, n, d_status);
+            }
+        } else if (!use_vm3) {
             hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
                                (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status);
         } else {

@@ -21,7 +21,10 @@ namespace ecg {
 // the wave's cycles parked on s_waitcnt).  The slots hold, in turn, the two running points of the Miller loop (2 x 6 Fp) and
 // one Fp12 operand of the final exponentiation.  Loads are volatile:
 // the point of the slots is that a value is re-read where it is used instead of staying live (and spilling).
-constexpr int LANE_SLOTS = 12;
+#ifndef ECG_LANE_SLOTS
+#define ECG_LANE_SLOTS 12  // bls_pairing2_kernels.hip (two lanes per tuple, two waves per SIMD) compiles with 6: 320 bytes of LDS per lane
+#endif
+constexpr int LANE_SLOTS = ECG_LANE_SLOTS;
 #if defined(__HIP_DEVICE_COMPILE__)
 // limb j of slot s at dword [13 s + j][lane]: every address is lane * 4 + constant (ONE address register for the whole kernel),
 // every access a ds_read_b32 / ds_write_b32 of 64 consecutive dwords (conflict-free).  Dword accesses on purpose: a

@@ -30,6 +30,17 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pairing(const A1* 
     status_out[i] = stage_pairing(a, h, s);
 }
 
+// Second half of the two-lanes-per-tuple pairing check (bls_pairing2_kernels.hip k_miller2 wrote the Miller value of every
+// tuple whose status is still 0xff): final exponentiation on one lane per tuple, status.
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_finalexp(const Fp12* fs, u32 n, u8* status_out) {
+    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (status_out[i] != 0xff) return;
+    Fp12 f = fs[i], e;
+    final_exponentiation(e, f);
+    status_out[i] = fp12_is_one(e) ? ECGPU_SUCCESS : ECGPU_VERIFY_FAIL;
+}
+
 // ---- aggregate_verify: one Miller loop per lane, product + final exponentiation on one lane ------
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;

@@ -11,12 +11,34 @@
 
 #include "bls_vm3.h"
 #include "bls_vm3_prog.h"
+#include "bls_pair2.h"
+#include <atomic>
 
 using namespace ecg;
 
 namespace ecg {
 unsigned long long g_ecg_fp_mul_count = 0, g_ecg_fp_sqr_count = 0, g_ecg_fp_mad_count = 0, g_ecg_column_overflows = 0;
 }
+
+// ---- the two lanes of a pair (bls_pair2.h) as two host threads in lock step: an exchange is a rendezvous ---------------------
+namespace ecg {
+thread_local PairChannel* t_pair_channel = nullptr;
+thread_local u32 t_pair_lane = 0;
+static std::atomic<int> g_pair_arrivals[2];
+Fp h_xch_host(const Fp& e) {
+    PairChannel* ch = t_pair_channel;
+    const u32 me = t_pair_lane;
+    ch->slot[me] = e;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    // sense-reversing barrier over two counters: publish, wait for the partner, read, acknowledge, wait for the partner's read
+    g_pair_arrivals[0].fetch_add(1, std::memory_order_acq_rel);
+    while (g_pair_arrivals[0].load(std::memory_order_acquire) % 2 != 0) std::this_thread::yield();
+    const Fp r = ch->slot[1 - me];
+    g_pair_arrivals[1].fetch_add(1, std::memory_order_acq_rel);
+    while (g_pair_arrivals[1].load(std::memory_order_acquire) % 2 != 0) std::this_thread::yield();
+    return r;
+}
+}  // namespace ecg
 
 static Fp in_fp(const u8* b) { return fp_from_raw(raw_from_be48(b, false)); }
 static void out_fp(const Fp& a, u8* b) { raw_to_be48(fp_to_raw(a), b); }
@@ -249,6 +271,43 @@ void hs_pairing(int n, const u8* p_xy, const int* p_inf, const u8* q_xy, const i
     miller_loop(f, pr, n);
     final_exponentiation(e, f);
     out_fp12(e, out);
+}
+
+// The same two-pair Miller loop on TWO lanes (bls_pair2.h h_miller_loop: what k_miller2 runs), then the one-lane final
+// exponentiation (k_finalexp): out = the 12 coefficients like hs_pairing.  miller_only != 0: the Miller value itself.
+void hs_pairing_split(const u8* p_xy, const int* p_inf, const u8* q_xy, const int* q_inf, int miller_only, u8* out) {
+    PairChannel ch;
+    std::memset(&ch, 0, sizeof(ch));
+    g_pair_arrivals[0] = 0;
+    g_pair_arrivals[1] = 0;
+    Fp12 f;
+    auto lane = [&](u32 s) {
+        t_pair_channel = &ch;
+        t_pair_lane = s;
+        MillerPairH pr[2];
+        for (int k = 0; k < 2; k++) miller_pair_h_init(pr[k], in_a1(p_xy + 96 * k, p_inf[k]), in_a2(q_xy + 192 * k, q_inf[k]));
+        H12 h;
+        h_miller_loop(h, pr);
+        h12_store(&f, h);
+    };
+    std::thread t1(lane, 1u);
+    lane(0u);
+    t1.join();
+    if (miller_only) {
+        out_fp12(f, out);
+        return;
+    }
+    Fp12 e;
+    final_exponentiation(e, f);
+    out_fp12(e, out);
+}
+// the one-lane Miller value, for comparison with the split one
+void hs_miller(const u8* p_xy, const int* p_inf, const u8* q_xy, const int* q_inf, u8* out) {
+    MillerPair pr[2];
+    for (int k = 0; k < 2; k++) miller_pair_init(pr[k], in_a1(p_xy + 96 * k, p_inf[k]), in_a2(q_xy + 192 * k, q_inf[k]));
+    Fp12 f;
+    miller_loop(f, pr, 2);
+    out_fp12(f, out);
 }
 
 // Multiplier census of the stages of one K = 1 verification (valid inputs): out[3*s] = fp_mul calls, out[3*s+1] = fp_sqr

@@ -622,6 +622,9 @@ def config2_workload(gpu, tmp_path_factory):
 
 @pytest.mark.parametrize("tower,pairing,n,want_tower,want_path", [
     ("sums", "lane", 65536, 1, "lane"),     # the large-batch kernel on a healthy box: k_pairing (lane slots in LDS)
+    ("sums", "split", 65536, 1, "split"),   # round 4: Miller loop on two lanes per tuple (k_miller2, two waves per SIMD) + k_finalexp
+    ("sums", "split", 65535, 1, "split"),   # ... ragged: the last lane pair of the last wave is missing
+    ("sums", "split", 4097, 1, "split"),    # ... and a small ragged batch (65 waves on 1 024 SIMDs)
     ("sums", "vm3", 8192, 1, "vm3"),        # the sum-of-products lane groups: the small-batch path
     ("sums", "vm3", 65536, 1, "vm3"),       # ... and at full size
     ("calls", "auto", 65536, 2, "vm3"),     # a box with slow instruction fetch: compact G2 stage kernels + lane groups at every size
@@ -661,7 +664,8 @@ def mutated_workload(gpu, tmp_path_factory):
     return path, info
 
 
-@pytest.mark.parametrize("tower,pairing,want_tower,want_path", [("sums", "lane", 1, "lane"), ("sums", "vm3", 1, "vm3"), ("calls", "auto", 2, "vm3")])
+@pytest.mark.parametrize("tower,pairing,want_tower,want_path", [("sums", "lane", 1, "lane"), ("sums", "vm3", 1, "vm3"), ("calls", "auto", 2, "vm3"),
+                                                                ("sums", "split", 1, "split")])
 def test_randomised_differential_parity_over_mutated_encodings(mutated_workload, tower, pairing, want_tower, want_path):
     """The negative space at scale: the whole 65 536-entry status vector of a batch in which every
     third tuple carries a seeded random mutation -- flag bits, x >= p, sign flips, swapped G2 halves, points outside the

@@ -22,6 +22,14 @@ def gpu():
     return L
 
 
+def _json_line(stdout):
+    """the JSON line of the run (the last line that is one: RCCL's printf banner may trail it on some builds)"""
+    for ln in reversed(stdout.strip().splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    raise AssertionError("no JSON line in: " + stdout[-1500:])
+
+
 def _env():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -38,7 +46,7 @@ def test_preflight_under_a_single_rank_nccl_group(gpu):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multi_gpu_preflight.py")], cwd=ROOT, env=_env(), capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    line = _json_line(out.stdout)
     assert line["backend"] == "nccl" and line["torch_device"] == line["library_device"] == 0
     assert line["all_gather_1_byte"] == "ok" and line["sharded_state_root_equals_unsharded"] and line["strong_bls_statuses_match"]
     assert line["all_ranks_ok"] is True
@@ -55,7 +63,7 @@ def test_bench_strong_modes_through_rccl_with_one_rank(gpu, argv, check):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + argv, cwd=ROOT, env=_env(),
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    line = _json_line(out.stdout)
     assert line["scaling"] == "strong" and line["n_gpus"] == 1
     assert line["check"][check] is True, line["check"]
     assert line["preflight"]["backend"] == "nccl" and line["preflight"]["all_gather_1_byte"] == "ok"

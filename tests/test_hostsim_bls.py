@@ -442,3 +442,35 @@ def test_two_lane_message_stage_on_the_compact_build():
         L.hs_hash_to_g2(msg, len(msg), xy, ctypes.byref(inf))
         L.hs_hash_to_g2_split(msg, len(msg), xy2, ctypes.byref(inf))
         assert xy.raw == xy2.raw and un2(xy.raw) == B.hash_to_g2(msg)
+
+
+def test_miller_loop_on_two_lanes_per_tuple_equals_the_one_lane_loop():
+    """csrc/bls_pair2.h (k_miller2: lane 2t = the real parts, lane 2t + 1 = the imaginary parts of every Fp2 value of tuple t,
+    operands exchanged across the pair): two host threads in lock step run the very lane program, an exchange being a
+    rendezvous.  The Miller value equals the one-lane loop's coefficient by coefficient, the final exponentiation of it equals
+    the oracle's product of pairings -- incl. a pair with a point at infinity (contributes 1), both pairs at infinity (the
+    loop is skipped: 1) and the verification equation e(pk, H) e(-g1, sig) = 1 itself."""
+    r = random.Random(31)
+    L = lib()
+    out, ref = ctypes.create_string_buffer(576), ctypes.create_string_buffer(576)
+    zero2 = (ctypes.c_int * 2)(0, 0)
+    for trial in range(2):
+        P1, Q1 = B.g1_mul(B.G1, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R))
+        P2, Q2 = B.g1_mul(B.G1, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R))
+        L.hs_pairing_split(a1(P1) + a1(P2), zero2, a2(Q1) + a2(Q2), zero2, 1, out)
+        L.hs_miller(a1(P1) + a1(P2), zero2, a2(Q1) + a2(Q2), zero2, ref)
+        assert out.raw == ref.raw
+        L.hs_pairing_split(a1(P1) + a1(P2), zero2, a2(Q1) + a2(Q2), zero2, 0, out)
+        assert f12_un(out.raw) == B.final_exponentiation(B.f12_mul(B.miller_loop(P1, Q1), B.miller_loop(P2, Q2)))
+    # a pair with a point at infinity contributes 1; both: the loop does not run
+    L.hs_pairing_split(a1(P1) + a1(None), (ctypes.c_int * 2)(0, 1), a2(Q1) + a2(Q2), zero2, 0, out)
+    assert f12_un(out.raw) == B.pairing(P1, Q1)
+    L.hs_pairing_split(a1(P1) + a1(P2), zero2, a2(None) + a2(None), (ctypes.c_int * 2)(1, 1), 0, out)
+    assert f12_un(out.raw) == B.F12_ONE
+    # the verification equation: sk * g1 against H, -g1 against sk * H
+    sk = r.randrange(1, B.R)
+    H = B.hash_to_g2(b"two lanes per tuple")
+    pk, sig = B.g1_mul(B.G1, sk), B.g2_mul(H, sk)
+    L.hs_pairing_split(a1(pk) + a1(B.g1_neg(B.G1)), zero2, a2(H) + a2(sig), zero2, 0, out)
+    assert f12_un(out.raw) == B.F12_ONE
+    assert L.hs_column_overflows() == 0

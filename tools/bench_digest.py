@@ -3,12 +3,14 @@
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+d = json.loads([ln for ln in open(sys.argv[1]).read().strip().splitlines() if ln.startswith("{")][-1])
 r = d.get("roofline", {})
 print("step %.2f ms  %.0f %s  kernel %s %.2f ms  check %s" % (d["ms_per_step"], d["value"], d["unit"], r.get("kernel"), r.get("avg_launch_ms") or 0, d.get("check")))
 if "stage_ms" in r:
     print("  stages", {k: round(v, 2) for k, v in r["stage_ms"].items()}, "T mult/s", {k: round(v, 1) for k, v in r["valu_int"]["achieved"].items()})
-for key in ("aggregates_k2048", "merkle", "epoch", "slots", "strong_2p20"):
+if r.get("pairing_parts_ms"):
+    print("  pairing parts", {k: round(v, 2) for k, v in r["pairing_parts_ms"].items()})
+for key in ("aggregates_k2048", "merkle", "epoch", "slots", "strong_2p20", "merkle_strong", "merkle_sharded_emulated"):
     if key in d:
         e = d[key]
         print("  %s: %.3f ms/step  %.4g %s  check %s" % (key, e.get("ms_per_step", 0), e.get("value", 0), e.get("unit"), e.get("check")))
@@ -18,6 +20,8 @@ if "msm" in d:
     print("  msm", {k: (round(v["ms"], 2), round(v["points_per_s"])) for k, v in d["msm"].items() if k.startswith("g1_")}, d["msm"]["check"])
 if "box_selfcheck" in d:
     print("  box slowdown", round(d["box_selfcheck"]["large_code_slowdown"], 2), d["box_selfcheck"]["pairing_kernels"])
+if "merkle" in d and d["merkle"].get("h2d_inclusive"):
+    print("  merkle incl. H2D", {k: round(v, 2) for k, v in d["merkle"]["h2d_inclusive"].items() if k.endswith("_ms")})
 if "cpu_baseline" in d:
     c = d["cpu_baseline"]
     print("  cpu", round(c["value"]), c["unit"], "cores", c.get("cores"), c.get("cores_effective"))

@@ -40,9 +40,10 @@ def main():
     ok = torch.tensor([int(out["sharded_state_root_equals_unsharded"] and out["strong_bls_statuses_match"])], device="cuda")
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     out["all_ranks_ok"] = bool(ok.item())
-    if rank == 0:
-        print(json.dumps(out))
     dist.destroy_process_group()
+    if rank == 0:
+        bench.flush_c_stdio()
+        print(json.dumps(out), flush=True)
     sys.exit(0 if out["all_ranks_ok"] else 1)
 
 
