@@ -181,7 +181,14 @@ ECG_HD void jac_add_aff_inl(Jac<F>& r, const Jac<F>& p, const F& qx, const F& qy
     F rr = f_sub(S2, p.y);
     if (f_is_zero(H)) {
         if (f_is_zero(rr)) {
-            jac_dbl(r, p);
+            // the doubling is out of line and takes its operand by address: a COPY made here, in the branch, keeps `p`
+            // itself a value (its address never escapes, so it lives in registers -- round 4: with `jac_dbl(r, p)` the
+            // whole operand was written back to the private segment at entry and re-read piecemeal, 60 k of the 181 k
+            // cycles of a G2 addition, profiles/r04f_h2c_parts.txt)
+            const Jac<F> pc = p;
+            Jac<F> d;
+            jac_dbl(d, pc);
+            r = d;
         } else {
             jac_set_inf(r);
         }
@@ -229,7 +236,10 @@ ECG_HD void jac_add_inl(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     F rr = f_sub(S2, S1);
     if (f_is_zero(H)) {
         if (f_is_zero(rr)) {
-            jac_dbl(r, p);
+            const Jac<F> pc = p;  // see jac_add_aff_inl
+            Jac<F> d;
+            jac_dbl(d, pc);
+            r = d;
         } else {
             jac_set_inf(r);
         }

@@ -80,6 +80,139 @@ ECG_HD_NOINLINE void xmd_expand_256(u8* out, const u8* msg, size_t msg_len) {
     }
 }
 
+// ---- expand_message_xmd for the 32-byte messages every caller of this crate signs (signing roots: signing.rs:14-22) ------------
+// Word-oriented and register-resident.  The byte-oriented routine above keeps its block in the private segment (one
+// scratch_store_byte per message byte, 64 byte loads per block): 430 us per message at one wave per SIMD, five times what its
+// instructions cost, 7 % of the message stage (profiles/r04f_h2c_parts.txt).  With msg_len = 32 every block boundary is known:
+//   b_0 = H(Z_pad | msg | 0x0100 | 0x00 | DST')   = [64 zero bytes] [msg, 01 00 00, DST'[0..29)] [DST'[29..44), pad, 1144 bits]
+//   b_i = H(b_0 ^ b_(i-1) | i | DST')             = [32 bytes, i, DST'[0..31)] [DST'[31..44), pad, 616 bits]
+// The state after the all-zero block is a constant, and the LAST block of every hash is a constant block: its message schedule
+// is folded into the round constants at compile time (what hash64 does for its padding block, sha256.h KW2).  18 compressions,
+// 9 of them without schedule work, no memory.
+constexpr u32 c_be32(const u8* b, int i) { return ((u32)b[i] << 24) | ((u32)b[i + 1] << 16) | ((u32)b[i + 2] << 8) | (u32)b[i + 3]; }
+struct Sha256KW {
+    u32 v[64];
+};
+// K[i] + W[i] for a constant 16-word block
+constexpr Sha256KW sha256_const_schedule(const u32 (&blk)[16]) {
+    Sha256KW t{};
+    u32 w[64] = {};
+    for (int i = 0; i < 16; i++) w[i] = blk[i];
+    for (int i = 16; i < 64; i++) w[i] = c_ssig1(w[i - 2]) + w[i - 7] + c_ssig0(w[i - 15]) + w[i - 16];
+    for (int i = 0; i < 64; i++) t.v[i] = SHA256_K[i] + w[i];
+    return t;
+}
+struct Sha256State {
+    u32 v[8];
+};
+constexpr Sha256State sha256_after_zero_block() {
+    u32 s[8] = {};
+    for (int i = 0; i < 8; i++) s[i] = SHA256_IV[i];
+    u32 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+    for (int i = 0; i < 64; i++) {  // W = 0 throughout
+        const u32 t1 = h + (c_rotr(e, 6) ^ c_rotr(e, 11) ^ c_rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA256_K[i];
+        const u32 t2 = (c_rotr(a, 2) ^ c_rotr(a, 13) ^ c_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g, g = f, f = e, e = d + t1, d = c, c = b, b = a, a = t1 + t2;
+    }
+    Sha256State r{};
+    const u32 o[8] = {a, b, c, d, e, f, g, h};
+    for (int i = 0; i < 8; i++) r.v[i] = s[i] + o[i];
+    return r;
+}
+struct XmdConsts {
+    Sha256State after_zpad;
+    u32 b0_tail[8];   // words 8..15 of b_0's second block: 01 00 00 DST'[0], DST'[1..29)
+    u32 bi_tail[8];   // words 8..15 of b_i's first block with i = 0: 00 DST'[0..3), DST'[3..31)
+    Sha256KW b0_last;  // b_0's third block: DST'[29..44), 0x80, zeros, 1144 bits
+    Sha256KW bi_last;  // b_i's second block: DST'[31..44), 0x80, zeros, 616 bits
+};
+constexpr XmdConsts make_xmd_consts() {
+    XmdConsts c{};
+    c.after_zpad = sha256_after_zero_block();
+    const u8* d = blsc::DST_PRIME;
+    u8 t0[32] = {};
+    t0[0] = 0x01;
+    for (int i = 0; i < 29; i++) t0[3 + i] = d[i];
+    for (int i = 0; i < 8; i++) c.b0_tail[i] = c_be32(t0, 4 * i);
+    u8 t1[32] = {};
+    for (int i = 0; i < 31; i++) t1[1 + i] = d[i];
+    for (int i = 0; i < 8; i++) c.bi_tail[i] = c_be32(t1, 4 * i);
+    u8 l0[64] = {};
+    for (int i = 0; i < 15; i++) l0[i] = d[29 + i];
+    l0[15] = 0x80;
+    u32 w0[16] = {};
+    for (int i = 0; i < 16; i++) w0[i] = c_be32(l0, 4 * i);
+    w0[15] = 8 * (64 + 32 + 3 + 44);
+    c.b0_last = sha256_const_schedule(w0);
+    u8 l1[64] = {};
+    for (int i = 0; i < 13; i++) l1[i] = d[31 + i];
+    l1[13] = 0x80;
+    u32 w1[16] = {};
+    for (int i = 0; i < 16; i++) w1[i] = c_be32(l1, 4 * i);
+    w1[15] = 8 * (32 + 1 + 44);
+    c.bi_last = sha256_const_schedule(w1);
+    return c;
+}
+ECG_CONST XmdConsts XMD32 = make_xmd_consts();
+// one compression whose message schedule is a compile-time constant (kw = K + W)
+ECG_HD void sha256_compress_const(u32 st[8], const u32 (&kw)[64]) {
+    u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; i += 8) {
+        ECG_SHA_ROUND(a, b, c, d, e, f, g, h, kw[i + 0]);
+        ECG_SHA_ROUND(h, a, b, c, d, e, f, g, kw[i + 1]);
+        ECG_SHA_ROUND(g, h, a, b, c, d, e, f, kw[i + 2]);
+        ECG_SHA_ROUND(f, g, h, a, b, c, d, e, kw[i + 3]);
+        ECG_SHA_ROUND(e, f, g, h, a, b, c, d, kw[i + 4]);
+        ECG_SHA_ROUND(d, e, f, g, h, a, b, c, kw[i + 5]);
+        ECG_SHA_ROUND(c, d, e, f, g, h, a, b, kw[i + 6]);
+        ECG_SHA_ROUND(b, c, d, e, f, g, h, a, kw[i + 7]);
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+// out: the 256 bytes of expand_message_xmd as 64 big-endian words; msg: 32 bytes (global or private memory)
+ECG_HD_NOINLINE void xmd_expand_256_msg32(u32* out, const u8* msg) {
+    u32 b0[8], w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        b0[i] = XMD32.after_zpad.v[i];
+        w[i] = ((u32)msg[4 * i] << 24) | ((u32)msg[4 * i + 1] << 16) | ((u32)msg[4 * i + 2] << 8) | (u32)msg[4 * i + 3];
+        w[8 + i] = XMD32.b0_tail[i];
+    }
+    sha256_block(b0, w);
+    sha256_compress_const(b0, XMD32.b0_last.v);
+    u32 bi[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) bi[i] = 0;
+    for (u32 k = 1; k <= 8; k++) {
+        u32 st[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            st[i] = SHA256_IV[i];
+            w[i] = b0[i] ^ bi[i];  // b_1 = H(b_0 | 1 | DST'): bi = 0 on the first round
+            w[8 + i] = XMD32.bi_tail[i];
+        }
+        w[8] |= k << 24;
+        sha256_block(st, w);
+        sha256_compress_const(st, XMD32.bi_last.v);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            bi[i] = st[i];
+            out[8 * (k - 1) + i] = st[i];
+        }
+    }
+}
+// OS2IP of 64 bytes given as 16 big-endian words, mod p -> Montgomery (fp_from_be64)
+ECG_HD Fp fp_from_be_words16(const u32* w) {
+    u32 hw[12], lw[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        hw[i] = i < 4 ? w[3 - i] : 0u;
+        lw[i] = w[15 - i];
+    }
+    return fp_add(fp_mul(raw_from_words(lw), blsc::R2), fp_mul(raw_from_words(hw), blsc::R2_384));
+}
+
 // OS2IP(64 bytes) mod p -> Montgomery
 ECG_HD Fp fp_from_be64(const u8* b) {
     u32 w[12];
@@ -190,11 +323,24 @@ ECG_HD_NOINLINE void g2_clear_cofactor(J2& r, const J2& p_in) {
     ecg_priv_store(r, t3);
 }
 
-ECG_HD_NOINLINE void hash_to_g2(A2& r, const u8* msg, size_t msg_len) {
+// hash_to_field: the two field elements u0, u1 of a message
+ECG_HD void hash_to_field2(Fp2& u0, Fp2& u1, const u8* msg, size_t msg_len) {
+    if (msg_len == 32) {  // every signing root: the register-resident form
+        u32 xw[64];
+        xmd_expand_256_msg32(xw, msg);
+        u0 = Fp2{fp_from_be_words16(xw), fp_from_be_words16(xw + 16)};
+        u1 = Fp2{fp_from_be_words16(xw + 32), fp_from_be_words16(xw + 48)};
+        return;
+    }
     u8 xm[256];
     xmd_expand_256(xm, msg, msg_len);
-    Fp2 u0 = Fp2{fp_from_be64(xm), fp_from_be64(xm + 64)};
-    Fp2 u1 = Fp2{fp_from_be64(xm + 128), fp_from_be64(xm + 192)};
+    u0 = Fp2{fp_from_be64(xm), fp_from_be64(xm + 64)};
+    u1 = Fp2{fp_from_be64(xm + 128), fp_from_be64(xm + 192)};
+}
+
+ECG_HD_NOINLINE void hash_to_g2(A2& r, const u8* msg, size_t msg_len) {
+    Fp2 u0, u1;
+    hash_to_field2(u0, u1, msg, msg_len);
     // one inversion for the two SSWU maps: 1/t0 = t1 / (t0 t1), 1/t1 = t0 / (t0 t1); a zero tv2 (the exceptional case
     // of the map, which then ignores its inverse) is replaced by 1 so that it does not poison the other one
     Fp2 t0 = sswu_tv2(u0), t1 = sswu_tv2(u1);
@@ -216,9 +362,9 @@ ECG_HD_NOINLINE void hash_to_g2(A2& r, const u8* msg, size_t msg_len) {
 // to the curve -- each lane inverts its own tv2 instead of sharing one inversion -- and one lane adds the two points, clears the
 // cofactor and converts.  The two maps are ~45 % of the multiplies of hash_to_g2 and the only part with parallelism.
 ECG_HD_NOINLINE void hash_to_g2_map(J2& q, const u8* msg, size_t msg_len, int j) {
-    u8 xm[256];
-    xmd_expand_256(xm, msg, msg_len);
-    const Fp2 u = Fp2{fp_from_be64(xm + 128 * j), fp_from_be64(xm + 128 * j + 64)};
+    Fp2 u0, u1;
+    hash_to_field2(u0, u1, msg, msg_len);
+    const Fp2 u = j ? u1 : u0;
     Fp2 t = sswu_tv2(u);
     if (fp2_is_zero(t)) t = fp2_one();  // the exceptional case of the map ignores the inverse
     const Fp2 ti = fp2_inv(t);

@@ -175,6 +175,48 @@ struct Eth1DataLeaves {
     }
 };
 
+// hash_tree_root of a container of two uint64 from its 16-byte record: hash64(chunk(a), chunk(b)) -- electra's
+// PendingBalanceDeposit {index, amount} and PendingConsolidation {source_index, target_index}
+// (/root/reference/ethereum-consensus/src/electra/beacon_state.rs:27-58)
+struct U64x2Leaves {
+    const u8* base;
+    u64 total_bytes;
+    ECG_HD Node operator()(u64 idx) const {
+        u32 d[4];
+        load_bytes_le<4>(d, base, idx * 16, total_bytes);
+        Node a, b;
+        node_zero(a);
+        node_zero(b);
+        a.w[0] = ecg_bswap32(d[0]);
+        a.w[1] = ecg_bswap32(d[1]);
+        b.w[0] = ecg_bswap32(d[2]);
+        b.w[1] = ecg_bswap32(d[3]);
+        return hash64(a, b);
+    }
+};
+// ... and of three uint64 from its 24-byte record (3 leaves padded to 4): electra's PendingPartialWithdrawal
+// {index, amount, withdrawable_epoch} (electra/beacon_state.rs:38-47)
+struct U64x3Leaves {
+    const u8* base;
+    u64 total_bytes;
+    ECG_HD Node operator()(u64 idx) const {
+        u32 d[6];
+        load_bytes_le<6>(d, base, idx * 24, total_bytes);
+        Node a, b, c, z;
+        node_zero(a);
+        node_zero(b);
+        node_zero(c);
+        node_zero(z);
+        a.w[0] = ecg_bswap32(d[0]);
+        a.w[1] = ecg_bswap32(d[1]);
+        b.w[0] = ecg_bswap32(d[2]);
+        b.w[1] = ecg_bswap32(d[3]);
+        c.w[0] = ecg_bswap32(d[4]);
+        c.w[1] = ecg_bswap32(d[5]);
+        return hash64(hash64(a, b), hash64(c, z));
+    }
+};
+
 // ---- in-lane depth-first subtree ------------------------------------------------------------
 // Root of the aligned subtree of height K whose first level-0 node is `first`; level-0 nodes
 // with index >= n are virtual: an entirely virtual subtree of height k at absolute level

@@ -128,6 +128,8 @@ __device__ __forceinline__ void run_tile(const TileDesc& d, const ZeroTable* zt)
         case LEAF_BYTES48: x = tile_lane_node(Bytes48Leaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
         case LEAF_PAIR64: x = tile_lane_node(Pair64Leaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
         case LEAF_ETH1DATA: x = tile_lane_node(Eth1DataLeaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
+        case LEAF_U64X2: x = tile_lane_node(U64x2Leaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
+        case LEAF_U64X3: x = tile_lane_node(U64x3Leaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
         default: x = tile_lane_node(ChunkLeaves{d.in, d.in_bytes}, first, d.n0, zt, l0); break;
     }
     nodes[t] = x;
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u
     if (!tail_last_arrival(&P.counters[P.n_fields + P.n_jobs1], P.final_parties)) return;
     TAIL_TRACE_SET(4);
     const TreeJob top = P.job2;
-    tail_gather(P, buf, P.froots_off, 32);  // all 32 chunk slots of the state container: the unused ones are zero descriptors
+    tail_gather(P, buf, P.froots_off, P.n_froots);  // every chunk slot of the state container: the unused ones are zero descriptors
     run_tree_job(top, buf, zt);
     __syncthreads();
     const u32 t = threadIdx.x;
@@ -283,7 +285,8 @@ __global__ void __launch_bounds__(TILE_LANES) k_state_tail(const TailPlan* pl, u
     }
     if (t < 8) reinterpret_cast<u32*>(P.d_root)[t] = bad ? 0xffffffffu : reinterpret_cast<const u32*>(buf + P.root_off)[t];
     if (t == 0 && P.d_status) *P.d_status = bad ? ECGPU_ERR_BAD_ARG : ECGPU_SUCCESS;
-    if (P.d_field_roots) reinterpret_cast<u32*>(P.d_field_roots)[t] = reinterpret_cast<const u32*>(buf + P.froots_off)[t];  // 32 x 32 B = 256 dwords
+    if (P.d_field_roots)  // n_froots x 32 B
+        for (u32 k = t; k < 8 * P.n_froots; k += blockDim.x) reinterpret_cast<u32*>(P.d_field_roots)[k] = reinterpret_cast<const u32*>(buf + P.froots_off)[k];
     TAIL_TRACE_SET(5);
 }
 
@@ -409,6 +412,8 @@ int merkleize_device(hipStream_t s, LeafKind kind, const u8* d_in, u64 in_bytes,
                     case LEAF_VALIDATORS: rc = launch_pass(s, p.D, ValidatorLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_validators", g0, g1); break;
                     case LEAF_BYTES48: rc = launch_pass(s, p.D, Bytes48Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_bytes48", g0, g1); break;
                     case LEAF_PAIR64: rc = launch_pass(s, p.D, Pair64Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_pair64", g0, g1); break;
+                    case LEAF_U64X2: rc = launch_pass(s, p.D, U64x2Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_u64x2", g0, g1); break;
+                    case LEAF_U64X3: rc = launch_pass(s, p.D, U64x3Leaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_u64x3", g0, g1); break;
                     default: rc = launch_pass(s, p.D, Eth1DataLeaves{d_in, in_bytes}, p.n_in, p.n_out, out, 0, "merkle_pass_eth1data", g0, g1); break;
                 }
                 if (h == 0 && after_wide_passes && !rc) {

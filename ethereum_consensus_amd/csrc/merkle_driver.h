@@ -13,6 +13,8 @@ inline u64 leaf_record_bytes(LeafKind k) {
         case LEAF_BYTES48: return 48;
         case LEAF_PAIR64: return 64;
         case LEAF_ETH1DATA: return 72;
+        case LEAF_U64X2: return 16;
+        case LEAF_U64X3: return 24;
         default: return 32;
     }
 }
@@ -78,8 +80,9 @@ struct TailPlan {
     TreeJob jobs1[TAIL_MAX_JOBS1];      // nested containers
     u32 jobs1_deps[TAIL_MAX_JOBS1];     // units feeding each (>= 1)
     TreeJob job2;                       // the state container
-    u32 n_fields, n_tile_wgs, n_jobs0, n_jobs1, final_parties, pad_;
-    u64 root_off, froots_off;           // byte offsets in the job buffer: the state root, the 32 field-root chunks
+    u32 n_fields, n_tile_wgs, n_jobs0, n_jobs1, final_parties;
+    u32 n_froots;                       // chunk slots of the state container: 32, or 64 from electra on (37 fields)
+    u64 root_off, froots_off;           // byte offsets in the job buffer: the state root, the n_froots field-root chunks
     u8* d_root;
     u8* d_field_roots;                  // may be null
     u32* counters;                      // [n_fields] tile tickets, [n_jobs1] nested containers, [1] the state container; zero before the launch

@@ -127,10 +127,10 @@ static int state_shard_subroots_device(hipStream_t s, ThreadCtx* c, const u8* d_
     plan.n_small_chunks = B.next_chunk;
     plan.root_chunk = root_chunk;
     plan.small_hashes = B.hashes;
-    // chunks 0 .. 31 of the small buffer are handed back whole (d_field_roots); the first five are the sub-roots
-    if (!c->small_scratch) ECG_HIP_CHECK(hipMalloc((void**)&c->small_scratch, 2048));
-    u8* d_sc = c->small_scratch;  // 1 KB field-root block + the 32-byte root of the dummy container
-    int rc = run_state_plan(s, c, d_ssz, n_bytes, plan, fork, false, d_sc + 32 * 32, nullptr, nullptr, d_sc, nullptr, nullptr, 0);
+    // the field-root chunks of the small buffer are handed back whole (d_field_roots); the first five are the sub-roots
+    if (!c->small_scratch) ECG_HIP_CHECK(hipMalloc((void**)&c->small_scratch, 4096));
+    u8* d_sc = c->small_scratch;  // <= 2 KB field-root block + the 32-byte root of the dummy container
+    int rc = run_state_plan(s, c, d_ssz, n_bytes, plan, fork, false, d_sc + 2048, nullptr, nullptr, d_sc, nullptr, nullptr, 0);
     if (rc) return rc;
     ECG_HIP_CHECK(hipMemcpyAsync(d_subroots, d_sc, 32 * N_SHARDED_LISTS, hipMemcpyDeviceToDevice, s));
     return ECGPU_SUCCESS;
@@ -274,7 +274,8 @@ static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_by
     tp.job2 = rebased(plan.jobs[2][0]);
     tp.final_parties = direct + tp.n_jobs1;
     tp.root_off = small_off + 32ull * plan.root_chunk;
-    tp.froots_off = small_off;  // chunks 0 .. 31 of the small buffer are the roots of the state's fields (proofs: ssz_proof.hip)
+    tp.froots_off = small_off;  // the first chunks of the small buffer are the roots of the state's fields (proofs: ssz_proof.hip)
+    tp.n_froots = state_field_chunks(fork);
     tp.d_root = d_root;
     tp.d_field_roots = d_field_roots;
     tp.counters = d_counters;
@@ -676,7 +677,7 @@ int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
 }
 
 uint64_t ecgpu_beacon_state_fixed_size(int fork, int preset) {
-    if (preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_DENEB) return 0;
+    if (preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_LAST) return 0;
     return layout_for(STATE_PRESETS[preset], fork).size;
 }
 
@@ -684,7 +685,7 @@ int ecgpu_htr_beacon_state_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes,
                                ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (!d_ssz || !h_fixed || !d_root || fork < FORK_ALTAIR || fork > FORK_DENEB) return ECGPU_ERR_BAD_ARG;
+    if (!d_ssz || !h_fixed || !d_root || fork < FORK_ALTAIR || fork > FORK_LAST) return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
     return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork);
@@ -694,7 +695,7 @@ int ecgpu_htr_beacon_state_dev_checked(int fork, const uint8_t* d_ssz, uint64_t 
                                        uint8_t* d_root, int32_t* d_status, ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (!d_ssz || !h_fixed || !d_root || !d_status || fork < FORK_ALTAIR || fork > FORK_DENEB) return ECGPU_ERR_BAD_ARG;
+    if (!d_ssz || !h_fixed || !d_root || !d_status || fork < FORK_ALTAIR || fork > FORK_LAST) return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
     return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork, nullptr, nullptr, nullptr, (int*)d_status);
@@ -704,7 +705,7 @@ int ecgpu_beacon_state_shard_subroots_dev(int fork, const uint8_t* d_ssz, uint64
                                           uint32_t rank, uint32_t world, uint8_t* d_subroots, ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (!d_ssz || !h_fixed || !d_subroots || fork < FORK_ALTAIR || fork > FORK_DENEB || !world || world > 512 || rank >= world)
+    if (!d_ssz || !h_fixed || !d_subroots || fork < FORK_ALTAIR || fork > FORK_LAST || !world || world > 512 || rank >= world)
         return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
@@ -715,7 +716,7 @@ int ecgpu_htr_beacon_state_sharded_dev(int fork, const uint8_t* d_ssz, uint64_t 
                                        const uint8_t* d_all_subroots, uint32_t world, uint8_t* d_root, ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (!d_ssz || !h_fixed || !d_all_subroots || !d_root || fork < FORK_ALTAIR || fork > FORK_DENEB || !world || world > 512)
+    if (!d_ssz || !h_fixed || !d_all_subroots || !d_root || fork < FORK_ALTAIR || fork > FORK_LAST || !world || world > 512)
         return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
@@ -746,8 +747,8 @@ int ecgpu_htr_beacon_state(int fork, const uint8_t* ssz, uint64_t n_bytes, int p
 
 int ecgpu_beacon_state_field_roots(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t* roots, uint32_t capacity,
                                    uint32_t* n_fields, uint8_t root[32]) {
-    if (!roots || !n_fields || !root || fork < FORK_PHASE0 || fork > FORK_DENEB || capacity < state_field_count(fork)) return ECGPU_ERR_BAD_ARG;
-    u8 all[32 * 32];
+    if (!roots || !n_fields || !root || fork < FORK_PHASE0 || fork > FORK_LAST || capacity < state_field_count(fork)) return ECGPU_ERR_BAD_ARG;
+    u8 all[32 * STATE_MAX_FIELD_CHUNKS];
     int rc = beacon_state_host(fork, ssz, n_bytes, preset, root, all);
     if (rc) return rc;
     *n_fields = state_field_count(fork);
@@ -759,7 +760,7 @@ static int beacon_state_host(int fork, const uint8_t* ssz, uint64_t n_bytes, int
     int rc = ensure_init();
     if (rc) return rc;
     if (!ssz || !root) return ECGPU_ERR_BAD_ARG;
-    if (preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_DENEB || n_bytes < layout_for(STATE_PRESETS[preset], fork).size) {
+    if (preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_LAST || n_bytes < layout_for(STATE_PRESETS[preset], fork).size) {
         set_last_error("bad fork / preset or truncated state");
         return ECGPU_ERR_BAD_ARG;
     }
@@ -801,7 +802,7 @@ static int beacon_state_host(int fork, const uint8_t* ssz, uint64_t n_bytes, int
             d_state = nullptr;
             d_state_cap = 0;
         }
-        ECG_HIP_CHECK(hipMalloc((void**)&d_state, n_bytes + 2048 + (n_bytes >> 3)));
+        ECG_HIP_CHECK(hipMalloc((void**)&d_state, n_bytes + 4096 + (n_bytes >> 3)));  // + the root and up to 64 field roots
         d_state_cap = n_bytes + 64 + (n_bytes >> 3);
     }
     ECG_HIP_CHECK(hipMemcpyAsync(d_state, ssz, n_bytes, hipMemcpyHostToDevice, s));
@@ -809,7 +810,7 @@ static int beacon_state_host(int fork, const uint8_t* ssz, uint64_t n_bytes, int
     rc = state_root_device(s, c, d_state, n_bytes, ssz, preset, d_root, nullptr, fork, fork == FORK_PHASE0 ? ext : nullptr, h_payload,
                            field_roots ? d_root + 32 : nullptr);
     if (rc) return rc;
-    if (field_roots) ECG_HIP_CHECK(hipMemcpyAsync(field_roots, d_root + 32, 32 * 32, hipMemcpyDeviceToHost, s));
+    if (field_roots) ECG_HIP_CHECK(hipMemcpyAsync(field_roots, d_root + 32, 32 * state_field_chunks(fork), hipMemcpyDeviceToHost, s));
     ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
     ECG_HIP_CHECK(hipStreamSynchronize(s));
     return ECGPU_SUCCESS;

@@ -22,6 +22,8 @@ enum LeafKind : int {
     LEAF_BYTES48 = 3,     // 48-byte records -> htr(ByteVector<48>)
     LEAF_PAIR64 = 4,      // 64-byte records -> hash64 (two-field containers of roots)
     LEAF_ETH1DATA = 5,    // 72-byte Eth1Data records -> htr(Eth1Data)
+    LEAF_U64X2 = 6,       // 16-byte records of two uint64 -> hash64 of their chunks (electra PendingBalanceDeposit, PendingConsolidation)
+    LEAF_U64X3 = 7,       // 24-byte records of three uint64 -> htr of the 3-field container (electra PendingPartialWithdrawal)
 };
 
 inline u32 ceil_log2_u64(u64 x) {
@@ -67,8 +69,10 @@ inline u64 leaf_hash_cost(LeafKind k) {
     switch (k) {
         case LEAF_VALIDATORS: return 8;
         case LEAF_BYTES48:
-        case LEAF_PAIR64: return 1;
-        case LEAF_ETH1DATA: return 3;
+        case LEAF_PAIR64:
+        case LEAF_U64X2: return 1;
+        case LEAF_ETH1DATA:
+        case LEAF_U64X3: return 3;
         default: return 0;
     }
 }
@@ -166,10 +170,12 @@ struct StatePlan {
 struct Preset {
     u64 slots_per_historical_root, historical_roots_limit, eth1_data_votes_bound, validator_registry_limit,
         epochs_per_historical_vector, epochs_per_slashings_vector, sync_committee_size;
+    // electra (electra/presets/{mainnet,minimal}.rs:10-12)
+    u64 pending_balance_deposits_limit, pending_partial_withdrawals_limit, pending_consolidations_limit;
 };
 static const Preset STATE_PRESETS[2] = {
-    {8192, 1ull << 24, 2048, 1ull << 40, 65536, 8192, 512},  // mainnet
-    {64, 1ull << 24, 32, 1ull << 40, 64, 64, 32},            // minimal
+    {8192, 1ull << 24, 2048, 1ull << 40, 65536, 8192, 512, 1ull << 27, 1ull << 27, 1ull << 18},  // mainnet
+    {64, 1ull << 24, 32, 1ull << 40, 64, 64, 32, 1ull << 27, 1ull << 6, 1ull << 6},              // minimal
 };
 
 // The forks whose BeaconState this plan knows: phase0/beacon_state.rs:50-88 (21 fields),
@@ -178,14 +184,20 @@ static const Preset STATE_PRESETS[2] = {
 // Fields 0..14 are the same in every fork; altair replaced phase0's two PendingAttestation lists (fields 15, 16) by the
 // participation-flag lists and appended inactivity_scores and the sync committees; the payload header grew from 14 fields
 // (bellatrix/execution_payload.rs:58-81) to 15 (capella: + withdrawals_root) to 17 (deneb: + blob_gas_used, excess_blob_gas).
-enum StateFork : int { FORK_PHASE0 = 0, FORK_ALTAIR = 1, FORK_BELLATRIX = 2, FORK_CAPELLA = 3, FORK_DENEB = 4 };
+// electra (electra/beacon_state.rs:73-145; round 4, below SURVEY 8f): 37 fields -- deneb's 28, six uint64 and three lists of
+// small fixed-size containers -- in a 64-leaf container; the payload header has 19 fields (electra/execution_payload.rs:54-84).
+enum StateFork : int { FORK_PHASE0 = 0, FORK_ALTAIR = 1, FORK_BELLATRIX = 2, FORK_CAPELLA = 3, FORK_DENEB = 4, FORK_ELECTRA = 5 };
+constexpr int FORK_LAST = FORK_ELECTRA;
+constexpr u32 STATE_MAX_FIELD_CHUNKS = 64;  // chunks 0 .. 63 of the small buffer: the roots of the state's fields
 constexpr u64 NO_FIELD = ~0ull;
 
 inline u32 state_field_count(int fork) {
-    return fork == FORK_PHASE0 ? 21u : fork == FORK_ALTAIR ? 24u : fork == FORK_BELLATRIX ? 25u : 28u;
+    return fork == FORK_PHASE0 ? 21u : fork == FORK_ALTAIR ? 24u : fork == FORK_BELLATRIX ? 25u : fork == FORK_ELECTRA ? 37u : 28u;
 }
+// leaves of the fork's container tree: 32, or 64 from electra on
+inline u32 state_field_chunks(int fork) { return fork == FORK_ELECTRA ? 64u : 32u; }
 // fixed part of the fork's ExecutionPayloadHeader (the offset word of extra_data sits at byte 436 and must hold this value)
-inline u64 payload_header_fixed(int fork) { return fork == FORK_BELLATRIX ? 536 : fork == FORK_CAPELLA ? 568 : 584; }
+inline u64 payload_header_fixed(int fork) { return fork == FORK_BELLATRIX ? 536 : fork == FORK_CAPELLA ? 568 : fork == FORK_ELECTRA ? 648 : 584; }
 
 // byte offsets of the fields inside the fixed-size part of the encoding (NO_FIELD: the fork has no such field)
 struct FixedLayout {
@@ -194,7 +206,8 @@ struct FixedLayout {
         randao_mixes, slashings, prev_participation_off, cur_participation_off, justification_bits,
         prev_justified, cur_justified, finalized, inactivity_scores_off, current_sync_committee,
         next_sync_committee, payload_header_off, next_withdrawal_index, next_withdrawal_validator_index,
-        historical_summaries_off, prev_attestations_off, cur_attestations_off, size;
+        historical_summaries_off, prev_attestations_off, cur_attestations_off,
+        deposit_receipts_start_index, pending_balance_deposits_off, pending_partial_withdrawals_off, pending_consolidations_off, size;
 };
 
 inline FixedLayout layout_for(const Preset& p, int fork = FORK_DENEB) {
@@ -202,7 +215,7 @@ inline FixedLayout layout_for(const Preset& p, int fork = FORK_DENEB) {
     u64 o = 0;
     auto take = [&](u64 n) { u64 r = o; o += n; return r; };
     auto take_if = [&](bool have, u64 n) { return have ? take(n) : NO_FIELD; };
-    const bool altair = fork >= FORK_ALTAIR, bellatrix = fork >= FORK_BELLATRIX, capella = fork >= FORK_CAPELLA;
+    const bool altair = fork >= FORK_ALTAIR, bellatrix = fork >= FORK_BELLATRIX, capella = fork >= FORK_CAPELLA, electra = fork >= FORK_ELECTRA;
     L.genesis_time = take(8);
     L.genesis_validators_root = take(32);
     L.slot = take(8);
@@ -233,6 +246,12 @@ inline FixedLayout layout_for(const Preset& p, int fork = FORK_DENEB) {
     L.next_withdrawal_index = take_if(capella, 8);
     L.next_withdrawal_validator_index = take_if(capella, 8);
     L.historical_summaries_off = take_if(capella, 4);
+    // electra: deposit_receipts_start_index, deposit_balance_to_consume, exit_balance_to_consume, earliest_exit_epoch,
+    // consolidation_balance_to_consume, earliest_consolidation_epoch (six uint64), then three list offsets
+    L.deposit_receipts_start_index = take_if(electra, 48);
+    L.pending_balance_deposits_off = take_if(electra, 4);
+    L.pending_partial_withdrawals_off = take_if(electra, 4);
+    L.pending_consolidations_off = take_if(electra, 4);
     L.size = o;
     return L;
 }
@@ -245,7 +264,7 @@ constexpr u64 PAYLOAD_EXTRA_DATA_OFFSET_WORD = 436;
 struct Builder {
     std::vector<GatherDesc> gathers;
     std::vector<TreeJob> jobs[3];
-    u32 next_chunk = 32;  // chunks 0..31 = the state container's field roots
+    u32 next_chunk = STATE_MAX_FIELD_CHUNKS;  // chunks 0 .. 63 = the state container's field roots (37 of them in electra)
     u64 hashes = 0;
     u32 alloc(u32 n) { u32 r = next_chunk; next_chunk += n; return r; }
     void gather(u64 src, u32 nbytes, u32 dst_chunk) { gathers.push_back({src, nbytes, dst_chunk, 0u, 0u}); }
@@ -274,23 +293,25 @@ inline bool build_state_plan(int fork, const u8* h_fixed, u64 n_bytes, int prese
                              const u8* h_payload_fixed = nullptr) {
     auto fail = [&](const char* m) { plan.error = m; return false; };
     if (preset < 0 || preset > 1) return fail("bad preset");
-    if (fork < FORK_PHASE0 || fork > FORK_DENEB) return fail("unknown fork");
+    if (fork < FORK_PHASE0 || fork > FORK_LAST) return fail("unknown fork");
     const Preset& P = STATE_PRESETS[preset];
     const FixedLayout L = layout_for(P, fork);
-    const bool altair = fork >= FORK_ALTAIR, bellatrix = fork >= FORK_BELLATRIX, capella = fork >= FORK_CAPELLA;
+    const bool altair = fork >= FORK_ALTAIR, bellatrix = fork >= FORK_BELLATRIX, capella = fork >= FORK_CAPELLA, electra = fork >= FORK_ELECTRA;
     if (n_bytes < L.size) {
         return fail("state encoding shorter than its fixed part");
     }
     if (fork == FORK_PHASE0 && !ext_roots) return fail("phase0: the PendingAttestation list roots must be supplied");
     // variable parts, in field order
-    const u64 off_words[10] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off,
+    constexpr int NV = 12;  // variable-size fields in encoding order
+    const u64 off_words[NV] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off,
                                altair ? L.prev_participation_off : L.prev_attestations_off,
                                altair ? L.cur_participation_off : L.cur_attestations_off, L.inactivity_scores_off, L.payload_header_off,
-                               L.historical_summaries_off, NO_FIELD};
-    u64 off[10];
+                               L.historical_summaries_off, L.pending_balance_deposits_off, L.pending_partial_withdrawals_off,
+                               L.pending_consolidations_off};
+    u64 off[NV];
     u64 prev = L.size;
     bool first = true;
-    for (int i = 0; i < 9; i++) {
+    for (int i = 0; i < NV; i++) {
         if (off_words[i] == NO_FIELD) {
             off[i] = NO_FIELD;
             continue;
@@ -302,15 +323,17 @@ inline bool build_state_plan(int fork, const u8* h_fixed, u64 n_bytes, int prese
         first = false;
     }
     auto end_of = [&](int i) {  // where variable part i ends: the next present offset, or the end of the encoding
-        for (int k = i + 1; k < 9; k++)
+        for (int k = i + 1; k < NV; k++)
             if (off[k] != NO_FIELD) return off[k];
         return n_bytes;
     };
     const u64 HDR_FIXED = payload_header_fixed(fork);
     const u64 len_hroots = end_of(0) - off[0], len_votes = end_of(1) - off[1], len_vals = end_of(2) - off[2], len_bal = end_of(3) - off[3],
               len_pp = altair ? end_of(4) - off[4] : 0, len_cp = altair ? end_of(5) - off[5] : 0, len_inact = altair ? end_of(6) - off[6] : 0,
-              len_hdr = bellatrix ? end_of(7) - off[7] : 0, len_hsum = capella ? end_of(8) - off[8] : 0;
-    if (len_hroots % 32 || len_votes % 72 || len_vals % 121 || len_bal % 8 || len_inact % 8 || len_hsum % 64 ||
+              len_hdr = bellatrix ? end_of(7) - off[7] : 0, len_hsum = capella ? end_of(8) - off[8] : 0,
+              len_pbd = electra ? end_of(9) - off[9] : 0, len_ppw = electra ? end_of(10) - off[10] : 0, len_pc = electra ? end_of(11) - off[11] : 0;
+    if (len_hroots % 32 || len_votes % 72 || len_vals % 121 || len_bal % 8 || len_inact % 8 || len_hsum % 64 || len_pbd % 16 || len_ppw % 24 ||
+        len_pc % 16 ||
         (bellatrix && (len_hdr < HDR_FIXED || len_hdr > HDR_FIXED + 32))) {
         return fail("variable-size field has an impossible length");
     }
@@ -318,8 +341,10 @@ inline bool build_state_plan(int fork, const u8* h_fixed, u64 n_bytes, int prese
         return fail("payload header: extra_data offset does not match the fixed part");
     const u64 n_hroots = len_hroots / 32, n_votes = len_votes / 72, n_vals = len_vals / 121, n_bal = len_bal / 8,
               n_inact = len_inact / 8, n_hsum = len_hsum / 64, extra_len = bellatrix ? len_hdr - HDR_FIXED : 0;
+    const u64 n_pbd = len_pbd / 16, n_ppw = len_ppw / 24, n_pc = len_pc / 16;
     if (n_hroots > P.historical_roots_limit || n_votes > P.eth1_data_votes_bound ||
-        n_vals > P.validator_registry_limit || n_hsum > P.historical_roots_limit) {
+        n_vals > P.validator_registry_limit || n_hsum > P.historical_roots_limit || n_pbd > P.pending_balance_deposits_limit ||
+        n_ppw > P.pending_partial_withdrawals_limit || n_pc > P.pending_consolidations_limit) {
         return fail("list longer than its limit");
     }
     // chunk numbers of the field roots = field positions in the fork's container
@@ -358,6 +383,11 @@ inline bool build_state_plan(int fork, const u8* h_fixed, u64 n_bytes, int prese
         plan.ext_chunks.push_back({16u, 32u});
     }
     if (capella) bigs.push_back({LEAF_PAIR64, off[8], len_hsum, n_hsum, lg(P.historical_roots_limit), true, n_hsum, F_HSUM});
+    if (electra) {  // fields 34, 35, 36: lists of two- / three-uint64 containers
+        bigs.push_back({LEAF_U64X2, off[9], len_pbd, n_pbd, lg(P.pending_balance_deposits_limit), true, n_pbd, 34});
+        bigs.push_back({LEAF_U64X3, off[10], len_ppw, n_ppw, lg(P.pending_partial_withdrawals_limit), true, n_ppw, 35});
+        bigs.push_back({LEAF_U64X2, off[11], len_pc, n_pc, lg(P.pending_consolidations_limit), true, n_pc, 36});
+    }
 
     // ---- small fields: gathers + jobs ----------------------------------------------------------
     // basic fields: the root is the zero-padded chunk itself
@@ -370,6 +400,8 @@ inline bool build_state_plan(int fork, const u8* h_fixed, u64 n_bytes, int prese
         B.gather(L.next_withdrawal_index, 8, F_NWI);
         B.gather(L.next_withdrawal_validator_index, 8, F_NWVI);
     }
+    if (electra)  // fields 28 .. 33: six uint64
+        for (u32 k = 0; k < 6; k++) B.gather(L.deposit_receipts_start_index + 8 * k, 8, 28 + k);
     {   // Fork: previous_version[4], current_version[4], epoch u64
         u32 c0 = B.alloc(3);
         B.gather(L.fork, 4, c0);
@@ -409,7 +441,7 @@ inline bool build_state_plan(int fork, const u8* h_fixed, u64 n_bytes, int prese
     }
     if (bellatrix) {   // ExecutionPayloadHeader: 14 (bellatrix), 15 (capella) or 17 (deneb) fields
         const u64 h = off[7];
-        const u32 nf = fork == FORK_BELLATRIX ? 14u : fork == FORK_CAPELLA ? 15u : 17u;
+        const u32 nf = fork == FORK_BELLATRIX ? 14u : fork == FORK_CAPELLA ? 15u : fork == FORK_ELECTRA ? 19u : 17u;
         u32 f = B.alloc(nf);
         B.gather(h + 0, 32, f + 0);      // parent_hash
         B.gather(h + 32, 20, f + 1);     // fee_recipient
@@ -430,14 +462,18 @@ inline bool build_state_plan(int fork, const u8* h_fixed, u64 n_bytes, int prese
         B.gather(h + 472, 32, f + 12);   // block_hash
         B.gather(h + 504, 32, f + 13);   // transactions_root
         if (capella) B.gather(h + 536, 32, f + 14);  // withdrawals_root
-        if (fork == FORK_DENEB) {
+        if (fork >= FORK_DENEB) {
             B.gather(h + 568, 8, f + 15);  // blob_gas_used
             B.gather(h + 576, 8, f + 16);  // excess_blob_gas
+        }
+        if (electra) {
+            B.gather(h + 584, 32, f + 17);  // deposit_receipts_root
+            B.gather(h + 616, 32, f + 18);  // withdrawal_requests_root
         }
         B.job(1, f, nf, lg(nf), F_HDR);
     }
     const u32 root_chunk = B.alloc(1);
-    B.job(2, 0, state_field_count(fork), 5, root_chunk);
+    B.job(2, 0, state_field_count(fork), ceil_log2_u64(state_field_chunks(fork)), root_chunk);
 
     plan.gathers = B.gathers;
     for (int l = 0; l < 3; l++) plan.jobs[l] = B.jobs[l];

@@ -114,7 +114,7 @@ def hash_tree_root_beacon_state_deneb(ssz: bytes, preset: int = MAINNET) -> byte
     return _root(L.ecgpu_htr_beacon_state_deneb, _buf(ssz), len(ssz), preset)
 
 
-FORKS = {"phase0": 0, "altair": 1, "bellatrix": 2, "capella": 3, "deneb": 4}
+FORKS = {"phase0": 0, "altair": 1, "bellatrix": 2, "capella": 3, "deneb": 4, "electra": 5}
 
 
 def hash_tree_root_beacon_state(fork, ssz: bytes, preset: int = MAINNET) -> bytes:

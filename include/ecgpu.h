@@ -120,6 +120,10 @@ uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);
 #define ECGPU_FORK_BELLATRIX 2
 #define ECGPU_FORK_CAPELLA 3
 #define ECGPU_FORK_DENEB 4
+/* electra as this revision of the reference defines it (electra/beacon_state.rs:73-145: 37 fields, three lists of pending
+ * operations; electra/execution_payload.rs:54-84: a 19-field payload header): the host-pointer entry, the _dev entries and
+ * the sharded form; resident states stop at deneb. */
+#define ECGPU_FORK_ELECTRA 5
 int ecgpu_htr_beacon_state(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32]);
 int ecgpu_htr_beacon_state_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
                                uint8_t* d_root, ecgpu_stream_t stream);
@@ -227,7 +231,7 @@ int ecgpu_ssz_prove(const ecgpu_ssz_type* types, uint32_t n_types, const uint32_
 int ecgpu_merkle_proof(const uint8_t* chunks, uint64_t n_chunks, uint64_t limit_chunks, uint64_t index, uint8_t* branch);
 /* the roots of the fields of a BeaconState (the chunks of its container tree) next to its root: with ecgpu_merkle_proof
  * they give the light-client branches (current / next sync committee, finalized_checkpoint -> root) of a 2^20-validator
- * state at the cost of one state root.  roots: 32 * capacity bytes, *n_fields = 21 / 24 / 25 / 28 by fork. */
+ * state at the cost of one state root.  roots: 32 * capacity bytes, *n_fields = 21 / 24 / 25 / 28 / 28 / 37 by fork. */
 int ecgpu_beacon_state_field_roots(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t* roots, uint32_t capacity,
                                    uint32_t* n_fields, uint8_t root[32]);
 

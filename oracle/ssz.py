@@ -594,8 +594,17 @@ def ExecutionPayloadHeader(fork: str) -> Container:
     """bellatrix/execution_payload.rs:58-81 (14 fields), capella/execution_payload.rs (+ withdrawals_root), deneb/
     execution_payload.rs:48-76 (+ blob_gas_used, excess_blob_gas)"""
     full = ExecutionPayloadHeaderDeneb()
+    if fork == "electra":  # electra/execution_payload.rs:54-84: + deposit_receipts_root, withdrawal_requests_root
+        return Container("ExecutionPayloadHeader", full.fields + [("deposit_receipts_root", Root), ("withdrawal_requests_root", Root)])
     n = {"bellatrix": 14, "capella": 15, "deneb": 17}[fork]
     return Container("ExecutionPayloadHeader", full.fields[:n])
+
+
+# electra/beacon_state.rs:27-58 and the limits of electra/presets/{mainnet,minimal}.rs:10-12
+PendingBalanceDeposit = Container("PendingBalanceDeposit", [("index", uint64), ("amount", uint64)])
+PendingPartialWithdrawal = Container("PendingPartialWithdrawal", [("index", uint64), ("amount", uint64), ("withdrawable_epoch", uint64)])
+PendingConsolidation = Container("PendingConsolidation", [("source_index", uint64), ("target_index", uint64)])
+ELECTRA_LIMITS = {"mainnet": (1 << 27, 1 << 27, 1 << 18), "minimal": (1 << 27, 1 << 6, 1 << 6)}
 
 
 def PendingAttestation(max_validators_per_committee: int = 2048) -> Container:
@@ -616,11 +625,18 @@ def BeaconState(fork: str, p: Preset) -> Container:
         att = SSZList(PendingAttestation(), PENDING_ATTESTATIONS_BOUND[p.name])
         return Container("BeaconState", common + [("previous_epoch_attestations", att), ("current_epoch_attestations", att)] + bits_cps)
     fields = d[:24]
-    if fork in ("bellatrix", "capella", "deneb"):
+    if fork in ("bellatrix", "capella", "deneb", "electra"):
         fields = fields + [("latest_execution_payload_header", ExecutionPayloadHeader(fork))]
-    if fork in ("capella", "deneb"):
+    if fork in ("capella", "deneb", "electra"):
         fields = fields + d[25:28]
-    assert len(fields) == {"altair": 24, "bellatrix": 25, "capella": 28, "deneb": 28}[fork]
+    if fork == "electra":  # electra/beacon_state.rs:73-145: six uint64, three lists of pending operations
+        lim = ELECTRA_LIMITS[p.name]
+        fields = fields + [(n, uint64) for n in ("deposit_receipts_start_index", "deposit_balance_to_consume", "exit_balance_to_consume",
+                                                  "earliest_exit_epoch", "consolidation_balance_to_consume", "earliest_consolidation_epoch")]
+        fields = fields + [("pending_balance_deposits", SSZList(PendingBalanceDeposit, lim[0])),
+                           ("pending_partial_withdrawals", SSZList(PendingPartialWithdrawal, lim[1])),
+                           ("pending_consolidations", SSZList(PendingConsolidation, lim[2]))]
+    assert len(fields) == {"altair": 24, "bellatrix": 25, "capella": 28, "deneb": 28, "electra": 37}[fork]
     return Container("BeaconState", fields)
 
 

@@ -642,6 +642,163 @@ pub mod merkle {
         }
     }
 
+    // ---- a resident state that FOLLOWS the host-side `BeaconState` ---------------------------------------
+    // `process_slot` asks for `state.hash_tree_root()` once per slot (phase0/slot_processing.rs:67).  Re-serialising the state for
+    // it costs the host ~148 MB of writes and the bus 3.8 ms (bench.py `merkle.h2d_inclusive`) for a root the device computes in
+    // 0.5 ms once the bytes are there.  A `StateMirror` is a `ResidentState` plus a record of what the state transition changed
+    // since the last root: the reference's mutation sites call `touch_*` (rust/patches/ethereum-consensus-gpu-feature.patch, second
+    // half), `root()` uploads those bytes -- KBs per slot -- and returns the device's root.  Whatever is NOT tracked field by
+    // field is covered wholesale: every root re-sends the small fixed-size fields (a few hundred bytes), and an epoch boundary,
+    // which rewrites every balance, `invalidate()`s the mirror (one full upload per 32 slots).
+    /// byte offset of each tracked region in the serialization (fork- and preset-dependent; recomputed when a list grows)
+    #[derive(Clone, Debug, Default)]
+    pub struct StateLayout {
+        pub block_roots: u64, pub state_roots: u64, pub randao_mixes: u64, pub slashings: u64,
+        pub validators: u64, pub balances: u64, pub previous_epoch_participation: u64, pub current_epoch_participation: u64,
+        pub inactivity_scores: u64,
+        /// (offset, length) of the runs of small fixed-size fields between the big vectors: genesis .. latest_block_header,
+        /// eth1_data .. eth1_deposit_index, justification_bits .. finalized_checkpoint, withdrawal indices
+        pub small_runs: Vec<(u64, u64)>,
+        pub payload_header: (u64, u64),
+        pub n_validators: u64,
+        pub vector_len: u64,  // SLOTS_PER_HISTORICAL_ROOT
+        pub mixes_len: u64,   // EPOCHS_PER_HISTORICAL_VECTOR
+    }
+    pub struct StateMirror {
+        state: ResidentState,
+        layout: StateLayout,
+        patches: Vec<(u64, Vec<u8>)>,
+        appended_validators: Vec<u8>,  // 121-byte records of add_validator_to_registry since the last root
+        appended_balances: Vec<u8>,
+        stale: bool,                   // the next root re-creates the resident state from a full serialization
+        fork: i32,
+        preset: i32,
+    }
+    impl StateMirror {
+        /// `layout_of(ssz)` derives the offsets from the offset table of the serialization (the caller knows its fork's table)
+        pub fn new(fork: i32, preset: i32, ssz: &[u8], layout: StateLayout) -> Result<Self, MerkleizationError> {
+            Ok(Self { state: ResidentState::new(fork, preset, ssz)?, layout, patches: Vec::new(), appended_validators: Vec::new(),
+                      appended_balances: Vec::new(), stale: false, fork, preset })
+        }
+        pub fn touch_balance(&mut self, index: usize, gwei: u64) {
+            self.patches.push((self.layout.balances + 8 * index as u64, gwei.to_le_bytes().to_vec()));
+        }
+        pub fn touch_inactivity_score(&mut self, index: usize, score: u64) {
+            self.patches.push((self.layout.inactivity_scores + 8 * index as u64, score.to_le_bytes().to_vec()));
+        }
+        /// `current`: current_epoch_participation, else previous (altair/block_processing.rs process_attestation)
+        pub fn touch_participation(&mut self, current: bool, index: usize, flags: u8) {
+            let base = if current { self.layout.current_epoch_participation } else { self.layout.previous_epoch_participation };
+            self.patches.push((base + index as u64, vec![flags]));
+        }
+        /// the whole 121-byte record (slashings, exits, credential changes, effective-balance updates)
+        pub fn touch_validator(&mut self, index: usize, record121: &[u8]) {
+            debug_assert_eq!(record121.len(), 121);
+            self.patches.push((self.layout.validators + 121 * index as u64, record121.to_vec()));
+        }
+        pub fn touch_block_root(&mut self, slot: u64, root: &Bytes32) {
+            self.patches.push((self.layout.block_roots + 32 * (slot % self.layout.vector_len), root.to_vec()));
+        }
+        pub fn touch_state_root(&mut self, slot: u64, root: &Bytes32) {
+            self.patches.push((self.layout.state_roots + 32 * (slot % self.layout.vector_len), root.to_vec()));
+        }
+        pub fn touch_randao_mix(&mut self, epoch: u64, mix: &Bytes32) {
+            self.patches.push((self.layout.randao_mixes + 32 * (epoch % self.layout.mixes_len), mix.to_vec()));
+        }
+        pub fn touch_slashings(&mut self, index: usize, gwei: u64) {
+            self.patches.push((self.layout.slashings + 8 * index as u64, gwei.to_le_bytes().to_vec()));
+        }
+        /// add_validator_to_registry (phase0/block_processing.rs:317-349): five lists grow by one element
+        pub fn append_validator(&mut self, record121: &[u8], balance: u64) {
+            self.appended_validators.extend_from_slice(record121);
+            self.appended_balances.extend_from_slice(&balance.to_le_bytes());
+        }
+        /// anything the hooks do not follow (process_epoch rewrites every balance and rotates the participation lists; a fork
+        /// upgrade changes the layout): the next root starts from a full serialization
+        pub fn invalidate(&mut self) {
+            self.stale = true;
+            self.patches.clear();
+            self.appended_validators.clear();
+            self.appended_balances.clear();
+        }
+        /// The root of the state the hooks have described.  `small(run)` serializes one run of small fixed-size fields
+        /// (`layout.small_runs`) and `payload_header()` the header -- together < 1 KB, re-sent every time; `full()` is only
+        /// called when the mirror is stale (once per epoch) and returns (serialization, its layout).
+        pub fn root(&mut self, small: impl Fn(usize) -> Vec<u8>, payload_header: impl FnOnce() -> Vec<u8>,
+                    full: impl FnOnce() -> (Vec<u8>, StateLayout)) -> Result<Bytes32, MerkleizationError> {
+            if self.stale {
+                let (ssz, layout) = full();
+                self.state = ResidentState::new(self.fork, self.preset, &ssz)?;
+                self.layout = layout;
+                self.stale = false;
+                return self.state.root();
+            }
+            if !self.appended_validators.is_empty() {
+                let n = (self.appended_validators.len() / 121) as u64;
+                self.state.append(sys::ECGPU_STATE_VALIDATORS, &self.appended_validators)?;
+                self.state.append(sys::ECGPU_STATE_BALANCES, &self.appended_balances)?;
+                let zeros = vec![0u8; 8 * n as usize];
+                self.state.append(sys::ECGPU_STATE_PREVIOUS_EPOCH_PARTICIPATION, &zeros[..n as usize])?;
+                self.state.append(sys::ECGPU_STATE_CURRENT_EPOCH_PARTICIPATION, &zeros[..n as usize])?;
+                self.state.append(sys::ECGPU_STATE_INACTIVITY_SCORES, &zeros)?;
+                // every list behind `validators` moved: offsets shift by the bytes inserted in front of them
+                let (dv, db, dp) = (121 * n, 8 * n, n);
+                self.layout.balances += dv;
+                self.layout.previous_epoch_participation += dv + db;
+                self.layout.current_epoch_participation += dv + db + dp;
+                self.layout.inactivity_scores += dv + db + 2 * dp;
+                self.layout.payload_header.0 += dv + 2 * db + 2 * dp;
+                self.layout.n_validators += n;
+                self.appended_validators.clear();
+                self.appended_balances.clear();
+            }
+            for (k, (off, len)) in self.layout.small_runs.clone().into_iter().enumerate() {
+                let bytes = small(k);
+                debug_assert_eq!(bytes.len() as u64, len);
+                self.patches.push((off, bytes));
+            }
+            let hdr = payload_header();
+            if hdr.len() as u64 == self.layout.payload_header.1 {
+                self.patches.push((self.layout.payload_header.0, hdr));
+            } else {
+                self.invalidate();  // extra_data changed length: rare enough for a full upload
+                return self.root(small, || Vec::new(), full);
+            }
+            // later writes win: a byte range touched twice keeps its last value (patches of one call must not overlap)
+            self.patches.reverse();
+            let mut seen = std::collections::HashSet::new();
+            self.patches.retain(|(o, d)| seen.insert((*o, d.len())));
+            let refs: Vec<(u64, &[u8])> = self.patches.iter().map(|(o, d)| (*o, d.as_slice())).collect();
+            self.state.patch(&refs)?;
+            self.patches.clear();
+            self.state.root()
+        }
+    }
+    thread_local! {
+        static MIRROR: std::cell::Cell<*mut StateMirror> = std::cell::Cell::new(std::ptr::null_mut());
+    }
+    /// runs `f` (process_slots / process_block) with `m` installed as this thread's mirror: the hooks below reach it
+    pub fn with_state_mirror<R>(m: &mut StateMirror, f: impl FnOnce() -> R) -> R {
+        struct Restore(*mut StateMirror);
+        impl Drop for Restore {
+            fn drop(&mut self) {
+                MIRROR.with(|c| c.set(self.0));
+            }
+        }
+        let _restore = Restore(MIRROR.with(|c| c.replace(m as *mut StateMirror)));
+        f()
+    }
+    /// the hook the reference's mutation sites call: a no-op without a mirror
+    pub fn mirror(f: impl FnOnce(&mut StateMirror)) {
+        let p = MIRROR.with(|c| c.get());
+        if !p.is_null() {
+            f(unsafe { &mut *p });
+        }
+    }
+    pub fn has_mirror() -> bool {
+        !MIRROR.with(|c| c.get()).is_null()
+    }
+
     /// ssz_rs `is_valid_merkle_branch` (phase0/block_processing.rs:433, deneb/blob_sidecar.rs:62)
     pub fn is_valid_merkle_branch(leaf: &Bytes32, branch: &[Bytes32], depth: usize, index: usize, root: &Bytes32) -> bool {
         if branch.len() < depth || depth > 64 {

@@ -73,6 +73,16 @@ extern "C" {
                                       n: u32) -> c_int;
     pub fn ecgpu_resident_state_root(st: *mut ecgpu_resident_state_t, root: *mut u8) -> c_int;
     pub fn ecgpu_sha256_batch(data: *const u8, len: usize, n: u64, out: *mut u8) -> c_int;
+    // device-resident forms (round 4): the checked root, ONE state over several ranks, the thread's device
+    pub fn ecgpu_htr_beacon_state_dev_checked(fork: c_int, d_ssz: *const u8, n_bytes: u64, h_fixed: *const u8, preset: c_int,
+                                              d_root: *mut u8, d_status: *mut i32, stream: *mut core::ffi::c_void) -> c_int;
+    pub fn ecgpu_beacon_state_shard_subroots_dev(fork: c_int, d_ssz: *const u8, n_bytes: u64, h_fixed: *const u8, preset: c_int,
+                                                 rank: u32, world: u32, d_subroots: *mut u8, stream: *mut core::ffi::c_void) -> c_int;
+    pub fn ecgpu_htr_beacon_state_sharded_dev(fork: c_int, d_ssz: *const u8, n_bytes: u64, h_fixed: *const u8, preset: c_int,
+                                              d_all_subroots: *const u8, world: u32, d_root: *mut u8,
+                                              stream: *mut core::ffi::c_void) -> c_int;
+    pub fn ecgpu_beacon_state_shard_lists() -> u32;
+    pub fn ecgpu_thread_device() -> c_int;
     pub fn ecgpu_validators_subtree_root(ssz121: *const u8, n: u64, width: u64, root: *mut u8) -> c_int;
     pub fn ecgpu_merkleize_subtree_roots(sub_roots: *const u8, n_sub: u32, width: u64, limit: u64, mix_in_len: c_int, len: u64,
                                          root: *mut u8) -> c_int;

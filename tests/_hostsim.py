@@ -85,3 +85,13 @@ def state_root_deneb(ssz: bytes, preset: int):
     h = ctypes.c_uint64(0)
     rc = L.hs_state_root_deneb(ssz, len(ssz), preset, out, ctypes.byref(h))
     return rc, out.raw, h.value
+
+
+def state_root_fork(fork: int, ssz: bytes, preset: int):
+    L = lib()
+    L.hs_state_root_fork.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.POINTER(ctypes.c_uint64)]
+    out = ctypes.create_string_buffer(32)
+    h = ctypes.c_uint64(0)
+    rc = L.hs_state_root_fork(fork, ssz, len(ssz), preset, out, ctypes.byref(h))
+    return rc, out.raw, h.value

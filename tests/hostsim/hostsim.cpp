@@ -87,6 +87,8 @@ u64 hs_pass(int kind, int D, const u8* in, u64 in_bytes, u64 n_in, u8* out, int 
         case 2: run_pass(D, ValidatorLeaves{in, in_bytes}, n_in, n_out, out, level0); break;
         case 3: run_pass(D, Bytes48Leaves{in, in_bytes}, n_in, n_out, out, level0); break;
         case 4: run_pass(D, Pair64Leaves{in, in_bytes}, n_in, n_out, out, level0); break;
+        case 6: run_pass(D, U64x2Leaves{in, in_bytes}, n_in, n_out, out, level0); break;
+        case 7: run_pass(D, U64x3Leaves{in, in_bytes}, n_in, n_out, out, level0); break;
         default: run_pass(D, Eth1DataLeaves{in, in_bytes}, n_in, n_out, out, level0); break;
     }
     return n_out;
@@ -105,6 +107,8 @@ u64 hs_tiles(int kind, const u8* in, u64 in_bytes, u64 n0, u32 level0, u32 top, 
                 case 3: nodes[t] = tile_lane(Bytes48Leaves{in, in_bytes}, first, n0, (int)level0); break;
                 case 4: nodes[t] = tile_lane(Pair64Leaves{in, in_bytes}, first, n0, (int)level0); break;
                 case 5: nodes[t] = tile_lane(Eth1DataLeaves{in, in_bytes}, first, n0, (int)level0); break;
+                case 6: nodes[t] = tile_lane(U64x2Leaves{in, in_bytes}, first, n0, (int)level0); break;
+                case 7: nodes[t] = tile_lane(U64x3Leaves{in, in_bytes}, first, n0, (int)level0); break;
                 default: nodes[t] = tile_lane(ChunkLeaves{in, in_bytes}, first, n0, (int)level0); break;
             }
         }
@@ -180,10 +184,23 @@ u64 hs_merkleize(int kind, const u8* in, u64 in_bytes, u64 n0, u32 depth, int mi
     return h;
 }
 
-// state_deneb.hip::state_root_device on the lane simulator: same plan, same order
+// state_deneb.hip::state_root_device on the lane simulator: same plan, same order (any fork from altair on; the payload
+// header's extra_data offset is checked on the host copy like the host-pointer entry does)
+int hs_state_root_fork(int fork, const u8* ssz, u64 n_bytes, int preset, u8* out, u64* hashes);
 int hs_state_root_deneb(const u8* ssz, u64 n_bytes, int preset, u8* out, u64* hashes) {
+    return hs_state_root_fork(FORK_DENEB, ssz, n_bytes, preset, out, hashes);
+}
+int hs_state_root_fork(int fork, const u8* ssz, u64 n_bytes, int preset, u8* out, u64* hashes) {
     StatePlan plan;
-    if (!build_state_plan_deneb(ssz, n_bytes, preset, plan)) return -3;
+    if (preset < 0 || preset > 1 || fork < FORK_ALTAIR || fork > FORK_LAST) return -3;
+    const FixedLayout L = layout_for(STATE_PRESETS[preset], fork);
+    const u8* h_payload = nullptr;
+    if (fork >= FORK_BELLATRIX && n_bytes >= L.size) {
+        const u64 h = rd32(ssz + L.payload_header_off);
+        if (h > n_bytes || n_bytes - h < payload_header_fixed(fork)) return -3;
+        h_payload = ssz + h;
+    }
+    if (!build_state_plan(fork, ssz, n_bytes, preset, plan, nullptr, h_payload)) return -3;
     std::vector<u8> small(32ull * plan.n_small_chunks, 0);
     for (const GatherDesc& g : plan.gathers) {
         u32 d[8];

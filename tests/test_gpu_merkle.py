@@ -331,7 +331,7 @@ def test_sharded_big_lists_equal_the_unsharded_roots(gpu):
     assert gpu.merkleize_sharded(None, bal, n_chunks, limit_chunks, n) == full_bal
 
 
-@pytest.mark.parametrize("fork", ["altair", "bellatrix", "capella", "deneb"])
+@pytest.mark.parametrize("fork", ["altair", "bellatrix", "capella", "deneb", "electra"])
 def test_one_beacon_state_sharded_over_emulated_ranks(gpu, fork):
     """SURVEY.md 8e row 2 / north_star "2^20-validator batch at 1, 2, 4 and 8 GPUs": ONE state over `world` ranks through the
     two-phase device entries (ecgpu_beacon_state_shard_subroots_dev per rank, the 5 x 32-byte exchange, ecgpu_htr_beacon_state_
@@ -410,11 +410,24 @@ def _fork_state_value(fork, f, rnd):
         for k in (["blob_gas_used", "excess_blob_gas"] + (["withdrawals_root"] if fork == "bellatrix" else [])):
             hdr.pop(k)
         v["latest_execution_payload_header"] = hdr
+    if fork == "electra":
+        hdr = dict(v["latest_execution_payload_header"])
+        hdr["deposit_receipts_root"], hdr["withdrawal_requests_root"] = rnd.randbytes(32), rnd.randbytes(32)
+        v["latest_execution_payload_header"] = hdr
+        for k in ("deposit_receipts_start_index", "deposit_balance_to_consume", "exit_balance_to_consume", "earliest_exit_epoch",
+                  "consolidation_balance_to_consume", "earliest_consolidation_epoch"):
+            v[k] = rnd.randrange(1 << 64)
+        small = f["_preset"] == "minimal"
+        v["pending_balance_deposits"] = [{"index": rnd.randrange(1 << 40), "amount": rnd.randrange(1 << 64)} for _ in range(rnd.choice([0, 1, 5, 1500]))]
+        v["pending_partial_withdrawals"] = [{"index": rnd.randrange(1 << 40), "amount": rnd.randrange(1 << 64), "withdrawable_epoch": rnd.randrange(1 << 64)}
+                                            for _ in range(rnd.choice([0, 3, 64] if small else [0, 3, 700]))]
+        v["pending_consolidations"] = [{"source_index": rnd.randrange(1 << 40), "target_index": rnd.randrange(1 << 40)}
+                                       for _ in range(rnd.choice([0, 2, 64] if small else [1, 300]))]
     t = O.BeaconState(fork, O.MINIMAL if f["_preset"] == "minimal" else O.MAINNET)
     return t, {n: v[n] for n, _ in t.fields}
 
 
-@pytest.mark.parametrize("fork", ["phase0", "altair", "bellatrix", "capella", "deneb"])
+@pytest.mark.parametrize("fork", ["phase0", "altair", "bellatrix", "capella", "deneb", "electra"])
 def test_beacon_state_root_of_every_fork(gpu, fork):
     """hash_tree_root(BeaconState) for phase0 / altair / bellatrix / capella / deneb, both presets,
     against the oracle's independent restatement of each fork's container (oracle/ssz.py BeaconState); the encodings are the
@@ -424,7 +437,7 @@ def test_beacon_state_root_of_every_fork(gpu, fork):
     from ethereum_consensus_amd import synthetic
     from oracle import ssz as O
     ssz = gpu
-    rnd = random.Random({"phase0": 1, "altair": 2, "bellatrix": 3, "capella": 4, "deneb": 5}[fork])
+    rnd = random.Random({"phase0": 1, "altair": 2, "bellatrix": 3, "capella": 4, "deneb": 5, "electra": 6}[fork])
     for preset_name, preset, n in (("minimal", ssz.MINIMAL, 37), ("mainnet", ssz.MAINNET, 300), ("minimal", ssz.MINIMAL, 0)):
         f = synthetic.state_fields(n, preset_name, seed=rnd.randrange(1000), extra_data=rnd.randbytes(rnd.choice([0, 5, 32])))
         f["_preset"] = preset_name
@@ -443,8 +456,8 @@ def test_beacon_state_root_of_every_fork(gpu, fork):
     bad[pos] ^= 1
     with pytest.raises(ssz.MerkleizationError):
         ssz.hash_tree_root_beacon_state(fork, bytes(bad), ssz.MINIMAL)
-    if fork in ("bellatrix", "capella", "deneb"):
-        hdr_fixed = {"bellatrix": 536, "capella": 568, "deneb": 584}[fork]
+    if fork in ("bellatrix", "capella", "deneb", "electra"):
+        hdr_fixed = {"bellatrix": 536, "capella": 568, "deneb": 584, "electra": 648}[fork]
         t = O.BeaconState(fork, O.MINIMAL)
         names = [n for n, _ in t.fields]
         # the payload header starts at the offset stored in its slot of the fixed part

@@ -130,6 +130,26 @@ def test_beacon_state_deneb_plan(preset, n):
     assert hashes > 8 * n
 
 
+@pytest.mark.parametrize("fork", ["altair", "bellatrix", "capella", "deneb", "electra"])
+def test_beacon_state_plan_of_every_fork(fork):
+    """csrc/state_plan.h for altair .. electra on the lane simulator == the oracle's container of that fork
+    (oracle/ssz.py BeaconState; electra: 37 fields in a 64-leaf container, a 19-field payload header, three lists of two- /
+    three-uint64 containers: electra/beacon_state.rs:73-145), both presets, empty / short / tile-sized pending lists."""
+    import random
+    from ethereum_consensus_amd import synthetic as S
+    from tests.test_gpu_merkle import _fork_state_value
+    fork_id = {"altair": 1, "bellatrix": 2, "capella": 3, "deneb": 4, "electra": 5}[fork]
+    rnd = random.Random(100 + fork_id)
+    for preset, n in (("minimal", 0), ("minimal", 37), ("mainnet", 5), ("minimal", 3), ("mainnet", 2)):
+        f = S.state_fields(n, preset, seed=n + 11, extra_data=b"y" * (n % 33))
+        f["_preset"] = preset
+        t, v = _fork_state_value(fork, f, rnd)
+        enc = t.serialize(v)
+        rc, root, hashes = hs.state_root_fork(fork_id, enc, S.PRESETS[preset]["id"])
+        assert rc == 0 and root == t.htr(v), (fork, preset, n)
+    assert hs.state_root_fork(fork_id, enc[:200], S.PRESETS[preset]["id"])[0] == -3
+
+
 def test_beacon_state_plan_rejects_malformed():
     from ethereum_consensus_amd import synthetic as S
     enc = bytearray(S.beacon_state_deneb(3, "minimal"))
