@@ -681,13 +681,47 @@ uint64_t ecgpu_beacon_state_fixed_size(int fork, int preset) {
     return layout_for(STATE_PRESETS[preset], fork).size;
 }
 
+static int pending_attestations_root(const u8* ssz, u64 n_bytes, int preset, u8 root[32]);
+
+// phase0 through the device entry ("missing" 4): the two PendingAttestation lists hold variable-size elements
+// whose offset tables are part of the encoding, and the plan of such a list is built from those tables -- on the host.  They
+// are the LAST two variable fields of a phase0 state (phase0/beacon_state.rs:80-81) and small (<= 4 096 attestations of a few
+// hundred bytes), so the entry copies that tail of the encoding back ONCE (one synchronisation of the stream: the phase0
+// form is not fully asynchronous, include/ecgpu.h says so), roots the two lists through the generic planner, and hands the two
+// nodes to the device plan like the host entry does.
+static int phase0_attestation_roots_dev(hipStream_t s, const u8* d_ssz, u64 n_bytes, const u8* h_fixed, int preset, u8 ext[64]) {
+    if (preset < 0 || preset > 1) return ECGPU_ERR_BAD_ARG;
+    const FixedLayout L = layout_for(STATE_PRESETS[preset], FORK_PHASE0);
+    if (n_bytes < L.size) {
+        set_last_error("state encoding shorter than its fixed part");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    const u64 a = rd32(h_fixed + L.prev_attestations_off), b = rd32(h_fixed + L.cur_attestations_off);
+    if (a > b || b > n_bytes || a < L.size) {
+        set_last_error("SSZ offsets not monotonic");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    std::vector<u8> tail(n_bytes - a ? n_bytes - a : 1);
+    if (n_bytes - a) ECG_HIP_CHECK(hipMemcpyAsync(tail.data(), d_ssz + a, n_bytes - a, hipMemcpyDeviceToHost, s));
+    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    int rc = pending_attestations_root(tail.data(), b - a, preset, ext);
+    if (rc) return rc;
+    return pending_attestations_root(tail.data() + (b - a), n_bytes - b, preset, ext + 32);
+}
+
 int ecgpu_htr_beacon_state_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset, uint8_t* d_root,
                                ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (!d_ssz || !h_fixed || !d_root || fork < FORK_ALTAIR || fork > FORK_LAST) return ECGPU_ERR_BAD_ARG;
+    if (!d_ssz || !h_fixed || !d_root || fork < FORK_PHASE0 || fork > FORK_LAST) return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
+    if (fork == FORK_PHASE0) {
+        u8 ext[64];
+        if ((rc = phase0_attestation_roots_dev(s, d_ssz, n_bytes, h_fixed, preset, ext))) return rc;
+        // (the generic planner used this thread's own stream and arena; the caller's stream is idle here)
+        return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork, ext);
+    }
     return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork);
 }
 

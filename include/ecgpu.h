@@ -112,9 +112,10 @@ int ecgpu_htr_beacon_state_deneb_dev(const uint8_t* d_ssz, uint64_t n_bytes, con
 uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);
 /* The same for every fork the reference defines up to deneb: phase0/beacon_state.rs:50-88 (21 fields),
  * altair/beacon_state.rs:13-55 (24), bellatrix/beacon_state.rs:13-58 (25), capella/beacon_state.rs:13-64 (28),
- * deneb/beacon_state.rs:13-64 (28).  The host-pointer entry takes any fork; phase0 states hold two lists of variable-size
- * elements (PendingAttestation), whose offset tables live in the encoding itself, so the device-resident forms
- * (_dev, resident states) start at altair. */
+ * deneb/beacon_state.rs:13-64 (28).  The host-pointer entry takes any fork.  phase0 states hold two lists of variable-size
+ * elements (PendingAttestation) whose offset tables live in the encoding itself: ecgpu_htr_beacon_state_dev(phase0) copies those
+ * two lists -- the tail of the encoding, KBs to ~1 MB -- back to the host once (ONE synchronisation of the stream; every other
+ * fork is fully asynchronous) and plans them there; the checked / sharded forms and resident states start at altair. */
 #define ECGPU_FORK_PHASE0 0
 #define ECGPU_FORK_ALTAIR 1
 #define ECGPU_FORK_BELLATRIX 2

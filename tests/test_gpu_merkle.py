@@ -493,6 +493,33 @@ def test_beacon_state_root_of_every_fork(gpu, fork):
             assert bytes(out.cpu().numpy()) == want and int(status.item()) == (0 if blob is enc else -3)
 
 
+@pytest.mark.parametrize("fork", ["phase0", "altair", "bellatrix", "capella", "deneb", "electra"])
+def test_device_entry_of_every_fork(gpu, fork):
+    """ecgpu_htr_beacon_state_dev from phase0 (whose two PendingAttestation lists are copied back and planned on the host: one
+    synchronisation, include/ecgpu.h) to electra: the root of a device-resident encoding equals the oracle's"""
+    import random
+    import torch
+    from ethereum_consensus_amd import synthetic
+    ssz = gpu
+    L = ssz._lib.load()
+    rnd = random.Random(40 + ssz.FORKS[fork])
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    for preset_name, preset, n in (("minimal", ssz.MINIMAL, 37), ("mainnet", ssz.MAINNET, 9), ("minimal", ssz.MINIMAL, 0)):
+        f = synthetic.state_fields(n, preset_name, seed=rnd.randrange(1000))
+        f["_preset"] = preset_name
+        t, v = _fork_state_value(fork, f, rnd)
+        enc = t.serialize(v)
+        fixed = L.ecgpu_beacon_state_fixed_size(ssz.FORKS[fork], preset)
+        d = torch.frombuffer(bytearray(enc), dtype=torch.uint8).cuda()
+        h_fixed = ctypes.create_string_buffer(bytes(enc[:fixed]), fixed)
+        out.zero_()
+        rc = L.ecgpu_htr_beacon_state_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, out.data_ptr(), st)
+        assert rc == 0, (rc, L.ecgpu_last_error())
+        torch.cuda.synchronize()
+        assert bytes(out.cpu().numpy()) == t.htr(v), (fork, preset_name, n)
+
+
 def test_resident_state_of_an_older_fork(gpu):
     """a capella state kept resident: patches + roots equal the from-scratch roots of the patched encoding"""
     import random

@@ -22,6 +22,9 @@ if "box_selfcheck" in d:
     print("  box slowdown", round(d["box_selfcheck"]["large_code_slowdown"], 2), d["box_selfcheck"]["pairing_kernels"])
 if "merkle" in d and d["merkle"].get("h2d_inclusive"):
     print("  merkle incl. H2D", {k: round(v, 2) for k, v in d["merkle"]["h2d_inclusive"].items() if k.endswith("_ms")})
+if "merkle" in d and d["merkle"].get("two_roots_in_flight"):
+    t = d["merkle"]["two_roots_in_flight"]
+    print("  merkle, two roots in flight: %.3f ms per root  %.4g leaves/s  %s" % (t["ms_per_root"], t["leaves_per_s"], t["roots_equal_the_one_stream_root"]))
 if "cpu_baseline" in d:
     c = d["cpu_baseline"]
     print("  cpu", round(c["value"]), c["unit"], "cores", c.get("cores"), c.get("cores_effective"))
