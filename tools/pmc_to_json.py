@@ -1,5 +1,5 @@
-"""profiles/pmc_traffic.json from the two rocprofv3 --pmc passes of tools/gpu_visit.sh (step `pmc`): per bench step, the sum of
-FETCH_SIZE / WRITE_SIZE (KiB) over the launches of each dominant kernel.  usage: pmc_to_json.py TAG N_STEPS_IN_PMC_RUN"""
+"""profiles/pmc_traffic.json from the two rocprofv3 --pmc passes of tools/gpu_visit.sh (step `pmc`): per LAUNCH, the mean of
+FETCH_SIZE / WRITE_SIZE (KiB) over the dispatches of each dominant kernel.  usage: pmc_to_json.py TAG N_STEPS_IN_PMC_RUN"""
 import csv
 import glob
 import json
@@ -40,7 +40,8 @@ def main(tag, n_steps, only=None):
         f, nf = total(f"gpurun_out/pmc_{tag}_FETCH_SIZE", "FETCH_SIZE", needle)
         w, nw = total(f"gpurun_out/pmc_{tag}_WRITE_SIZE", "WRITE_SIZE", needle)
         if nf and nw:
-            out[key] = {"fetch_kib": f / n_steps, "write_kib": w / n_steps, "launches_per_step": nf / n_steps, "src_hash": src_hash(key),
+            # per LAUNCH (mean over the dispatches of the run): bench.py's roofline.traffic is quoted per launch like `achieved`
+            out[key] = {"fetch_kib": f / nf, "write_kib": w / nw, "launches_in_run": nf, "src_hash": src_hash(key),
                         "source": f"profiles/{tag}{'_merkle' if only == 'merkle' else ''}_pmc_FETCH_SIZE.txt, profiles/{tag}{'_merkle' if only == 'merkle' else ''}_pmc_WRITE_SIZE.txt (rocprofv3 --pmc, one counter per "
                                   f"pass, bench.py over {n_steps} steps incl. warm-up)"}
     json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
