@@ -464,6 +464,10 @@ static const bool g_split_default = [] {
     const char* e = getenv("ECGPU_SPLIT_DEFAULT");
     return e ? atoi(e) != 0 : false;
 }();
+static const int g_h2c_finish_lanes = [] {  // ECGPU_H2C_FINISH_LANES=1: the one-lane end of the small-batch message stage (round 3)
+    const char* e = getenv("ECGPU_H2C_FINISH_LANES");
+    return e ? atoi(e) : 2;
+}();
 static const u32 g_vm_max_tuples = [] {
     const char* e = getenv("ECGPU_VM_MAX");
     return e ? (u32)strtoul(e, nullptr, 10) : 24576u;
@@ -550,7 +554,12 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         const bool calls = g_tower.load() == 2;
         if (h2c_maps) {  // two lanes per message while that still leaves SIMDs idle
             hipLaunchKernelGGL(calls ? k_h2c_map_calls : k_h2c_map, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, h2c_maps);
-            hipLaunchKernelGGL(calls ? k_h2c_finish_calls : k_h2c_finish, grid_for(n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
+            // ... and its end -- the addition of the two maps, the cofactor clearing, the affine conversion: a 3.5 ms chain on
+            // one lane -- on a lane PAIR (bls_g2_pair2.h): half the Fp2 components, 0.57 of the instructions, per lane
+            if (calls || g_h2c_finish_lanes == 1)
+                hipLaunchKernelGGL(calls ? k_h2c_finish_calls : k_h2c_finish, grid_for(n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
+            else
+                hipLaunchKernelGGL(k_h2c_finish2, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
         } else {
             hipLaunchKernelGGL(calls ? k_h2c_calls : k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
         }

@@ -12,6 +12,7 @@
 #include "bls_vm3.h"
 #include "bls_vm3_prog.h"
 #include "bls_pair2.h"
+#include "bls_g2_pair2.h"
 #include <atomic>
 
 using namespace ecg;
@@ -226,6 +227,29 @@ void hs_hash_to_g2_split(const u8* msg, u64 len, u8* xy, int* inf) {
     hash_to_g2_map(q1, msg, (size_t)len, 1);
     A2 h;
     hash_to_g2_finish(h, q0, q1);
+    out_a2(h, xy);
+    *inf = (int)h.inf;
+}
+// the two-lanes-per-message end of the message stage (bls_g2_pair2.h, k_h2c_finish2): the two maps on one lane each, then the
+// addition, the cofactor clearing and the affine conversion on a lane PAIR -- two host threads in lock step
+void hs_hash_to_g2_pair2(const u8* msg, u64 len, u8* xy, int* inf) {
+    J2 q0, q1;
+    hash_to_g2_map(q0, msg, (size_t)len, 0);
+    hash_to_g2_map(q1, msg, (size_t)len, 1);
+    PairChannel ch;
+    std::memset(&ch, 0, sizeof(ch));
+    g_pair_arrivals[0] = 0;
+    g_pair_arrivals[1] = 0;
+    A2 h;
+    std::memset(&h, 0, sizeof(h));
+    auto lane = [&](u32 s) {
+        t_pair_channel = &ch;
+        t_pair_lane = s;
+        h_hash_to_g2_finish(&h, q0, q1);
+    };
+    std::thread t1(lane, 1u);
+    lane(0u);
+    t1.join();
     out_a2(h, xy);
     *inf = (int)h.inf;
 }

@@ -304,6 +304,9 @@ def test_expand_message_and_hash_to_g2():
         xy2 = ctypes.create_string_buffer(192)  # the two-lanes-per-message form of small batches
         L.hs_hash_to_g2_split(msg, len(msg), xy2, ctypes.byref(inf))
         assert xy2.raw == xy.raw
+        xy3 = ctypes.create_string_buffer(192)  # ... whose second half runs on a lane PAIR (k_h2c_finish2, bls_g2_pair2.h)
+        L.hs_hash_to_g2_pair2(msg, len(msg), xy3, ctypes.byref(inf))
+        assert xy3.raw == xy.raw and inf.value == 0
     # crypto/bls.rs:530-544 test_can_sign through the lane programs: [sk] H(msg) compressed
     xy = ctypes.create_string_buffer(192)
     inf = ctypes.c_int(0)
