@@ -339,6 +339,7 @@ def run_merkle_sharded(args, L, torch, dist, rank, world, emulate_world=None):
     d_all = torch.zeros(32 * nl * w_eff, dtype=torch.uint8, device=dev)
     d_root = torch.zeros(32, dtype=torch.uint8, device=dev)
     d_ref = torch.zeros(32, dtype=torch.uint8, device=dev)
+    d_keep = torch.zeros(64 * 32, dtype=torch.uint8, device=dev)  # the other fields' roots: phase A leaves them, phase B takes them
     stream = _stream(torch)
 
     def chk(rc, what):
@@ -354,17 +355,17 @@ def run_merkle_sharded(args, L, torch, dist, rank, world, emulate_world=None):
         if emulate_world:
             for r in range(emulate_world):
                 chk(L.ecgpu_beacon_state_shard_subroots_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, r, emulate_world,
-                                                            d_all.data_ptr() + 32 * nl * r, stream), "ecgpu_beacon_state_shard_subroots_dev")
+                                                            d_all.data_ptr() + 32 * nl * r, d_keep.data_ptr(), stream), "ecgpu_beacon_state_shard_subroots_dev")
             gathered = d_all
         else:
-            chk(L.ecgpu_beacon_state_shard_subroots_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, rank, world, d_sub.data_ptr(), stream),
-                "ecgpu_beacon_state_shard_subroots_dev")
+            chk(L.ecgpu_beacon_state_shard_subroots_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, rank, world, d_sub.data_ptr(),
+                                                        d_keep.data_ptr(), stream), "ecgpu_beacon_state_shard_subroots_dev")
             hashes["a"] = int(L.ecgpu_last_hash64_count())
             # the path's only collective: 160 bytes per rank
             from ethereum_consensus_amd import shard
             gathered = shard.all_gather_bytes(dist, d_sub, world, force=FORCE_DIST) if _multi(dist, world) else d_sub
-        chk(L.ecgpu_htr_beacon_state_sharded_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, gathered.data_ptr(), w_eff, d_root.data_ptr(), stream),
-            "ecgpu_htr_beacon_state_sharded_dev")
+        chk(L.ecgpu_htr_beacon_state_sharded_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, gathered.data_ptr(), w_eff, d_keep.data_ptr(),
+                                                 d_root.data_ptr(), stream), "ecgpu_htr_beacon_state_sharded_dev")
         hashes["b"] = int(L.ecgpu_last_hash64_count())
         return gathered
 
@@ -382,6 +383,30 @@ def run_merkle_sharded(args, L, torch, dist, rank, world, emulate_world=None):
         dist.barrier()
     dt = time.perf_counter() - t0
     del keep
+    # the two phases on their own (this rank's phase A; phase B), a few repetitions each: what an N-rank run adds to their sum is
+    # the all-gather
+    phases = None
+    if DEV == "cuda":
+        def timed(fn, reps=5):
+            fn()
+            _sync(torch)
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            _sync(torch)
+            return (time.perf_counter() - t) / reps * 1e3
+        r_a, w_a = (0, emulate_world) if emulate_world else (rank, world)
+        a_ms = timed(lambda: chk(L.ecgpu_beacon_state_shard_subroots_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, r_a, w_a,
+                                                                        d_sub.data_ptr(), d_keep.data_ptr(), stream), "phase A"))
+        g_all = d_all if (emulate_world or world > 1 or FORCE_DIST) else d_sub
+        if not emulate_world and (world > 1 or FORCE_DIST):
+            from ethereum_consensus_amd import shard as _sh
+            g_all = _sh.all_gather_bytes(dist, d_sub, world, force=FORCE_DIST)
+        b_ms = timed(lambda: chk(L.ecgpu_htr_beacon_state_sharded_dev(fork, d_state.data_ptr(), len(enc), h_fixed, 0, g_all.data_ptr(), w_eff,
+                                                                     d_keep.data_ptr(), d_root.data_ptr(), stream), "phase B"))
+        phases = {"phase_a_ms_this_rank": a_ms, "phase_b_ms": b_ms,
+                  "note": "each phase alone, enqueue to completion; phase A = this rank's subtrees of the five lists + every other "
+                          "field, phase B = the five list tops + the state container"}
     root = bytes(d_root.cpu().numpy())
     ref = bytes(d_ref.cpu().numpy())
     same = root == ref
@@ -392,11 +417,13 @@ def run_merkle_sharded(args, L, torch, dist, rank, world, emulate_world=None):
                 "hash64_per_state": hashes_unsharded, "hash64_this_rank_phase_a": hashes["a"], "hash64_every_rank_phase_b": hashes["b"],
                 "state_bytes": len(enc),
                 "sharding": "the five registry-sized lists (validators, balances, 2 x participation, inactivity_scores) as aligned "
-                            "power-of-two subtrees per rank; all-gather of 5 x 32 bytes per rank; the list tops, the other fields and "
-                            "the root redundantly on every rank"},
+                            "power-of-two subtrees per rank, the other fields redundantly on every rank underneath its validator pass "
+                            "(phase A); all-gather of 5 x 32 bytes per rank; the five list tops and the state container on every rank "
+                            "(phase B)"},
         roofline={"bound": "hbm", "kernel": "k_merkle_pass<2, ValidatorLeaves>", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": None, "traffic": None, "note": "latency-bound at N > 1: see the N = 1 `merkle` record for the pass kernel's roofline"},
         check={"root": root.hex(), "equals_unsharded_root": same},
+        extra={"phases": phases} if phases else {},
     )
 
 
@@ -1095,7 +1122,7 @@ def multi_gpu_preflight(L, torch, dist, rank, world, local):
     return out
 
 
-def sub_record(line, keys=("metric", "value", "unit", "ms_per_step", "steps", "scaling", "dtype", "config", "roofline", "check")):
+def sub_record(line, keys=("metric", "value", "unit", "ms_per_step", "steps", "scaling", "dtype", "config", "roofline", "check", "phases")):
     out = {k: line[k] for k in keys if k in line}
     for k in ("validated_key_registry", "aggregates_per_s"):
         if k in line:

@@ -65,8 +65,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_htr_beacon_state_dev": (c_int, [c_int, u8p, c_u64, u8p, c_int, u8p, ctypes.c_void_p]),
         "ecgpu_beacon_state_fixed_size": (c_u64, [c_int, c_int]),
         "ecgpu_htr_beacon_state_dev_checked": (c_int, [c_int, u8p, c_u64, u8p, c_int, u8p, ctypes.c_void_p, ctypes.c_void_p]),
-        "ecgpu_beacon_state_shard_subroots_dev": (c_int, [c_int, u8p, c_u64, u8p, c_int, c_u32, c_u32, u8p, ctypes.c_void_p]),
-        "ecgpu_htr_beacon_state_sharded_dev": (c_int, [c_int, u8p, c_u64, u8p, c_int, u8p, c_u32, u8p, ctypes.c_void_p]),
+        "ecgpu_beacon_state_shard_subroots_dev": (c_int, [c_int, u8p, c_u64, u8p, c_int, c_u32, c_u32, u8p, u8p, ctypes.c_void_p]),
+        "ecgpu_htr_beacon_state_sharded_dev": (c_int, [c_int, u8p, c_u64, u8p, c_int, u8p, c_u32, u8p, u8p, ctypes.c_void_p]),
         "ecgpu_beacon_state_shard_lists": (c_u32, []),
         "ecgpu_resident_state_create_fork": (c_int, [c_int, c_int, u8p, c_u64, ctypes.POINTER(ctypes.c_void_p)]),
         "ecgpu_last_hash64_count": (c_u64, []),

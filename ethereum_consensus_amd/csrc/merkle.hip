@@ -225,7 +225,8 @@ __device__ __forceinline__ void tail_gather(const TailPlan& P, u8* buf, u64 off,
     for (u32 i = threadIdx.x; i < P.n_gathers; i += blockDim.x) {
         const GatherDesc g = P.gathers[i];
         if (g.dst_chunk >= c0 && g.dst_chunk < c0 + n)
-            gather_chunk(g.src_sel ? P.ext_src : P.src, g.src_sel ? P.ext_total : P.src_total, g, buf + P.small_off);
+            gather_chunk(g.src_sel == 2 ? P.ext2_src : g.src_sel ? P.ext_src : P.src,
+                         g.src_sel == 2 ? 32ull * STATE_MAX_FIELD_CHUNKS : g.src_sel ? P.ext_total : P.src_total, g, buf + P.small_off);
     }
     __syncthreads();
 }

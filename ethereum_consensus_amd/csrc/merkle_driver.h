@@ -95,6 +95,7 @@ struct TailPlan {
     u64 chk_off;                        // != ~0: the little-endian u32 at src + chk_off must equal chk_expect, else the root is 32 x 0xFF
     const u8* ext_src;                  // gathers with src_sel == 1 read here (ext_total bytes): nodes computed elsewhere
     u64 ext_total;
+    const u8* ext2_src;                 // gathers with src_sel == 2: the field-root block phase A of a sharded root left (64 x 32 bytes)
     int* d_status;                      // may be null: 0 / ECGPU_ERR_BAD_ARG next to the root, see ecgpu_htr_beacon_state_dev_checked
 };
 int launch_state_tail(hipStream_t s, const TailPlan* d_plan, u32 n_wgs, u8* d_buf);

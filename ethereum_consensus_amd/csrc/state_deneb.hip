@@ -42,13 +42,16 @@ static u64 shard_width(u64 n0, u32 world) {
     return 1ull << ceil_log2_u64(per);
 }
 struct ShardTop {
-    const u8* d_all;  // world x 5 x 32 bytes, rank-major: what the all-gather of the phase-A outputs leaves on every rank
+    const u8* d_all;   // world x 5 x 32 bytes, rank-major: what the all-gather of the phase-A outputs leaves on every rank
     u32 world;
+    const u8* d_keep;  // may be null.  The field roots phase A left behind (64 x 32 bytes): phase B then hashes nothing but the
+                       // five list tops and the state container -- the other fields ran underneath phase A's validator pass
 };
+constexpr u32 SHARD_FIELD_SLOTS[N_SHARDED_LISTS] = {11, 12, 15, 16, 21};
 
 static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, StatePlan& plan, int fork, bool dev_check,
                           u8* d_root, const u8* d_vroots, const u8* ext_roots, u8* d_field_roots, int* d_status, const u8* ext_src,
-                          u64 ext_total);
+                          u64 ext_total, const u8* ext2_src = nullptr);
 
 // d_vroots != nullptr (resident state): the 32-byte hash_tree_root of every validator record is cached there and kept
 // current by the caller, so the registry enters the tree as a list of 2^20 ready chunks (1.0 M hash64) instead of 121-byte
@@ -96,28 +99,71 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
             if (b.mix) plan.small_hashes++;
         }
         plan.bigs.swap(keep);
+        if (shard->d_keep) {
+            // ... and with phase A's field roots handed in, every OTHER field leaves it too: their roots are copied from that
+            // block into the field slots (one gathered chunk each), and what is left to hash is the five list tops above and
+            // the state container
+            StatePlan top;
+            top.n_small_chunks = plan.n_small_chunks;
+            top.root_chunk = plan.root_chunk;
+            top.payload_header_off = plan.payload_header_off;
+            for (const GatherDesc& g : plan.gathers)
+                if (g.src_sel == 1) top.gathers.push_back(g);
+            const u32 nf = state_field_count(fork);
+            for (u32 f = 0; f < nf; f++) {
+                bool deep = false;
+                for (u32 k = 0; k < N_SHARDED_LISTS; k++) deep = deep || SHARD_FIELD_SLOTS[k] == f;
+                if (!deep) top.gathers.push_back({32ull * f, 32u, f, 0u, 2u});
+            }
+            const size_t n_tops = N_SHARDED_LISTS;
+            top.jobs[0].assign(plan.jobs[0].end() - n_tops, plan.jobs[0].end());
+            top.jobs[2] = plan.jobs[2];
+            top.small_hashes = 0;
+            for (const TreeJob& j : top.jobs[0]) top.small_hashes += (j.n ? j.n - 1 + (j.depth - j.level) : 0) + j.mix;  // an upper bound
+            top.small_hashes += state_field_chunks(fork) - 1;
+            plan = top;
+        }
     }
     const bool dev_check = fork >= FORK_BELLATRIX && !h_payload_fixed && plan.payload_header_off != ~0ull;
     return run_state_plan(s, c, d_ssz, n_bytes, plan, fork, dev_check, d_root, d_vroots, ext_roots, d_field_roots, d_status,
-                          shard ? shard->d_all : nullptr, shard ? 32ull * N_SHARDED_LISTS * shard->world : 0);
+                          shard ? shard->d_all : nullptr, shard ? 32ull * N_SHARDED_LISTS * shard->world : 0, shard ? shard->d_keep : nullptr);
 }
 
-// phase A of a sharded state root: this rank's subtree of each of the five lists -> d_subroots[5 x 32]
+// phase A of a sharded state root: this rank's subtree of each of the five lists -> d_subroots[5 x 32].  With d_keep (64 x 32
+// bytes, the caller's) the rank also computes every OTHER field of the state in the same launches -- their tile stages and
+// chains run underneath its validator pass -- and leaves the field roots there for phase B, which then only climbs the five
+// list tops and hashes the container: what stands between the all-gather and the root is ~30 dependent hash64, not a state's tail.
 static int state_shard_subroots_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, const u8* h_fixed, int preset,
-                                       int fork, u32 rank, u32 world, u8* d_subroots) {
+                                       int fork, u32 rank, u32 world, u8* d_subroots, u8* d_keep) {
     StatePlan full;
     if (!build_state_plan(fork, h_fixed, n_bytes, preset, full, nullptr, nullptr)) {
         set_last_error(full.error);
         return ECGPU_ERR_BAD_ARG;
     }
-    StatePlan plan;
-    for (const BigField& b : full.bigs) {
-        const int f = sharded_list_index(b);
-        if (f < 0) continue;
+    auto restricted = [&](const BigField& b, u32 out_chunk) {
         const u64 W = shard_width(b.n0, world), rec = leaf_record_bytes(b.kind);
         const u64 lo = std::min<u64>((u64)rank * W, b.n0), hi = std::min<u64>(((u64)rank + 1) * W, b.n0);
         const u64 lo_b = std::min<u64>(lo * rec, b.bytes), hi_b = std::min<u64>(hi * rec, b.bytes);  // a packed list's last chunk may be partial
-        plan.bigs.push_back({b.kind, b.src + lo_b, hi_b - lo_b, hi - lo, ceil_log2_u64(W), false, 0, (u32)f});
+        return BigField{b.kind, b.src + lo_b, hi_b - lo_b, hi - lo, ceil_log2_u64(W), false, 0, out_chunk};
+    };
+    if (!c->small_scratch) ECG_HIP_CHECK(hipMalloc((void**)&c->small_scratch, 4096));
+    u8* d_sc = c->small_scratch;  // <= 2 KB field-root block + the 32-byte root of a container nobody reads
+    if (d_keep) {
+        // the whole state plan, the five lists cut down to this rank's subtrees (their field slots then hold SUB-roots, the
+        // container job a root nobody reads)
+        for (BigField& b : full.bigs)
+            if (sharded_list_index(b) >= 0) b = restricted(b, b.out_chunk);
+        full.small_hashes = 0;  // (work accounting of this form: the big fields only)
+        int rc = run_state_plan(s, c, d_ssz, n_bytes, full, fork, false, d_sc + 2048, nullptr, nullptr, d_keep, nullptr, nullptr, 0);
+        if (rc) return rc;
+        for (u32 k = 0; k < N_SHARDED_LISTS; k++)
+            ECG_HIP_CHECK(hipMemcpyAsync(d_subroots + 32 * k, d_keep + 32 * SHARD_FIELD_SLOTS[k], 32, hipMemcpyDeviceToDevice, s));
+        return ECGPU_SUCCESS;
+    }
+    StatePlan plan;
+    for (const BigField& b : full.bigs) {
+        const int f = sharded_list_index(b);
+        if (f >= 0) plan.bigs.push_back(restricted(b, (u32)f));
     }
     // the fused tail ends in a container job: here a 5-leaf tree over the sub-roots, whose root nobody reads
     Builder B;
@@ -128,8 +174,6 @@ static int state_shard_subroots_device(hipStream_t s, ThreadCtx* c, const u8* d_
     plan.root_chunk = root_chunk;
     plan.small_hashes = B.hashes;
     // the field-root chunks of the small buffer are handed back whole (d_field_roots); the first five are the sub-roots
-    if (!c->small_scratch) ECG_HIP_CHECK(hipMalloc((void**)&c->small_scratch, 4096));
-    u8* d_sc = c->small_scratch;  // <= 2 KB field-root block + the 32-byte root of the dummy container
     int rc = run_state_plan(s, c, d_ssz, n_bytes, plan, fork, false, d_sc + 2048, nullptr, nullptr, d_sc, nullptr, nullptr, 0);
     if (rc) return rc;
     ECG_HIP_CHECK(hipMemcpyAsync(d_subroots, d_sc, 32 * N_SHARDED_LISTS, hipMemcpyDeviceToDevice, s));
@@ -138,11 +182,7 @@ static int state_shard_subroots_device(hipStream_t s, ThreadCtx* c, const u8* d_
 
 static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, StatePlan& plan, int fork, bool dev_check,
                           u8* d_root, const u8* d_vroots, const u8* ext_roots, u8* d_field_roots, int* d_status, const u8* ext_src,
-                          u64 ext_total) {
-    if (plan.bigs.empty()) {
-        set_last_error("state plan without a big field");
-        return ECGPU_ERR_BAD_ARG;
-    }
+                          u64 ext_total, const u8* ext2_src) {
     std::vector<const u8*> fptr(plan.bigs.size());
     for (size_t i = 0; i < plan.bigs.size(); i++) {
         BigField& b = plan.bigs[i];
@@ -192,7 +232,8 @@ static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_by
         if (plan.bigs[i].bytes > plan.bigs[biggest].bytes) biggest = i;
     static TailPlan tp_init{};
     TailPlan tp = tp_init;
-    std::vector<size_t> order{biggest};
+    std::vector<size_t> order;  // (a plan may have no big field at all: phase B of a sharded root with the field roots handed in)
+    if (!plan.bigs.empty()) order.push_back(biggest);
     for (size_t i = 0; i < plan.bigs.size(); i++)
         if (i != biggest) order.push_back(i);
     std::vector<u8*> wss;
@@ -289,6 +330,7 @@ static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_by
     tp.chk_expect = (u32)payload_header_fixed(fork);
     tp.ext_src = ext_src;
     tp.ext_total = ext_total;
+    tp.ext2_src = ext2_src;
     tp.d_status = d_status;
     // the block: plan, zero tickets, descriptors, zero chunks (+ phase0: the two list roots the generic planner computed)
     u8* h_block;
@@ -736,25 +778,27 @@ int ecgpu_htr_beacon_state_dev_checked(int fork, const uint8_t* d_ssz, uint64_t 
 }
 
 int ecgpu_beacon_state_shard_subroots_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
-                                          uint32_t rank, uint32_t world, uint8_t* d_subroots, ecgpu_stream_t stream) {
+                                          uint32_t rank, uint32_t world, uint8_t* d_subroots, uint8_t* d_field_roots,
+                                          ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!d_ssz || !h_fixed || !d_subroots || fork < FORK_ALTAIR || fork > FORK_LAST || !world || world > 512 || rank >= world)
         return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
-    return state_shard_subroots_device(s, c, d_ssz, n_bytes, h_fixed, preset, fork, rank, world, d_subroots);
+    return state_shard_subroots_device(s, c, d_ssz, n_bytes, h_fixed, preset, fork, rank, world, d_subroots, d_field_roots);
 }
 
 int ecgpu_htr_beacon_state_sharded_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
-                                       const uint8_t* d_all_subroots, uint32_t world, uint8_t* d_root, ecgpu_stream_t stream) {
+                                       const uint8_t* d_all_subroots, uint32_t world, const uint8_t* d_field_roots, uint8_t* d_root,
+                                       ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!d_ssz || !h_fixed || !d_all_subroots || !d_root || fork < FORK_ALTAIR || fork > FORK_LAST || !world || world > 512)
         return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
-    const ShardTop top{d_all_subroots, world};
+    const ShardTop top{d_all_subroots, world, d_field_roots};
     return state_root_device(s, c, d_ssz, n_bytes, h_fixed, preset, d_root, nullptr, fork, nullptr, nullptr, nullptr, nullptr, &top);
 }
 

@@ -139,7 +139,8 @@ struct GatherDesc {
     u32 dst_chunk;  // chunk index in the small-chunk buffer
     u32 last_and;   // 0: copy as is; else AND mask for the last copied byte (Bitlist delimiter removal)
     u32 src_sel;    // 0: src_off counts from the SSZ encoding; 1: from the caller's node buffer (sharded state roots: the sub-roots
-                    // of the registry-sized lists, all-gathered over the ranks -- merkle_driver.h TailPlan::ext_src)
+                    // of the registry-sized lists, all-gathered over the ranks -- merkle_driver.h TailPlan::ext_src); 2: from the
+                    // field-root block phase A of a sharded root left behind (TailPlan::ext2_src)
 };
 
 // A big field: reduced by the pass kernels straight from the encoding.

@@ -140,15 +140,21 @@ int ecgpu_htr_beacon_state_dev_checked(int fork, const uint8_t* d_ssz, uint64_t 
  * participation, inactivity_scores, 99 % of the hash64 -- are cut into aligned power-of-two subtrees, one per rank
  * (width = the smallest power of two with width * world >= leaves); everything else is computed by every rank.
  *   phase A  ecgpu_beacon_state_shard_subroots_dev: rank `rank` of `world` reduces its subtree of each list from the
- *            device-resident encoding (only its own byte ranges of the five lists are read) -> d_subroots: 5 x 32 bytes;
+ *            device-resident encoding (only its own byte ranges of the five lists are read) -> d_subroots: 5 x 32 bytes.
+ *            d_field_roots (64 x 32 bytes, may be NULL): the rank ALSO computes every other field of the state in the same
+ *            launches -- underneath its validator pass -- and leaves the field roots there for phase B;
  *   exchange all-gather the 160 bytes over the ranks (rank-major: d_all[rank][list]) -- the path's only collective;
  *   phase B  ecgpu_htr_beacon_state_sharded_dev: finishes the five lists from the gathered nodes (zero ladder to the list
- *            limit, length mix-in), computes the remaining fields and the state root.  world == 1 gives the plain root.
+ *            limit, length mix-in) and hashes the state container.  d_field_roots = what phase A left (then that is ALL it
+ *            hashes: ~30 dependent hash64 between the exchange and the root), or NULL: it computes the remaining fields
+ *            itself.  world == 1 gives the plain root.
  * fork >= altair, like the other device-resident forms. */
 int ecgpu_beacon_state_shard_subroots_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
-                                          uint32_t rank, uint32_t world, uint8_t* d_subroots, ecgpu_stream_t stream);
+                                          uint32_t rank, uint32_t world, uint8_t* d_subroots, uint8_t* d_field_roots,
+                                          ecgpu_stream_t stream);
 int ecgpu_htr_beacon_state_sharded_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
-                                       const uint8_t* d_all_subroots, uint32_t world, uint8_t* d_root, ecgpu_stream_t stream);
+                                       const uint8_t* d_all_subroots, uint32_t world, const uint8_t* d_field_roots,
+                                       uint8_t* d_root, ecgpu_stream_t stream);
 uint32_t ecgpu_beacon_state_shard_lists(void); /* 5: nodes per rank in the exchange */
 /* number of hash64 the last state root of this thread performed (work accounting for benches) */
 uint64_t ecgpu_last_hash64_count(void);

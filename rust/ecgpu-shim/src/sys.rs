@@ -77,9 +77,10 @@ extern "C" {
     pub fn ecgpu_htr_beacon_state_dev_checked(fork: c_int, d_ssz: *const u8, n_bytes: u64, h_fixed: *const u8, preset: c_int,
                                               d_root: *mut u8, d_status: *mut i32, stream: *mut core::ffi::c_void) -> c_int;
     pub fn ecgpu_beacon_state_shard_subroots_dev(fork: c_int, d_ssz: *const u8, n_bytes: u64, h_fixed: *const u8, preset: c_int,
-                                                 rank: u32, world: u32, d_subroots: *mut u8, stream: *mut core::ffi::c_void) -> c_int;
+                                                 rank: u32, world: u32, d_subroots: *mut u8, d_field_roots: *mut u8,
+                                                 stream: *mut core::ffi::c_void) -> c_int;
     pub fn ecgpu_htr_beacon_state_sharded_dev(fork: c_int, d_ssz: *const u8, n_bytes: u64, h_fixed: *const u8, preset: c_int,
-                                              d_all_subroots: *const u8, world: u32, d_root: *mut u8,
+                                              d_all_subroots: *const u8, world: u32, d_field_roots: *const u8, d_root: *mut u8,
                                               stream: *mut core::ffi::c_void) -> c_int;
     pub fn ecgpu_beacon_state_shard_lists() -> u32;
     pub fn ecgpu_thread_device() -> c_int;

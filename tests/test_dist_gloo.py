@@ -334,7 +334,7 @@ class _StateStub:
         self.last = 1000
         return 0
 
-    def ecgpu_beacon_state_shard_subroots_dev(self, fork, d_ssz, n_bytes, h_fixed, preset, rank, world, d_sub, stream):
+    def ecgpu_beacon_state_shard_subroots_dev(self, fork, d_ssz, n_bytes, h_fixed, preset, rank, world, d_sub, d_keep, stream):
         import ctypes
         self._check_state(d_ssz, n_bytes)
         out = b""
@@ -347,7 +347,7 @@ class _StateStub:
         self.last = 100
         return 0
 
-    def ecgpu_htr_beacon_state_sharded_dev(self, fork, d_ssz, n_bytes, h_fixed, preset, d_all, world, d_root, stream):
+    def ecgpu_htr_beacon_state_sharded_dev(self, fork, d_ssz, n_bytes, h_fixed, preset, d_all, world, d_keep, d_root, stream):
         import ctypes
         self._check_state(d_ssz, n_bytes)
         O = self.O

@@ -365,20 +365,24 @@ def test_one_beacon_state_sharded_over_emulated_ranks(gpu, fork):
         h_fixed = ctypes.create_string_buffer(bytes(enc[:fixed]), fixed)
         out = torch.zeros(32, dtype=torch.uint8, device="cuda")
         for world in (1, 2, 3, 8):
-            d_all = torch.full((32 * nl * world,), 0xAB, dtype=torch.uint8, device="cuda")
-            for rank in range(world):
-                rc = L.ecgpu_beacon_state_shard_subroots_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, rank, world,
-                                                             d_all.data_ptr() + 32 * nl * rank, st)
+            for keep in (False, True):  # phase B computes the other fields itself / takes the roots phase A left behind
+                d_all = torch.full((32 * nl * world,), 0xAB, dtype=torch.uint8, device="cuda")
+                d_keep = torch.full((64 * 32,), 0xCD, dtype=torch.uint8, device="cuda")
+                kp = d_keep.data_ptr() if keep else None
+                for rank in range(world):
+                    rc = L.ecgpu_beacon_state_shard_subroots_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, rank, world,
+                                                                 d_all.data_ptr() + 32 * nl * rank, kp, st)
+                    assert rc == 0, (rc, L.ecgpu_last_error())
+                out.zero_()
+                rc = L.ecgpu_htr_beacon_state_sharded_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, d_all.data_ptr(), world, kp,
+                                                          out.data_ptr(), st)
                 assert rc == 0, (rc, L.ecgpu_last_error())
-            rc = L.ecgpu_htr_beacon_state_sharded_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, d_all.data_ptr(), world,
-                                                      out.data_ptr(), st)
-            assert rc == 0, (rc, L.ecgpu_last_error())
-            torch.cuda.synchronize()
-            assert bytes(out.cpu().numpy()) == want, (fork, preset_name, n, world)
+                torch.cuda.synchronize()
+                assert bytes(out.cpu().numpy()) == want, (fork, preset_name, n, world, keep)
     # argument checks: rank outside the world, no ranks, phase0 (host entry only)
-    assert L.ecgpu_beacon_state_shard_subroots_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, 2, 2, d_all.data_ptr(), st) == -3
-    assert L.ecgpu_htr_beacon_state_sharded_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, d_all.data_ptr(), 0, out.data_ptr(), st) == -3
-    assert L.ecgpu_beacon_state_shard_subroots_dev(0, d.data_ptr(), len(enc), h_fixed, preset, 0, 1, d_all.data_ptr(), st) == -3
+    assert L.ecgpu_beacon_state_shard_subroots_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, 2, 2, d_all.data_ptr(), None, st) == -3
+    assert L.ecgpu_htr_beacon_state_sharded_dev(ssz.FORKS[fork], d.data_ptr(), len(enc), h_fixed, preset, d_all.data_ptr(), 0, None, out.data_ptr(), st) == -3
+    assert L.ecgpu_beacon_state_shard_subroots_dev(0, d.data_ptr(), len(enc), h_fixed, preset, 0, 1, d_all.data_ptr(), None, st) == -3
 
 
 def test_box_selfcheck_runs_and_reports_positive_times(gpu):

@@ -14,6 +14,8 @@ for key in ("aggregates_k2048", "merkle", "epoch", "slots", "strong_2p20", "merk
     if key in d:
         e = d[key]
         print("  %s: %.3f ms/step  %.4g %s  check %s" % (key, e.get("ms_per_step", 0), e.get("value", 0), e.get("unit"), e.get("check")))
+        if e.get("phases"):
+            print("      phases", {k: round(v, 3) for k, v in e["phases"].items() if k.endswith("_ms") or k.endswith("rank")})
 if "block" in d:
     print("  block", round(d["block"]["reference_semantics"]["block_verify_ms"], 2), round(d["block"]["validated_key_registry"]["block_verify_ms"], 2))
 if "msm" in d:
