@@ -464,6 +464,16 @@ static const bool g_split_default = [] {
     const char* e = getenv("ECGPU_SPLIT_DEFAULT");
     return e ? atoi(e) != 0 : false;
 }();
+static const int g_g2_waves = [] {  // ECGPU_G2_WAVES=1|2 forces the register budget of k_sig / k_h2c (default: 2 beyond 65 536 tuples)
+    const char* e = getenv("ECGPU_G2_WAVES");
+    return e ? atoi(e) : 0;
+}();
+// ECGPU_SIDE_OVERLAP=1 (experiment): the three side stages of a big K = 1 batch on three streams, the G2 ones in their two-wave
+// builds, so that a SIMD holds a wave of each
+static const int g_side_overlap = [] {
+    const char* e = getenv("ECGPU_SIDE_OVERLAP");
+    return e ? atoi(e) : 0;
+}();
 static const int g_h2c_finish_lanes = [] {  // ECGPU_H2C_FINISH_LANES=1: the one-lane end of the small-batch message stage (round 3)
     const char* e = getenv("ECGPU_H2C_FINISH_LANES");
     return e ? atoi(e) : 2;
@@ -518,7 +528,8 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     // half-register-file builds side by side are SLOWER -- key 3.0 + signature 5.1 + message 15.4 ms against 1.85 + 2.95 + 8.8,
     // two megabyte-sized instruction streams through one instruction cache: profiles/r02l_stage_overlap.txt).
     const bool key_heavy = d_pk_off && !reg && n_pks >= 4ull * n;
-    const bool fork = d_pk_off && (reg || key_heavy) && n <= 16384;
+    const bool overlap_sides = g_side_overlap != 0 && !d_pk_off && !reg && g_tower.load() != 2;  // experiment: see g_side_overlap
+    const bool fork = (d_pk_off && (reg || key_heavy) && n <= 16384) || overlap_sides;
     hipStream_t s2 = s, s3 = s;  // message stage / signature stage
     if (fork) {
         int rc = ax.init();
@@ -527,7 +538,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
         ECG_HIP_CHECK(hipStreamWaitEvent(s2, ax.fork, 0));
         ECG_HIP_CHECK(hipEventRecord(ax.reached[2], s2));
-        if (key_heavy) {
+        if (key_heavy || overlap_sides) {
             // the two stages are independent of each other as well: a stream each (a lone aggregate is all latency:
             // 3.6 ms + 9.7 ms one after the other, 9.7 ms side by side)
             s3 = ax.st[1];
@@ -545,9 +556,12 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
         }
     };
+    // beyond 65 536 tuples more than one wave per SIMD is waiting: the builds that leave room for two (bls_g2_kernels_w2.hip)
+    const bool two_waves = g_tower.load() != 2 && (g_g2_waves == 2 || (g_g2_waves == 0 && n > 65536u) || overlap_sides);
     auto run_sig = [&] {
         ProfScope ps("bls_sig", s3);
-        hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts, st_dec, st_grp);
+        hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : two_waves ? k_sig_w2 : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts,
+                           st_dec, st_grp);
     };
     auto run_h2c = [&] {
         ProfScope ps("bls_h2c", s2);
@@ -561,7 +575,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             else
                 hipLaunchKernelGGL(k_h2c_finish2, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
         } else {
-            hipLaunchKernelGGL(calls ? k_h2c_calls : k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
+            hipLaunchKernelGGL(calls ? k_h2c_calls : two_waves ? k_h2c_w2 : k_h2c, grid_for(n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, hpts);
         }
     };
     if (fork) {

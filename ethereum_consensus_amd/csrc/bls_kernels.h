@@ -28,6 +28,11 @@ __global__ void k_h2c_finish(const J2* maps, u32 n, A2* hpts);
 __global__ void k_h2c_finish2(const J2* maps, u32 n, A2* hpts);  // bls_g2_pair2_kernels.hip: two lanes per message
 __global__ void k_h2c_map_calls(const u8* msgs, const u64* msg_off, u32 n, J2* maps);
 __global__ void k_h2c_finish_calls(const J2* maps, u32 n, A2* hpts);
+// bls_g2_kernels_w2.hip: room for two waves per SIMD (batches beyond 65 536 tuples)
+__global__ void k_sig_w2(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
+__global__ void k_h2c_w2(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
+__global__ void k_h2c_map_w2(const u8* msgs, const u64* msg_off, u32 n, J2* maps);
+__global__ void k_h2c_finish_w2(const J2* maps, u32 n, A2* hpts);
 __global__ void k_sig_calls(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
 __global__ void k_h2c_calls(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
 

@@ -653,6 +653,24 @@ def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, 
     assert res["ok"] and res["n"] == n and res["python_samples_checked"] >= (64 if n == 65536 else 8), res
 
 
+def test_config2_on_the_two_wave_builds_of_the_g2_stage_kernels(config2_workload):
+    """k_sig_w2 / k_h2c_w2 (csrc/bls_g2_kernels_w2.hip: room for two waves per SIMD, the default beyond 65 536 tuples -- the 2^20
+    batch of test_north_star_... goes through them) forced at config-2 size: the whole status vector against all three
+    expectations."""
+    import json
+    import os
+    import subprocess
+    import sys
+    path, info = config2_workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ECGPU_TOWER="sums", ECGPU_PAIRING="lane", ECGPU_G2_WAVES="2", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-m", "tests._bls_config2", "run", path, "65536", "1", "lane"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["n"] == 65536, res
+
+
 @pytest.fixture(scope="module")
 def mutated_workload(gpu, tmp_path_factory):
     """65 536 valid K = 1 tuples, 21 846 of them damaged at random (tests/_blsmutate.py): judged by the C++ oracle on all of
