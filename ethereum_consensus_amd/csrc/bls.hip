@@ -556,8 +556,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
         }
     };
-    // beyond 65 536 tuples more than one wave per SIMD is waiting: the builds that leave room for two (bls_g2_kernels_w2.hip)
-    const bool two_waves = g_tower.load() != 2 && (g_g2_waves == 2 || (g_g2_waves == 0 && n > 65536u) || overlap_sides);
+    // from 131 072 tuples on at least two waves per SIMD are waiting: the builds that leave room for two (bls_g2_kernels_w2.hip;
+    // in between, most SIMDs still hold one wave and the full-file build is the faster one per wave)
+    const bool two_waves = g_tower.load() != 2 && (g_g2_waves == 2 || (g_g2_waves == 0 && n >= 131072u) || overlap_sides);
     auto run_sig = [&] {
         ProfScope ps("bls_sig", s3);
         hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : two_waves ? k_sig_w2 : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts,

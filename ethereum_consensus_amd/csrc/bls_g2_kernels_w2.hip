@@ -1,4 +1,4 @@
-// k_sig / k_h2c once more with room for TWO waves per SIMD (256 registers): for batches beyond 65 536 tuples, where more than
+// k_sig / k_h2c once more with room for TWO waves per SIMD (256 registers): for batches of 131 072 tuples and more, where more than
 // one wave per SIMD is waiting -- two half-file waves issue more than one full-file wave (a lone wave issues once per ~5 cycles
 // whatever it runs).  Measured at 2^20 tuples: k_sig 35.9 -> 29.8 ms, k_h2c 87.2 -> 72.7 ms (profiles/r04o_*).  At 65 536
 // tuples there is exactly one wave per SIMD and the full-file build is the faster one.  (The register budget of the callees
