@@ -13,10 +13,15 @@
 #define ECG_G1_CAT2(a, b) a##b
 #define ECG_G1_CAT(a, b) ECG_G1_CAT2(a, b)
 #define ECG_G1_KN(name) ECG_G1_CAT(name##_w, ECG_G1_WAVES)
+// the register budget the compiler is given (default: room for ECG_G1_WAVES waves per SIMD); tools/build_variant.sh sets it apart
+// from the kernel's name to measure other budgets under the same dispatch
+#ifndef ECG_G1_OCCUPANCY
+#define ECG_G1_OCCUPANCY ECG_G1_WAVES
+#endif
 
 namespace ecg {
 
-__global__ void __launch_bounds__(BLS_BLOCK, ECG_G1_WAVES) ECG_G1_KN(k_pk_validate)(const u8* pks48, u32 n, A1* pts, u8* st) {
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_G1_OCCUPANCY) ECG_G1_KN(k_pk_validate)(const u8* pks48, u32 n, A1* pts, u8* st) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
     A1 p;
