@@ -191,7 +191,8 @@ def run_merkle(args, L, torch, dist, rank, world):
     # and every outstanding gather is waited for before the clock stops: a 32-byte all-gather is ~20-40 us of pure latency,
     # 2-4 % of a 1 ms step if the next root waited for it.
     d_root2 = [d_root, torch.zeros_like(d_root)]
-    gathered = [torch.empty(32 * world, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
+    multi = _multi(dist, world)  # (a single-rank group with the collectives forced: tests/test_gpu_dist.py)
+    gathered = [torch.empty(32 * world, dtype=torch.uint8, device="cuda") for _ in range(2)] if multi else None
     pending = [None, None]
     turn = {"k": 0}
 
@@ -204,7 +205,7 @@ def run_merkle(args, L, torch, dist, rank, world):
         rc = L.ecgpu_htr_beacon_state_deneb_dev(d_state.data_ptr(), len(enc), h_fixed, 0, d_root2[k].data_ptr(), stream)
         if rc != 0:
             raise RuntimeError(f"ecgpu_htr_beacon_state_deneb_dev -> {rc}: {L.ecgpu_last_error()}")
-        if world > 1:
+        if multi:
             pending[k] = dist.all_gather_into_tensor(gathered[k], d_root2[k], async_op=True)
 
     def drain():

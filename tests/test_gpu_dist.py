@@ -57,6 +57,8 @@ def test_preflight_under_a_single_rank_nccl_group(gpu):
     (["--workload", "merkle", "--scaling", "strong", "--validators", "70001", "--steps", "2", "--warmup", "1"], "equals_unsharded_root"),
     (["--workload", "bls", "--scaling", "strong", "--tuples", "4097", "--steps", "1", "--warmup", "1", "--no-aggregates"],
      "statuses_match_construction"),
+    # one state per rank, the roots all-gathered asynchronously every step (two buffers alternating)
+    (["--workload", "merkle", "--validators", "70001", "--steps", "5", "--warmup", "2"], "root"),
 ])
 def test_bench_strong_modes_through_rccl_with_one_rank(gpu, argv, check):
     """bench.py's own main(): nccl process group of one rank, collectives forced (ECGPU_BENCH_FORCE_DIST), preflight in the line"""
@@ -64,6 +66,9 @@ def test_bench_strong_modes_through_rccl_with_one_rank(gpu, argv, check):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     line = _json_line(out.stdout)
-    assert line["scaling"] == "strong" and line["n_gpus"] == 1
-    assert line["check"][check] is True, line["check"]
+    assert line["n_gpus"] == 1
+    if check == "root":
+        assert line["scaling"] == "weak" and len(line["check"]["root"]) == 64 and line["h2d_inclusive"]["root_equals_resident_root"] is True
+    else:
+        assert line["scaling"] == "strong" and line["check"][check] is True, line["check"]
     assert line["preflight"]["backend"] == "nccl" and line["preflight"]["all_gather_1_byte"] == "ok"
