@@ -464,6 +464,10 @@ static const bool g_split_default = [] {
     const char* e = getenv("ECGPU_SPLIT_DEFAULT");
     return e ? atoi(e) != 0 : false;
 }();
+static const u32 g_h2c_split_keys_max = [] {  // key-heavy batches keep the two-lane message stage up to this many keys
+    const char* e = getenv("ECGPU_H2C_SPLIT_KEYS_MAX");
+    return e ? (u32)strtoul(e, nullptr, 10) : 65536u;
+}();
 static const int g_g2_waves = [] {  // ECGPU_G2_WAVES=1|2 forces the register budget of k_sig / k_h2c (default: 2 beyond 65 536 tuples)
     const char* e = getenv("ECGPU_G2_WAVES");
     return e ? atoi(e) : 0;
@@ -515,7 +519,8 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     // (not under a committee batch's key stage: the second launch of the pair would find every SIMD taken by key waves and
     // wait for the stage to drain -- 256 x 2 048 keys: 25.3 ms against 21.2, profiles/r02p2_h2c_two_lanes.txt)
     J2* h2c_maps = nullptr;
-    if (n <= g_h2c_split_max && !(d_pk_off && !reg && n_pks >= 4ull * n)) {
+    // (round 4: a key stage of at most one wave per SIMD -- a block's ~50 000 keys -- does not flood the chip; only beyond that)
+    if (n <= g_h2c_split_max && !(d_pk_off && !reg && n_pks >= 4ull * n && n_pks > g_h2c_split_keys_max)) {
         h2c_maps = (J2*)ar.take((size_t)2 * n * sizeof(J2));
         if (!h2c_maps) return ECGPU_ERR_OOM;
     }
