@@ -543,7 +543,10 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
         ECG_HIP_CHECK(hipStreamWaitEvent(s2, ax.fork, 0));
         ECG_HIP_CHECK(hipEventRecord(ax.reached[2], s2));
-        if (key_heavy || overlap_sides) {
+        // (the two side streams share ONE hardware queue -- HISTORY.md 3.4 -- so a signature stage on its own stream runs after
+        // the message stage, not beside it: worth it behind a long key stage, not behind a block's ~50 000 keys, where the
+        // signature stage follows the keys on the caller's stream instead: block 9.0 -> 7.x ms, round 4)
+        if ((key_heavy && n_pks > g_h2c_split_keys_max) || overlap_sides) {
             // the two stages are independent of each other as well: a stream each (a lone aggregate is all latency:
             // 3.6 ms + 9.7 ms one after the other, 9.7 ms side by side)
             s3 = ax.st[1];
@@ -595,7 +598,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         if (s3 != s) run_sig();
         if (key_heavy) {
             ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.reached[2], 0));
-            ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.reached[1], 0));
+            if (s3 != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.reached[1], 0));
         }
         run_keys();
         if (s3 == s) run_sig();
