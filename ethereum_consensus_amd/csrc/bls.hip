@@ -546,7 +546,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         // (the two side streams share ONE hardware queue -- HISTORY.md 3.4 -- so a signature stage on its own stream runs after
         // the message stage, not beside it: worth it behind a long key stage, not behind a block's ~50 000 keys, where the
         // signature stage follows the keys on the caller's stream instead: block 9.0 -> 7.x ms, round 4)
-        if ((key_heavy && n_pks > g_h2c_split_keys_max) || overlap_sides) {
+        // (a lone aggregate -- a slot's sync committee -- measured the other way round: 7.45 ms with the stream of its own, 7.68
+        // behind the keys; hence the tuple count in the condition)
+        if ((key_heavy && (n_pks > g_h2c_split_keys_max || n < 16)) || overlap_sides) {
             // the two stages are independent of each other as well: a stream each (a lone aggregate is all latency:
             // 3.6 ms + 9.7 ms one after the other, 9.7 ms side by side)
             s3 = ax.st[1];
