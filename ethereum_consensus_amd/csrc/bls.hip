@@ -534,7 +534,11 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     // two megabyte-sized instruction streams through one instruction cache: profiles/r02l_stage_overlap.txt).
     const bool key_heavy = d_pk_off && !reg && n_pks >= 4ull * n;
     const bool overlap_sides = g_side_overlap != 0 && !d_pk_off && !reg && g_tower.load() != 2;  // experiment: see g_side_overlap
-    const bool fork = (d_pk_off && (reg || key_heavy) && n <= 16384) || overlap_sides;
+    // Small batches of any shape (round 4; before: only aggregates behind a registry or a long key list): at most 16 384
+    // tuples leave three quarters of the SIMDs idle under each stage, and the three stages do not depend on each other -- a
+    // lone verify_signature call is the sum of three latencies otherwise.  ECGPU_FORK_SMALL=0: the round-3 condition.
+    static const int fork_small = [] { const char* e = getenv("ECGPU_FORK_SMALL"); return e ? atoi(e) : 1; }();
+    const bool fork = (n <= 16384 && (fork_small || (d_pk_off && (reg || key_heavy)))) || overlap_sides;
     hipStream_t s2 = s, s3 = s;  // message stage / signature stage
     if (fork) {
         int rc = ax.init();
@@ -543,12 +547,10 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
         ECG_HIP_CHECK(hipStreamWaitEvent(s2, ax.fork, 0));
         ECG_HIP_CHECK(hipEventRecord(ax.reached[2], s2));
-        // (the two side streams share ONE hardware queue -- HISTORY.md 3.4 -- so a signature stage on its own stream runs after
-        // the message stage, not beside it: worth it behind a long key stage, not behind a block's ~50 000 keys, where the
-        // signature stage follows the keys on the caller's stream instead: block 9.0 -> 7.x ms, round 4)
-        // (a lone aggregate -- a slot's sync committee -- measured the other way round: 7.45 ms with the stream of its own, 7.68
-        // behind the keys; hence the tuple count in the condition)
-        if ((key_heavy && (n_pks > g_h2c_split_keys_max || n < 16)) || overlap_sides) {
+        // (st[1] and st[2] used to share ONE hardware queue -- HISTORY.md 3.4 -- so a signature stage on its own stream ran
+        // after the message stage, not beside it; since round 4 st[1] is a high-priority stream with a queue of its own:
+        // a block's 145 verifications 7.9 -> 6.8 ms, profiles/r04x_*)
+        if (key_heavy || overlap_sides || fork_small) {
             // the two stages are independent of each other as well: a stream each (a lone aggregate is all latency:
             // 3.6 ms + 9.7 ms one after the other, 9.7 ms side by side)
             s3 = ax.st[1];

@@ -51,7 +51,10 @@ struct AuxStreams {
     hipStream_t st[N_AUX_STREAMS] = {};
     hipEvent_t fork = nullptr, done[N_AUX_STREAMS] = {}, reached[N_AUX_STREAMS] = {};  // reached[i]: st[i] has passed its wait on fork
     bool ready = false;
-    int init();
+    int device = -1;
+    int init();     // takes a set from the device's pool of sets that exited threads gave back, or creates one
+    void give_back();  // (thread exit, after a device-wide synchronisation) back to the pool: streams are never destroyed --
+                       // short-lived host threads would otherwise create and destroy hardware queues at every exit
 };
 
 // A ring of pinned host slots for small descriptor blocks that travel to the device in front of a launch chain (the plan of a

@@ -109,15 +109,7 @@ void ThreadCtx::release() {
     if (staging.p) (void)hipHostFree(staging.p);
     staging = PinnedBuf();
     uploads.release();
-    if (aux.ready) {
-        (void)hipEventDestroy(aux.fork);
-        for (int i = 0; i < N_AUX_STREAMS; i++) {
-            (void)hipEventDestroy(aux.done[i]);
-            (void)hipEventDestroy(aux.reached[i]);
-            (void)hipStreamDestroy(aux.st[i]);
-        }
-        aux = AuxStreams();
-    }
+    aux.give_back();
     if (own_stream) (void)hipStreamDestroy(own_stream);
     own_stream = nullptr;
 }
@@ -237,11 +229,45 @@ hipStream_t ThreadCtx::stream_or_own(ecgpu_stream_t s) {
     return own_stream;
 }
 
+// (never destroyed: a host thread may exit after the static destructors have run)
+static std::mutex& g_aux_pool_mu = *new std::mutex();
+static std::vector<AuxStreams>* const g_aux_pool = new std::vector<AuxStreams>[MAX_DEVICES];
+
+void AuxStreams::give_back() {
+    if (!ready) return;
+    {
+        std::lock_guard<std::mutex> lk(g_aux_pool_mu);
+        g_aux_pool[device].push_back(*this);
+    }
+    *this = AuxStreams();
+}
+
 int AuxStreams::init() {
     if (ready) return ECGPU_SUCCESS;
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> lk(g_aux_pool_mu);
+        auto& pool = g_aux_pool[dev];
+        if (!pool.empty()) {
+            *this = pool.back();
+            pool.pop_back();
+            return ECGPU_SUCCESS;
+        }
+    }
+    device = dev;
     ECG_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     for (int i = 0; i < N_AUX_STREAMS; i++) {
-        ECG_HIP_CHECK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+        // st[1] sits at the high priority level: the runtime multiplexes normal-priority streams onto four hardware queues and
+        // st[1] / st[2] ended up sharing one (a signature stage on st[1] ran AFTER the message stage on st[2], not beside it);
+        // each priority level has queues of its own.  ECGPU_AUX1_PRIORITY=0: all three at normal priority (rounds 1-3).
+        static const int aux1_high = [] { const char* e = getenv("ECGPU_AUX1_PRIORITY"); return e ? atoi(e) : 1; }();
+        if (i == 1 && aux1_high) {
+            int lo = 0, hi = 0;
+            ECG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            ECG_HIP_CHECK(hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, hi));
+        } else {
+            ECG_HIP_CHECK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+        }
         ECG_HIP_CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         ECG_HIP_CHECK(hipEventCreateWithFlags(&reached[i], hipEventDisableTiming));
     }
