@@ -896,9 +896,11 @@ def run_slots(args, L, torch, dist, rank, world, n_sync=512):
 
     def one_slot(i, record):
         w = work[i % n_distinct]
-        st.patch(w["patches"])
+        # the aggregate does not depend on the state: enqueued first, so that marshalling and uploading the slot's patches
+        # (host work: ~1 ms of Python per 4 096 patches) and the root run underneath its 6.7 ms dependent chain
         rc1 = L.ecgpu_fast_aggregate_verify_indexed_batch_dev(reg.handle, w["d_idx"].data_ptr(), w["d_off"].data_ptr(), w["k"], w["d_msg"].data_ptr(),
                                                               w["d_sig"].data_ptr(), 1, 1, d_res.data_ptr(), s_bls.cuda_stream)
+        st.patch(w["patches"])
         rc2 = L.ecgpu_resident_state_root_dev(st.handle, d_res.data_ptr() + 1, s_mk.cuda_stream)
         if rc1 or rc2:
             raise RuntimeError(f"slot step -> {rc1}, {rc2}: {L.ecgpu_last_error()}")

@@ -547,15 +547,15 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         ECG_HIP_CHECK(hipEventRecord(ax.fork, s));
         ECG_HIP_CHECK(hipStreamWaitEvent(s2, ax.fork, 0));
         ECG_HIP_CHECK(hipEventRecord(ax.reached[2], s2));
-        // (st[1] and st[2] used to share ONE hardware queue -- HISTORY.md 3.4 -- so a signature stage on its own stream ran
-        // after the message stage, not beside it; since round 4 st[1] is a high-priority stream with a queue of its own:
+        // (st[1] and st[2] share ONE hardware queue -- HISTORY.md 3.4 -- so a signature stage on st[1] ran after the message
+        // stage, not beside it; since round 4 it has st[AUX_SIG], a high-priority stream with a queue of its own:
         // a block's 145 verifications 7.9 -> 6.8 ms, profiles/r04x_*)
         if (key_heavy || overlap_sides || fork_small) {
             // the two stages are independent of each other as well: a stream each (a lone aggregate is all latency:
             // 3.6 ms + 9.7 ms one after the other, 9.7 ms side by side)
-            s3 = ax.st[1];
+            s3 = ax.st[AUX_SIG];
             ECG_HIP_CHECK(hipStreamWaitEvent(s3, ax.fork, 0));
-            ECG_HIP_CHECK(hipEventRecord(ax.reached[1], s3));
+            ECG_HIP_CHECK(hipEventRecord(ax.reached[AUX_SIG], s3));
         }
     }
     auto run_keys = [&] {
@@ -602,7 +602,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         if (s3 != s) run_sig();
         if (key_heavy) {
             ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.reached[2], 0));
-            if (s3 != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.reached[1], 0));
+            if (s3 != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.reached[AUX_SIG], 0));
         }
         run_keys();
         if (s3 == s) run_sig();
@@ -615,8 +615,8 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         ECG_HIP_CHECK(hipEventRecord(ax.done[2], s2));
         ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[2], 0));
         if (s3 != s) {
-            ECG_HIP_CHECK(hipEventRecord(ax.done[1], s3));
-            ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[1], 0));
+            ECG_HIP_CHECK(hipEventRecord(ax.done[AUX_SIG], s3));
+            ECG_HIP_CHECK(hipStreamWaitEvent(s, ax.done[AUX_SIG], 0));
         }
     }
     {

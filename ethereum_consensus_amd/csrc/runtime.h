@@ -46,7 +46,8 @@ struct PinnedBuf {
 
 // Fork/join helper: a few auxiliary streams per host thread so that independent launch chains of one
 // call (the fields of a BeaconState) overlap on the device instead of queueing behind each other.
-constexpr int N_AUX_STREAMS = 3;
+constexpr int N_AUX_STREAMS = 4;
+constexpr int AUX_SIG = 3;  // the signature stage's stream: high priority = a hardware queue of its own (runtime.hip)
 struct AuxStreams {
     hipStream_t st[N_AUX_STREAMS] = {};
     hipEvent_t fork = nullptr, done[N_AUX_STREAMS] = {}, reached[N_AUX_STREAMS] = {};  // reached[i]: st[i] has passed its wait on fork
@@ -73,9 +74,9 @@ struct UploadRing {
 
 struct ThreadCtx {
     hipStream_t own_stream = nullptr;
-    // ONE set of three auxiliary streams per host thread.  State roots use st[0] (tile stages, batched jobs) and st[1]
-    // (fields that need passes of their own); BLS batches use st[2] (message stage) and st[1] (signature stage of
-    // key-heavy batches).  Not a set each: the runtime multiplexes streams onto 4 hardware queues, and with more live streams
+    // ONE set of auxiliary streams per host thread (three at normal priority + one at high priority).  State roots use st[0] (tile stages, batched jobs) and st[1]
+    // (fields that need passes of their own); BLS batches use st[2] (message stage) and st[AUX_SIG] (signature stage;
+    // rounds 1-3: st[1], which turned out to share a hardware queue with st[2] -- and a slot's root with its aggregate).  Not a set each: the runtime multiplexes streams onto 4 hardware queues, and with more live streams
     // than that the auxiliary ones start sharing a queue with the caller's stream -- measured: the state root loses its
     // overlap (1.05 -> 1.21 ms) as soon as a second set merely exists (profiles/r01s16_hw_queues.txt).
     AuxStreams aux;

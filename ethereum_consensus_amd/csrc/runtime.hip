@@ -257,11 +257,11 @@ int AuxStreams::init() {
     device = dev;
     ECG_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     for (int i = 0; i < N_AUX_STREAMS; i++) {
-        // st[1] sits at the high priority level: the runtime multiplexes normal-priority streams onto four hardware queues and
-        // st[1] / st[2] ended up sharing one (a signature stage on st[1] ran AFTER the message stage on st[2], not beside it);
-        // each priority level has queues of its own.  ECGPU_AUX1_PRIORITY=0: all three at normal priority (rounds 1-3).
+        // st[AUX_SIG] sits at the high priority level: the runtime multiplexes normal-priority streams onto four hardware queues
+        // and st[1] / st[2] ended up sharing one (a signature stage on st[1] ran AFTER the message stage on st[2], not beside
+        // it); each priority level has queues of its own.  ECGPU_AUX1_PRIORITY=0: all at normal priority.
         static const int aux1_high = [] { const char* e = getenv("ECGPU_AUX1_PRIORITY"); return e ? atoi(e) : 1; }();
-        if (i == 1 && aux1_high) {
+        if ((i == AUX_SIG && aux1_high) || (i == 2 && aux1_high >= 2)) {
             int lo = 0, hi = 0;
             ECG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
             ECG_HIP_CHECK(hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, hi));

@@ -320,7 +320,7 @@ int ecgpu_fast_aggregate_verify_indexed_batch_dev(const ecgpu_registry_t* reg, c
  * makes one after the other: proposer signature (phase0/state_transition.rs:56), randao reveal
  * (phase0/block_processing.rs:649), slashings / exits / deposits / BLS changes (signing.rs:40 callers), one
  * fast_aggregate_verify per attestation (phase0/block_processing.rs:752-761 -> phase0/helpers.rs:140) and the sync
- * aggregate (altair/block_processing.rs:226-234).  On a GPU a scalar call is tens of ms of dependent latency; a collector
+ * aggregate (altair/block_processing.rs:226-234).  On a GPU a scalar call is ~6 ms of dependent latency; a collector
  * queues them (host memory only, any thread) and `flush` verifies everything queued in ONE pass of the batch pipeline.
  * status_out[p] = exactly what the scalar call pushed at position p would have returned (verify_signature = one key;
  * eth_variant != 0 = eth_fast_aggregate_verify).  `reg` (may be NULL) enables push_indexed: keys named by validator
