@@ -568,9 +568,10 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
         }
     };
-    // from 131 072 tuples on at least two waves per SIMD are waiting: the builds that leave room for two (bls_g2_kernels_w2.hip;
-    // in between, most SIMDs still hold one wave and the full-file build is the faster one per wave)
-    const bool two_waves = g_tower.load() != 2 && (g_g2_waves == 2 || (g_g2_waves == 0 && n >= 131072u) || overlap_sides);
+    // beyond 65 536 tuples more than one wave per SIMD is waiting: the builds that leave room for two (bls_g2_kernels_w2.hip).
+    // (Up to 131 071 most SIMDs still hold ONE wave, which the full-file build runs faster -- but the full-file build then
+    // needs a second round for the rest: 70 000 tuples 4.7 + 11.3 ms against 4.2 + 9.8, profiles/r04y_ragged_*.)
+    const bool two_waves = g_tower.load() != 2 && (g_g2_waves == 2 || (g_g2_waves == 0 && n > 65536u) || overlap_sides);
     auto run_sig = [&] {
         ProfScope ps("bls_sig", s3);
         hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : two_waves ? k_sig_w2 : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts,
@@ -640,8 +641,28 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
                 hipLaunchKernelGGL(k_finalexp, grid_for(n), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, n, d_status);
             }
         } else if (!use_vm3) {
-            hipLaunchKernelGGL(k_pairing, grid_for(n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
-                               (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status);
+            // The lane kernel takes the whole register file: ONE wave per SIMD, so a batch runs in rounds of lane_round tuples
+            // (65 536 on this chip) and a ragged tail costs a whole 22 ms round however short it is.  In auto mode a tail within
+            // the lane groups' range goes to them instead (70 000 tuples: 22.3 + 4.4 ms instead of 44.6).  ECGPU_RAGGED_TAIL=0:
+            // everything through the lane kernel.
+            static const int ragged_tail = [] { const char* e = getenv("ECGPU_RAGGED_TAIL"); return e ? atoi(e) : 1; }();
+            static const u32 lane_round = [] {
+                hipDeviceProp_t prop;
+                return hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
+            }();
+            const u32 rem = n % lane_round;
+            const bool tail = ragged_tail && (g_pairing_mode == 3 || g_pairing_mode == 6) && n > lane_round && rem && rem <= g_vm_max_tuples;
+            const u32 full = tail ? n - rem : n;
+            hipLaunchKernelGGL(k_pairing, grid_for(full), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
+                               (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, full, eth_variant, d_status);
+            if (tail) {
+                u32* xfer = (u32*)ar.take(vm3_xfer_bytes(rem));
+                if (!xfer) return ECGPU_ERR_OOM;
+                int rc = vm3_pairing_launch(s, (const A1*)agg + full, (const u8*)st_pk + full, d_pk_off ? d_pk_off + full : nullptr, (const A2*)hpts + full,
+                                            (const A2*)sigpts + full, (const u8*)st_dec + full, (const u8*)st_grp + full, d_sigs96 + (size_t)96 * full, rem,
+                                            eth_variant, d_status + full, xfer);
+                if (rc) return rc;
+            }
         } else {
             u32* xfer = (u32*)ar.take(vm3_xfer_bytes(n));
             if (!xfer) return ECGPU_ERR_OOM;
