@@ -482,9 +482,13 @@ static const int g_h2c_finish_lanes = [] {  // ECGPU_H2C_FINISH_LANES=1: the one
     const char* e = getenv("ECGPU_H2C_FINISH_LANES");
     return e ? atoi(e) : 2;
 }();
-static const u32 g_vm_max_tuples = [] {
+static const u32 g_vm_max_tuples = [] {  // (round 3: 24 576, the crossover with the lane kernel's 22 ms; round 4: with the split path's 16.8 ms)
     const char* e = getenv("ECGPU_VM_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : 24576u;
+    return e ? (u32)strtoul(e, nullptr, 10) : 21504u;
+}();
+static const u32 g_split_max_tuples = [] {  // up to here two lanes per tuple are still ONE wave per SIMD for the Miller loop
+    const char* e = getenv("ECGPU_SPLIT_MAX");
+    return e ? (u32)strtoul(e, nullptr, 10) : 32768u;
 }();
 
 }  // namespace ecg
@@ -622,56 +626,80 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     }
     {
         ProfScope ps("bls_pairing", s);
-        const bool slow_box = g_tower.load() == 2;  // large-code kernels crawl here: the 47 KB kernel at every size
-        const bool use_vm3 = g_pairing_mode == 4 || ((g_pairing_mode == 3 || g_pairing_mode == 6) && (n <= g_vm_max_tuples || slow_box));
-        // two lanes per tuple for the Miller loop (bls_pair2.h): two waves per SIMD from the same batch.  Default above the
-        // lane groups' range on a healthy box since round 4 (ECGPU_PAIRING=auto1 / lane: the one-lane kernel).
-        const bool use_split = !use_vm3 && (g_pairing_mode == 5 || (g_pairing_mode == 3 && g_split_default));
-        t_last_pairing_path = use_vm3 ? 3 : use_split ? 5 : 1;
-        if (use_split) {
-            Fp12* fs = (Fp12*)ar.take((size_t)n * sizeof(Fp12));
+        // The three pairing paths over a sub-range [base, base + cnt) of the batch (every per-tuple array is indexed by tuple;
+        // the key offsets are only ever differenced).
+        auto run_lane = [&](u32 base, u32 cnt) {
+            hipLaunchKernelGGL(k_pairing, grid_for(cnt), dim3(BLS_BLOCK), 0, s, (const A1*)agg + base, (const u8*)st_pk + base,
+                               d_pk_off ? d_pk_off + base : nullptr, (const A2*)hpts + base, (const A2*)sigpts + base, (const u8*)st_dec + base,
+                               (const u8*)st_grp + base, d_sigs96 + (size_t)96 * base, cnt, eth_variant, d_status + base);
+        };
+        auto run_vm3 = [&](u32 base, u32 cnt) -> int {
+            u32* xfer = (u32*)ar.take(vm3_xfer_bytes(cnt));
+            if (!xfer) return ECGPU_ERR_OOM;
+            // (tuples whose pairing involves a point at infinity are decided in the lane groups' status step: such a pair
+            // contributes 1, and a single non-degenerate pair cannot be 1)
+            return vm3_pairing_launch(s, (const A1*)agg + base, (const u8*)st_pk + base, d_pk_off ? d_pk_off + base : nullptr, (const A2*)hpts + base,
+                                      (const A2*)sigpts + base, (const u8*)st_dec + base, (const u8*)st_grp + base, d_sigs96 + (size_t)96 * base, cnt,
+                                      eth_variant, d_status + base, xfer);
+        };
+        // two lanes per tuple for the Miller loop (bls_pair2.h), one lane per tuple for the final exponentiation
+        auto run_split = [&](u32 base, u32 cnt) -> int {
+            Fp12* fs = (Fp12*)ar.take((size_t)cnt * sizeof(Fp12));
             if (!fs) return ECGPU_ERR_OOM;
             {
                 ProfScope p2("bls_miller2", s);
-                hipLaunchKernelGGL(k_miller2, grid_for(2 * n), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
-                                   (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, fs);
+                hipLaunchKernelGGL(k_miller2, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s, (const A1*)agg + base, (const u8*)st_pk + base,
+                                   d_pk_off ? d_pk_off + base : nullptr, (const A2*)hpts + base, (const A2*)sigpts + base, (const u8*)st_dec + base,
+                                   (const u8*)st_grp + base, d_sigs96 + (size_t)96 * base, cnt, eth_variant, d_status + base, fs);
             }
             {
                 ProfScope p3("bls_finalexp", s);
-                hipLaunchKernelGGL(k_finalexp, grid_for(n), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, n, d_status);
+                hipLaunchKernelGGL(k_finalexp, grid_for(cnt), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, cnt, d_status + base);
             }
-        } else if (!use_vm3) {
-            // The lane kernel takes the whole register file: ONE wave per SIMD, so a batch runs in rounds of lane_round tuples
-            // (65 536 on this chip) and a ragged tail costs a whole 22 ms round however short it is.  In auto mode a tail within
-            // the lane groups' range goes to them instead (70 000 tuples: 22.3 + 4.4 ms instead of 44.6).  ECGPU_RAGGED_TAIL=0:
-            // everything through the lane kernel.
-            static const int ragged_tail = [] { const char* e = getenv("ECGPU_RAGGED_TAIL"); return e ? atoi(e) : 1; }();
-            static const u32 lane_round = [] {
-                hipDeviceProp_t prop;
-                return hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
-            }();
-            const u32 rem = n % lane_round;
-            const bool tail = ragged_tail && (g_pairing_mode == 3 || g_pairing_mode == 6) && n > lane_round && rem && rem <= g_vm_max_tuples;
-            const u32 full = tail ? n - rem : n;
-            hipLaunchKernelGGL(k_pairing, grid_for(full), dim3(BLS_BLOCK), 0, s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts,
-                               (const A2*)sigpts, (const u8*)st_dec, (const u8*)st_grp, d_sigs96, full, eth_variant, d_status);
-            if (tail) {
-                u32* xfer = (u32*)ar.take(vm3_xfer_bytes(rem));
-                if (!xfer) return ECGPU_ERR_OOM;
-                int rc = vm3_pairing_launch(s, (const A1*)agg + full, (const u8*)st_pk + full, d_pk_off ? d_pk_off + full : nullptr, (const A2*)hpts + full,
-                                            (const A2*)sigpts + full, (const u8*)st_dec + full, (const u8*)st_grp + full, d_sigs96 + (size_t)96 * full, rem,
-                                            eth_variant, d_status + full, xfer);
-                if (rc) return rc;
-            }
+            return ECGPU_SUCCESS;
+        };
+        // Dispatch.  The lane kernel takes the whole register file: ONE wave per SIMD, a batch runs in rounds of
+        // lane_round tuples (65 536 on this chip) at 22.3 ms each however full the round is.  In auto mode on a healthy box:
+        //   up to ECGPU_VM_MAX tuples                   the lane groups (latency 3.5 ms, 0.78 ms per 1 000 tuples)
+        //   up to ECGPU_SPLIT_MAX = half a round        the two-lane Miller loop, one wave per SIMD, + the one-lane final
+        //                                               exponentiation on half the SIMDs: 16.7 .. 17.2 ms (profiles/r04y_mid_size_*)
+        //   above                                       the lane kernel on the full rounds and on a tail of more than half a
+        //                                               round; a shorter tail by the two rules above
+        // On a box with slow instruction fetch: the lane groups at every size.  ECGPU_RAGGED_TAIL=0: no special tail.
+        static const int ragged_tail = [] { const char* e = getenv("ECGPU_RAGGED_TAIL"); return e ? atoi(e) : 1; }();
+        static const u32 lane_round = [] {
+            hipDeviceProp_t prop;
+            return hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
+        }();
+        const bool slow_box = g_tower.load() == 2;  // large-code kernels crawl here: the 47 KB kernel at every size
+        const bool auto_mode = g_pairing_mode == 3 || g_pairing_mode == 6;
+        const u32 split_max = g_pairing_mode == 3 ? g_split_max_tuples : 0;  // auto1 (round 3's rule) has no split window
+        auto small_path = [&](u32 cnt) { return cnt <= g_vm_max_tuples ? 3 : cnt <= split_max ? 5 : 1; };
+        int rc = ECGPU_SUCCESS;
+        if (g_pairing_mode == 4 || (auto_mode && slow_box)) {
+            t_last_pairing_path = 3;
+            rc = run_vm3(0, n);
+        } else if (g_pairing_mode == 5 || (g_pairing_mode == 3 && g_split_default)) {
+            t_last_pairing_path = 5;
+            rc = run_split(0, n);
+        } else if (!auto_mode) {
+            t_last_pairing_path = 1;
+            run_lane(0, n);
+        } else if (n <= lane_round) {
+            t_last_pairing_path = small_path(n);
+            if (t_last_pairing_path == 3) rc = run_vm3(0, n);
+            else if (t_last_pairing_path == 5) rc = run_split(0, n);
+            else run_lane(0, n);
         } else {
-            u32* xfer = (u32*)ar.take(vm3_xfer_bytes(n));
-            if (!xfer) return ECGPU_ERR_OOM;
-            int rc = vm3_pairing_launch(s, (const A1*)agg, (const u8*)st_pk, d_pk_off, (const A2*)hpts, (const A2*)sigpts, (const u8*)st_dec,
-                                        (const u8*)st_grp, d_sigs96, n, eth_variant, d_status, xfer);
-            if (rc) return rc;
-            // (tuples whose pairing involves a point at infinity are decided in the lane groups' status step: such a pair
-            // contributes 1, and a single non-degenerate pair cannot be 1)
+            t_last_pairing_path = 1;
+            const u32 rem = n % lane_round;
+            const int tail = ragged_tail && rem ? small_path(rem) : 1;
+            const u32 full = tail == 1 ? n : n - rem;
+            run_lane(0, full);
+            if (tail == 3) rc = run_vm3(full, rem);
+            else if (tail == 5) rc = run_split(full, rem);
         }
+        if (rc) return rc;
     }
     ECG_HIP_CHECK(hipGetLastError());
     return ECGPU_SUCCESS;

@@ -74,11 +74,11 @@ struct UploadRing {
 
 struct ThreadCtx {
     hipStream_t own_stream = nullptr;
-    // ONE set of auxiliary streams per host thread (three at normal priority + one at high priority).  State roots use st[0] (tile stages, batched jobs) and st[1]
-    // (fields that need passes of their own); BLS batches use st[2] (message stage) and st[AUX_SIG] (signature stage;
-    // rounds 1-3: st[1], which turned out to share a hardware queue with st[2] -- and a slot's root with its aggregate).  Not a set each: the runtime multiplexes streams onto 4 hardware queues, and with more live streams
-    // than that the auxiliary ones start sharing a queue with the caller's stream -- measured: the state root loses its
-    // overlap (1.05 -> 1.21 ms) as soon as a second set merely exists (profiles/r01s16_hw_queues.txt).
+    // ONE set of auxiliary streams per host thread (three at normal priority + one at high priority).  BLS batches run their
+    // message stage on st[2] and their signature stage on st[AUX_SIG] (rounds 1-3: st[1], which turned out to share a hardware
+    // queue with st[2]); the state root has needed none since its tail became one kernel (round 3).  Not a set per purpose:
+    // the runtime multiplexes normal-priority streams onto 4 hardware queues, and with more live streams than that the
+    // auxiliary ones start sharing a queue with the caller's stream (measured in round 1: profiles/r01s16_hw_queues.txt).
     AuxStreams aux;
     std::map<hipStream_t, Arena> arenas;
     PinnedBuf staging;      // host-pinned staging for small H2D/D2H payloads

@@ -254,22 +254,37 @@ int AuxStreams::init() {
             return ECGPU_SUCCESS;
         }
     }
-    device = dev;
-    ECG_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    for (int i = 0; i < N_AUX_STREAMS; i++) {
-        // st[AUX_SIG] sits at the high priority level: the runtime multiplexes normal-priority streams onto four hardware queues
-        // and st[1] / st[2] ended up sharing one (a signature stage on st[1] ran AFTER the message stage on st[2], not beside
-        // it); each priority level has queues of its own.  ECGPU_AUX1_PRIORITY=0: all at normal priority.
-        static const int aux1_high = [] { const char* e = getenv("ECGPU_AUX1_PRIORITY"); return e ? atoi(e) : 1; }();
-        if ((i == AUX_SIG && aux1_high) || (i == 2 && aux1_high >= 2)) {
-            int lo = 0, hi = 0;
-            ECG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            ECG_HIP_CHECK(hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, hi));
-        } else {
-            ECG_HIP_CHECK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+    // a half-built set is released, not kept (advisor, round 3: the same rule as for the upload ring)
+    auto build = [this]() -> int {
+        ECG_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int i = 0; i < N_AUX_STREAMS; i++) {
+            // st[AUX_SIG] sits at the high priority level: the runtime multiplexes normal-priority streams onto four hardware
+            // queues and st[1] / st[2] ended up sharing one (a signature stage on st[1] ran AFTER the message stage on st[2],
+            // not beside it); each priority level has queues of its own.  ECGPU_AUX1_PRIORITY=0: all at normal priority.
+            static const int aux1_high = [] { const char* e = getenv("ECGPU_AUX1_PRIORITY"); return e ? atoi(e) : 1; }();
+            if ((i == AUX_SIG && aux1_high) || (i == 2 && aux1_high >= 2)) {
+                int lo = 0, hi = 0;
+                ECG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                ECG_HIP_CHECK(hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, hi));
+            } else {
+                ECG_HIP_CHECK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+            }
+            ECG_HIP_CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+            ECG_HIP_CHECK(hipEventCreateWithFlags(&reached[i], hipEventDisableTiming));
         }
-        ECG_HIP_CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-        ECG_HIP_CHECK(hipEventCreateWithFlags(&reached[i], hipEventDisableTiming));
+        return ECGPU_SUCCESS;
+    };
+    device = dev;
+    const int rc = build();
+    if (rc) {
+        if (fork) (void)hipEventDestroy(fork);
+        for (int i = 0; i < N_AUX_STREAMS; i++) {
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            if (reached[i]) (void)hipEventDestroy(reached[i]);
+            if (st[i]) (void)hipStreamDestroy(st[i]);
+        }
+        *this = AuxStreams();
+        return rc;
     }
     ready = true;
     return ECGPU_SUCCESS;

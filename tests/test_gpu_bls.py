@@ -631,10 +631,14 @@ def config2_workload(gpu, tmp_path_factory):
     ("sums", "auto", 4096, 1, "vm3"),       # a small batch as dispatched by default: two-lane message stage + lane groups
     ("calls", "auto", 4096, 2, "vm3"),      # ... and on the compact-code build (k_h2c_map_calls / k_h2c_finish_calls, k_sig_calls)
     ("sums", "lane", 65535, 1, "lane"),     # a ragged batch on the lane kernel: the last wave is one lane short (lane slots, statuses)
-    ("sums", "auto", 24576, 1, "vm3"),      # the default dispatch on either side of ECGPU_VM_MAX: the last size of the lane groups ...
-    ("sums", "auto", 24577, 1, "lane"),     # ... and the first of the lane kernel (385 waves, the last with one lane)
-    ("sums", "auto", 65536 + 4097, 1, "lane"),  # a ragged batch beyond one round of lanes: 65 536 on the lane kernel, the tail on the lane groups
-    ("sums", "lane", 65536 + 130, 1, "lane"),   # ... and the same shape forced through the lane kernel alone (a second round of three waves)
+    ("sums", "auto", 21504, 1, "vm3"),      # the default dispatch on either side of ECGPU_VM_MAX: the last size of the lane groups ...
+    ("sums", "auto", 21505, 1, "split"),    # ... the first of the two-lane Miller loop (one wave per SIMD up to half a round of lanes) ...
+    ("sums", "auto", 32768, 1, "split"),    # ... its last ...
+    ("sums", "auto", 32769, 1, "lane"),     # ... and the first of the lane kernel (513 waves, the last with one lane)
+    ("sums", "auto1", 24577, 1, "lane"),    # round 3's rule (no split window), kept selectable
+    ("sums", "auto", 65536 + 4097, 1, "lane"),   # ragged batches beyond one round of lanes: 65 536 on the lane kernel, the tail on the lane groups
+    ("sums", "auto", 65536 + 30001, 1, "lane"),  # ... a longer tail on the two-lane Miller loop
+    ("sums", "lane", 65536 + 130, 1, "lane"),    # ... and the same shape forced through the lane kernel alone (a second round of three waves)
 ])
 def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, tower, pairing, n, want_tower, want_path):
     """The whole status vector of SURVEY.md 8(d) config 2 -- every fault class: wrong message, swapped key, signature outside
