@@ -478,7 +478,10 @@ static const int g_side_overlap = [] {
     const char* e = getenv("ECGPU_SIDE_OVERLAP");
     return e ? atoi(e) : 0;
 }();
-static const int g_h2c_finish_lanes = [] {  // ECGPU_H2C_FINISH_LANES=1: the one-lane end of the small-batch message stage (round 3)
+// ECGPU_H2C_FINISH_LANES=1: the one-lane (round 3) end of the small-batch message stage.  Default: the lane pair -- on a box
+// with slow instruction fetch as well (its hot loop, one 43 KB doubling, fits the instruction cache: a slot 11.0 -> 8.2 ms
+// there, profiles/r04slow_*).
+static const int g_h2c_finish_lanes = [] {
     const char* e = getenv("ECGPU_H2C_FINISH_LANES");
     return e ? atoi(e) : 2;
 }();
@@ -588,7 +591,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             hipLaunchKernelGGL(calls ? k_h2c_map_calls : k_h2c_map, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, h2c_maps);
             // ... and its end -- the addition of the two maps, the cofactor clearing, the affine conversion: a 3.5 ms chain on
             // one lane -- on a lane PAIR (bls_g2_pair2.h): half the Fp2 components, 0.57 of the instructions, per lane
-            if (calls || g_h2c_finish_lanes == 1)
+            if (g_h2c_finish_lanes == 1)
                 hipLaunchKernelGGL(calls ? k_h2c_finish_calls : k_h2c_finish, grid_for(n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
             else
                 hipLaunchKernelGGL(k_h2c_finish2, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);

@@ -16,8 +16,8 @@ open("gpurun_out/hunt_slow", "w").write("1" if sw[3] / sw[0] > 1.4 else "0")
 PY
 if [ "$(cat gpurun_out/hunt_slow)" = "1" ] || [ -n "$HUNT_ALWAYS" ]; then
   [ "$(cat gpurun_out/hunt_slow)" = "1" ] && echo "SLOW BOX"
-  {
-  for t in sums calls; do echo "== ECGPU_TOWER=$t"; ECGPU_TOWER=$t timeout 300 python tools/bls_probe.py 65536 2>&1 | grep "verify iter 1"; done
-  } | tee gpurun_out/hunt_probe_$(cat gpurun_out/hunt_slow).txt
-  timeout 900 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/hunt_bench_$(cat gpurun_out/hunt_slow).json
+  # the driver's bench line as the library dispatches it on this box; then the small-batch paths with the lane-pair end of the
+  # message stage forced (its hot loops -- one 43 KB doubling -- fit the instruction cache); then the dispatch parity cases
+  bash tools/gpu_visit.sh ${HUNT_TAG:-r04slow2} bench:--no-cpu-baseline py:h2c_small_probe.py env:ECGPU_TOWER=sums py:h2c_small_probe.py \
+       bench:--workload_slots_--no-cpu-baseline
 fi
