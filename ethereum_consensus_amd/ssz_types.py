@@ -163,3 +163,62 @@ def BeaconBlockBodyDeneb(p):
 def BeaconBlockDeneb(p):
     return container(("slot", uint64), ("proposer_index", uint64), ("parent_root", Root), ("state_root", Root),
                      ("body", BeaconBlockBodyDeneb(p)))
+
+
+# ---- electra (the alpha the reference implements: electra/beacon_block.rs:17-63, electra/operations.rs:10-50,
+# electra/execution_payload.rs:13-45, electra/beacon_state.rs:16-25,62-68, electra/presets/{mainnet,minimal}.rs:13-17).
+# MAX_VALIDATORS_PER_SLOT is a const parameter the reference never binds to a number; the specification's value is
+# MAX_VALIDATORS_PER_COMMITTEE * MAX_COMMITTEES_PER_SLOT (phase0/presets/*.rs:5).
+ELECTRA_MAINNET = dict(MAINNET, MAX_COMMITTEES_PER_SLOT=64, MAX_VALIDATORS_PER_SLOT=2048 * 64, MAX_ATTESTER_SLASHINGS_ELECTRA=1,
+                       MAX_ATTESTATIONS_ELECTRA=8, MAX_CONSOLIDATIONS=1, MAX_DEPOSIT_RECEIPTS_PER_PAYLOAD=8192,
+                       MAX_WITHDRAWAL_REQUESTS_PER_PAYLOAD=16)
+ELECTRA_MINIMAL = dict(MINIMAL, MAX_COMMITTEES_PER_SLOT=4, MAX_VALIDATORS_PER_SLOT=2048 * 4, MAX_ATTESTER_SLASHINGS_ELECTRA=1,
+                       MAX_ATTESTATIONS_ELECTRA=8, MAX_CONSOLIDATIONS=1, MAX_DEPOSIT_RECEIPTS_PER_PAYLOAD=4,
+                       MAX_WITHDRAWAL_REQUESTS_PER_PAYLOAD=2)
+DepositReceipt = container(("public_key", BlsPublicKey), ("withdrawal_credentials", Bytes32), ("amount", uint64),
+                           ("signature", BlsSignature), ("index", uint64))
+ExecutionLayerWithdrawalRequest = container(("source_address", ExecutionAddress), ("validator_public_key", BlsPublicKey),
+                                            ("amount", uint64))
+Consolidation = container(("source_index", uint64), ("target_index", uint64), ("epoch", uint64))
+SignedConsolidation = container(("message", Consolidation), ("signature", BlsSignature))
+
+
+def IndexedAttestationElectra(p):
+    return container(("attesting_indices", list_(uint64, p["MAX_VALIDATORS_PER_SLOT"])), ("data", AttestationData),
+                     ("signature", BlsSignature))
+
+
+def AttestationElectra(p):
+    return container(("aggregation_bits", bitlist(p["MAX_VALIDATORS_PER_SLOT"])), ("data", AttestationData),
+                     ("committee_bits", bitvector(p["MAX_COMMITTEES_PER_SLOT"])), ("signature", BlsSignature))
+
+
+def ExecutionPayloadElectra(p):
+    return container(
+        ("parent_hash", Hash32), ("fee_recipient", ExecutionAddress), ("state_root", Bytes32), ("receipts_root", Bytes32),
+        ("logs_bloom", bytevector(p["BYTES_PER_LOGS_BLOOM"])), ("prev_randao", Bytes32), ("block_number", uint64),
+        ("gas_limit", uint64), ("gas_used", uint64), ("timestamp", uint64), ("extra_data", bytelist(p["MAX_EXTRA_DATA_BYTES"])),
+        ("base_fee_per_gas", uint256), ("block_hash", Hash32),
+        ("transactions", list_(bytelist(p["MAX_BYTES_PER_TRANSACTION"]), p["MAX_TRANSACTIONS_PER_PAYLOAD"])),
+        ("withdrawals", list_(Withdrawal, p["MAX_WITHDRAWALS_PER_PAYLOAD"])), ("blob_gas_used", uint64), ("excess_blob_gas", uint64),
+        ("deposit_receipts", list_(DepositReceipt, p["MAX_DEPOSIT_RECEIPTS_PER_PAYLOAD"])),
+        ("withdrawal_requests", list_(ExecutionLayerWithdrawalRequest, p["MAX_WITHDRAWAL_REQUESTS_PER_PAYLOAD"])))
+
+
+def BeaconBlockBodyElectra(p):
+    ix = IndexedAttestationElectra(p)
+    return container(
+        ("randao_reveal", BlsSignature), ("eth1_data", Eth1Data), ("graffiti", Bytes32),
+        ("proposer_slashings", list_(ProposerSlashing, p["MAX_PROPOSER_SLASHINGS"])),
+        ("attester_slashings", list_(container(("attestation_1", ix), ("attestation_2", ix)), p["MAX_ATTESTER_SLASHINGS_ELECTRA"])),
+        ("attestations", list_(AttestationElectra(p), p["MAX_ATTESTATIONS_ELECTRA"])), ("deposits", list_(Deposit, p["MAX_DEPOSITS"])),
+        ("voluntary_exits", list_(SignedVoluntaryExit, p["MAX_VOLUNTARY_EXITS"])), ("sync_aggregate", SyncAggregate(p)),
+        ("execution_payload", ExecutionPayloadElectra(p)),
+        ("bls_to_execution_changes", list_(SignedBlsToExecutionChange, p["MAX_BLS_TO_EXECUTION_CHANGES"])),
+        ("blob_kzg_commitments", list_(KzgCommitment, p["MAX_BLOB_COMMITMENTS_PER_BLOCK"])),
+        ("consolidations", list_(SignedConsolidation, p["MAX_CONSOLIDATIONS"])))
+
+
+def BeaconBlockElectra(p):
+    return container(("slot", uint64), ("proposer_index", uint64), ("parent_root", Root), ("state_root", Root),
+                     ("body", BeaconBlockBodyElectra(p)))

@@ -695,6 +695,58 @@ def BeaconBlockDeneb(p: BlockPreset) -> Container:
                                      ("body", body)])
 
 
+# ---- electra block types: electra/beacon_block.rs:17-63, electra/operations.rs:10-50, electra/execution_payload.rs:13-45,
+# electra/beacon_state.rs:16-25 (DepositReceipt), :62-68 (ExecutionLayerWithdrawalRequest); limits electra/presets/*.rs:13-17.
+# MAX_VALIDATORS_PER_SLOT: a const parameter the reference never binds; the specification's value is
+# MAX_VALIDATORS_PER_COMMITTEE * MAX_COMMITTEES_PER_SLOT (phase0/presets/{mainnet,minimal}.rs:5 -> 64, 4).
+class BlockPresetElectra(BlockPreset):
+    def __init__(self, base: BlockPreset, committees_per_slot, max_deposit_receipts, max_withdrawal_requests):
+        self.__dict__.update(base.__dict__)
+        self.MAX_COMMITTEES_PER_SLOT = committees_per_slot
+        self.MAX_VALIDATORS_PER_SLOT = self.MAX_VALIDATORS_PER_COMMITTEE * committees_per_slot
+        self.MAX_ATTESTER_SLASHINGS_ELECTRA, self.MAX_ATTESTATIONS_ELECTRA, self.MAX_CONSOLIDATIONS = 1, 8, 1
+        self.MAX_DEPOSIT_RECEIPTS_PER_PAYLOAD, self.MAX_WITHDRAWAL_REQUESTS_PER_PAYLOAD = max_deposit_receipts, max_withdrawal_requests
+
+
+BLOCK_ELECTRA_MAINNET = BlockPresetElectra(BLOCK_MAINNET, 64, 8192, 16)
+BLOCK_ELECTRA_MINIMAL = BlockPresetElectra(BLOCK_MINIMAL, 4, 4, 2)
+DepositReceipt = Container("DepositReceipt", [("public_key", BlsPublicKey), ("withdrawal_credentials", Bytes32), ("amount", uint64),
+                                              ("signature", BlsSignature), ("index", uint64)])
+ExecutionLayerWithdrawalRequest = Container("ExecutionLayerWithdrawalRequest", [("source_address", ExecutionAddress),
+                                                                                ("validator_public_key", BlsPublicKey), ("amount", uint64)])
+Consolidation = Container("Consolidation", [("source_index", uint64), ("target_index", uint64), ("epoch", uint64)])
+SignedConsolidation = Container("SignedConsolidation", [("message", Consolidation), ("signature", BlsSignature)])
+
+
+def BeaconBlockElectra(p: BlockPresetElectra) -> Container:
+    indexed = Container("IndexedAttestation", [("attesting_indices", SSZList(uint64, p.MAX_VALIDATORS_PER_SLOT)),
+                                               ("data", AttestationData), ("signature", BlsSignature)])
+    attestation = Container("Attestation", [("aggregation_bits", Bitlist(p.MAX_VALIDATORS_PER_SLOT)), ("data", AttestationData),
+                                            ("committee_bits", Bitvector(p.MAX_COMMITTEES_PER_SLOT)), ("signature", BlsSignature)])
+    attester_slashing = Container("AttesterSlashing", [("attestation_1", indexed), ("attestation_2", indexed)])
+    sync_aggregate = Container("SyncAggregate", [("sync_committee_bits", Bitvector(p.SYNC_COMMITTEE_SIZE)),
+                                                 ("sync_committee_signature", BlsSignature)])
+    payload = Container("ExecutionPayload", [
+        ("parent_hash", Bytes32), ("fee_recipient", ExecutionAddress), ("state_root", Bytes32), ("receipts_root", Bytes32),
+        ("logs_bloom", ByteVector(p.BYTES_PER_LOGS_BLOOM)), ("prev_randao", Bytes32), ("block_number", uint64), ("gas_limit", uint64),
+        ("gas_used", uint64), ("timestamp", uint64), ("extra_data", ByteList(p.MAX_EXTRA_DATA_BYTES)), ("base_fee_per_gas", uint256),
+        ("block_hash", Bytes32), ("transactions", SSZList(ByteList(p.MAX_BYTES_PER_TRANSACTION), p.MAX_TRANSACTIONS_PER_PAYLOAD)),
+        ("withdrawals", SSZList(Withdrawal, p.MAX_WITHDRAWALS_PER_PAYLOAD)), ("blob_gas_used", uint64), ("excess_blob_gas", uint64),
+        ("deposit_receipts", SSZList(DepositReceipt, p.MAX_DEPOSIT_RECEIPTS_PER_PAYLOAD)),
+        ("withdrawal_requests", SSZList(ExecutionLayerWithdrawalRequest, p.MAX_WITHDRAWAL_REQUESTS_PER_PAYLOAD))])
+    body = Container("BeaconBlockBody", [
+        ("randao_reveal", BlsSignature), ("eth1_data", Eth1Data), ("graffiti", Bytes32),
+        ("proposer_slashings", SSZList(ProposerSlashing, p.MAX_PROPOSER_SLASHINGS)),
+        ("attester_slashings", SSZList(attester_slashing, p.MAX_ATTESTER_SLASHINGS_ELECTRA)),
+        ("attestations", SSZList(attestation, p.MAX_ATTESTATIONS_ELECTRA)), ("deposits", SSZList(Deposit, p.MAX_DEPOSITS)),
+        ("voluntary_exits", SSZList(SignedVoluntaryExit, p.MAX_VOLUNTARY_EXITS)), ("sync_aggregate", sync_aggregate),
+        ("execution_payload", payload), ("bls_to_execution_changes", SSZList(SignedBlsToExecutionChange, p.MAX_BLS_TO_EXECUTION_CHANGES)),
+        ("blob_kzg_commitments", SSZList(ByteVector(48), p.MAX_BLOB_COMMITMENTS_PER_BLOCK)),
+        ("consolidations", SSZList(SignedConsolidation, p.MAX_CONSOLIDATIONS))])
+    return Container("BeaconBlock", [("slot", uint64), ("proposer_index", uint64), ("parent_root", Root), ("state_root", Root),
+                                     ("body", body)])
+
+
 def compute_signing_root(obj_type: SSZType, obj, domain: bytes) -> bytes:
     """signing.rs:14-22."""
     return SigningData.htr({"object_root": obj_type.htr(obj), "domain": domain})

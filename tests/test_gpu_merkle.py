@@ -201,6 +201,12 @@ def test_generic_ssz_kinds_and_beacon_block(gpu):
         for fill in ("empty", "full", None, None, None):
             v = random_value(ot, r, fill)
             assert gpu.hash_tree_root(pt, ot.serialize(v)) == ot.htr(v), (preset, fill)
+    for preset in ("mainnet", "minimal"):  # electra/beacon_block.rs:17-63 (widening: the block that goes with the electra state)
+        pt = T.BeaconBlockElectra(T.ELECTRA_MAINNET if preset == "mainnet" else T.ELECTRA_MINIMAL)
+        ot = ossz.BeaconBlockElectra(ossz.BLOCK_ELECTRA_MAINNET if preset == "mainnet" else ossz.BLOCK_ELECTRA_MINIMAL)
+        for fill in ("empty", "full", None, None):
+            v = random_value(ot, r, fill)
+            assert gpu.hash_tree_root(pt, ot.serialize(v)) == ot.htr(v), ("electra", preset, fill)
     # wide sequences: pass + tile kernels under the generic plan
     for pt, ot, v in [(T.list_(T.uint64, 1 << 20), ossz.SSZList(ossz.uint64, 1 << 20), [r.randrange(1 << 64) for _ in range(70000)]),
                       (T.list_(T.bytevector(48), 4096), ossz.SSZList(ossz.ByteVector(48), 4096), [r.randbytes(48) for _ in range(3000)]),

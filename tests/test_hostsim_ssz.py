@@ -99,6 +99,28 @@ def test_beacon_block_deneb(preset):
     assert sim_htr(T.SigningData, sd)[1] == ssz.compute_signing_root(ot, v, dom)
 
 
+@pytest.mark.parametrize("preset", ["mainnet", "minimal"])
+def test_beacon_block_electra(preset):
+    """electra/beacon_block.rs:17-63: attestations with committee_bits over MAX_VALIDATORS_PER_SLOT-wide bitlists, the payload's
+    deposit receipts and withdrawal requests, signed consolidations -- through the same generic plan as the deneb block."""
+    pt = T.BeaconBlockElectra(T.ELECTRA_MAINNET if preset == "mainnet" else T.ELECTRA_MINIMAL)
+    ot = ssz.BeaconBlockElectra(ssz.BLOCK_ELECTRA_MAINNET if preset == "mainnet" else ssz.BLOCK_ELECTRA_MINIMAL)
+    v0 = ot.default()
+    rc, root, hashes = sim_htr(pt, ot.serialize(v0))
+    assert rc == 0 and root == ot.htr(v0) and hashes > 50
+    r = random.Random(23)
+    for fill in ("full", None, None, None):
+        v = random_value(ot, r, fill)
+        enc = ot.serialize(v)
+        rc, root, _ = sim_htr(pt, enc)
+        assert rc == 0
+        assert root == ot.htr(v), (preset, fill, len(enc))
+    # an electra block is not a deneb block: the same bytes under the deneb schema are rejected or hash differently
+    pd = T.BeaconBlockDeneb(T.MAINNET if preset == "mainnet" else T.MINIMAL)
+    rc_d, root_d, _ = sim_htr(pd, enc)
+    assert rc_d != 0 or root_d != root
+
+
 def test_reference_fixture_header_through_the_generic_entry():
     """deneb/blob_sidecar.rs:78-84: the sepolia header whose root test_oracle_ssz pins"""
     hdr = {"slot": 4996736, "proposer_index": 1508, "parent_root": bytes.fromhex("6b5d3b9ba1b0b0e1f2f5c5e4b5f7e4e0b2b0a4f0d0c7e1f3a5b7c9d1e3f5a7b9"),
