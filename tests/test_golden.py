@@ -52,10 +52,26 @@ def test_oracles_reproduce_the_ssz_fixture():
     assert cref.htr_validators(bytes.fromhex(v["ssz121"]))[0].hex() == v["hash_tree_root"]
     s = g["shuffling"]
     assert SH.compute_shuffled_indices(list(range(s["n"])), bytes.fromhex(s["seed"]), s["rounds"]) == s["permutation"]
+    # a block's root from its header fields and the body root (phase0/beacon_block.rs:66-81: five leaves)
+    for fork, b in g["blocks"].items():
+        enc = bytes.fromhex(b["ssz"])
+        leaves = [enc[0:8].ljust(32, b"\0"), enc[8:16].ljust(32, b"\0"), enc[16:48], enc[48:80], bytes.fromhex(b["body_root"])]
+        assert O.merkleize_chunks(leaves, 5).hex() == b["hash_tree_root"], fork
     # the state container's root from its field roots (the independent half of each state entry)
     for fork, st in g["states"].items():
         roots = [bytes.fromhex(r) for r in st["field_roots"]]
         assert O.merkleize_chunks(roots, len(roots)).hex() == st["hash_tree_root"], fork
+
+
+def test_lane_simulator_reproduces_the_block_vectors():
+    """the generic SSZ plan (the product's own planner and lane programs, on the CPU simulator) on the committed block encodings"""
+    from ethereum_consensus_amd import ssz_types as T
+    from tests.test_hostsim_ssz import sim_htr
+    g = _load("ssz.json")
+    for fork, b in g["blocks"].items():
+        pt = T.BeaconBlockDeneb(T.MINIMAL) if fork == "deneb" else T.BeaconBlockElectra(T.ELECTRA_MINIMAL)
+        rc, root, _ = sim_htr(pt, bytes.fromhex(b["ssz"]))
+        assert rc == 0 and root.hex() == b["hash_tree_root"], fork
 
 
 @pytest.fixture(scope="module")
@@ -92,6 +108,10 @@ def test_kernels_reproduce_the_ssz_fixture(gpu):
     g = _load("ssz.json")
     for fork, st in g["states"].items():
         assert ssz.hash_tree_root_beacon_state(fork, bytes.fromhex(st["ssz"]), ssz.MINIMAL).hex() == st["hash_tree_root"], fork
+    from ethereum_consensus_amd import ssz_types as T
+    for fork, b in g["blocks"].items():
+        pt = T.BeaconBlockDeneb(T.MINIMAL) if fork == "deneb" else T.BeaconBlockElectra(T.ELECTRA_MINIMAL)
+        assert ssz.hash_tree_root(pt, bytes.fromhex(b["ssz"])).hex() == b["hash_tree_root"], fork
     hdr = g["beacon_block_header"]
     assert ssz.hash_tree_root_beacon_block_header(bytes.fromhex(hdr["ssz"])).hex() == hdr["hash_tree_root"]
     v = g["validators_100"]

@@ -94,6 +94,15 @@ def ssz_fixture():
     from tests._statevalue import oracle_state_value
     fv = synthetic.state_fields(100, "minimal", seed=1)
     out["validators_100"] = {"ssz121": vals.hex(), "hash_tree_root": vt.htr(oracle_state_value(fv)["validators"]).hex()}
+    # a deneb and an electra block (minimal preset, seeded random values: tests/_sszrand.py), with the body's root as the
+    # independent half (the block container from its five field roots)
+    from tests._sszrand import random_value
+    out["blocks"] = {}
+    for k, (fork, t) in enumerate((("deneb", O.BeaconBlockDeneb(O.BLOCK_MINIMAL)), ("electra", O.BeaconBlockElectra(O.BLOCK_ELECTRA_MINIMAL)))):
+        v = random_value(t, random.Random(500 + k), None)
+        body_t = dict(t.fields)["body"]
+        out["blocks"][fork] = {"preset": "minimal", "ssz": t.serialize(v).hex(), "hash_tree_root": t.htr(v).hex(),
+                               "body_root": body_t.htr(v["body"]).hex()}
     seed = S(b"shuffle", 0)
     out["shuffling"] = {"seed": seed.hex(), "n": 333, "rounds": 10, "permutation": SH.compute_shuffled_indices(list(range(333)), seed, 10)}
     return out
@@ -101,7 +110,10 @@ def ssz_fixture():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]  # e.g. `tools/make_golden.py ssz.json`: the BLS fixture takes minutes of pure-Python pairings
     for name, fn in (("bls.json", bls_fixture), ("ssz.json", ssz_fixture)):
+        if only and name not in only:
+            continue
         with open(os.path.join(OUT, name), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
