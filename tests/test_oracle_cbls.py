@@ -128,3 +128,25 @@ def test_both_oracles_agree_on_randomly_mutated_tuples():
         py = B.fast_aggregate_verify([bytes(pks[48 * i:48 * i + 48])], bytes(msgs[32 * i:32 * i + 32]), bytes(sigs[96 * i:96 * i + 96]))
         assert py == cpp[i], (i, M.KINDS[kind[i]], py, cpp[i])
     assert {1, 2, 3, 5, 6, 0x43}.issubset(set(cpp))
+
+
+def test_both_oracles_agree_on_aggregates_with_damaged_members():
+    """tests/_blsaggcases.py (the corpus of the GPU suite's randomised test of `aggregate` and `eth_aggregate_public_keys`): the
+    Python and the C++ restatement return the same (status, bytes) on lists with damaged members -- short lists only: the
+    Python group checks are slow."""
+    from tests import _blsaggcases as A
+    r = random.Random(8)
+    sks = [r.randrange(1, B.R) for _ in range(6)]
+    msg = r.randbytes(32)
+    pks = [cbls.sk_to_pk(s) for s in sks]
+    sigs = [cbls.sign(s, msg) for s in sks]
+    cache = {}
+    seen = set()
+    for kind, members in A.cases(pks, sigs, 160, seed=19, max_len=4):
+        if len(members) > 6:
+            members = members[:6]
+        got = A.expect_cpp(kind, members, cbls, cache)
+        want = B.eth_aggregate_public_keys(members) if kind == "pk" else B.aggregate(members)
+        assert got == want, (kind, len(members), got[0], want[0])
+        seen.add((kind, got[0]))
+    assert {("pk", 0), ("sig", 0)}.issubset(seen) and len(seen) >= 5, seen
