@@ -770,6 +770,55 @@ def test_aggregate_verify_lengths_and_emptiness_against_both_oracles(gpu):
     assert {0, 1, 5}.issubset(seen), seen
 
 
+def test_randomised_aggregate_verify_against_the_cpp_oracle(gpu):
+    """crypto/bls.rs:95-112 over 150 seeded calls: 1 .. 40 (key, message) pairs with messages of 0 .. 120 bytes and repeats, and
+    on two calls out of three ONE thing wrong -- a damaged key (any kind, any position), a damaged aggregate signature (any kind),
+    a flipped message bit, a missing or an extra message, two messages swapped: the status equals the C++ oracle's on every call
+    (n = 0 and the length mismatches are the standard-pinned verdicts of DESIGN.md 6)."""
+    from oracle import cbls
+    from tests import _blsmutate as MU
+    r = random.Random(2027)
+    pool = 48
+    sks = [r.randrange(1, B.R) for _ in range(pool)]
+    pk_all = gpu.sk_to_pk_batch(b"".join(sk_bytes(s) for s in sks))
+    pks_pool = [pk_all[48 * i:48 * i + 48] for i in range(pool)]
+    seen = set()
+    for trial in range(150):
+        n = r.choice((1, 2, 3, 5, 8, 17, 40)) if r.random() < 0.7 else r.randrange(1, 41)
+        idx = [r.randrange(pool) for _ in range(n)]
+        msgs = [r.randbytes(r.choice((0, 1, 31, 32, 32, 32, 33, 120))) for _ in range(n)]
+        if n > 2 and r.random() < 0.4:
+            msgs[r.randrange(n)] = msgs[r.randrange(n)]  # a repeated message (allowed: crypto/bls.rs has no distinctness rule)
+        sig = _aggregate_signature(gpu, [sks[i] for i in idx], msgs)
+        pks = [pks_pool[i] for i in idx]
+        what = r.choice(("none", "pk", "sig", "msg", "drop", "extra", "swap"))
+        if what == "pk":
+            pos = r.randrange(n)
+            bad = bytearray(pks[pos])
+            MU.mutate_pk(bad, r.randrange(len(MU.PK_KINDS)), r, trial)
+            pks[pos] = bytes(bad)
+        elif what == "sig":
+            bad = bytearray(sig)
+            MU.mutate_sig(bad, r.randrange(len(MU.SIG_KINDS)), r, trial)
+            sig = bytes(bad)
+        elif what == "msg":
+            pos = r.randrange(n)
+            m = bytearray(msgs[pos] or b"\0")
+            m[r.randrange(len(m))] ^= 1 << r.randrange(8)
+            msgs[pos] = bytes(m)
+        elif what == "drop":
+            msgs = msgs[:-1]
+        elif what == "extra":
+            msgs = msgs + [r.randbytes(32)]
+        elif what == "swap" and n > 1:
+            a, b = r.sample(range(n), 2)
+            msgs[a], msgs[b] = msgs[b], msgs[a]
+        got, want = gpu.aggregate_verify_status(pks, msgs, sig), cbls.aggregate_verify(pks, msgs, sig)
+        assert got == want, (trial, what, n, got, want)
+        seen.add((what, got))
+    assert len({g for _, g in seen}) >= 4 and ("none", 0) in seen, seen
+
+
 def test_north_star_batch_of_2_pow_20_signatures_in_one_call(gpu):
     """north_star "Target": a 2^20-signature K = 1 batch.  1 048 576 tuples (the workload of `bench.py --tuples 1048576 --scaling
     strong`: SURVEY 8(d) config 2's generator and fault cycle, every 64th tuple corrupted, eight classes) through ONE
