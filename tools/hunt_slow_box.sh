@@ -18,6 +18,6 @@ if [ "$(cat gpurun_out/hunt_slow)" = "1" ] || [ -n "$HUNT_ALWAYS" ]; then
   [ "$(cat gpurun_out/hunt_slow)" = "1" ] && echo "SLOW BOX"
   # the driver's bench line as the library dispatches it on this box; then the small-batch paths with the lane-pair end of the
   # message stage forced (its hot loops -- one 43 KB doubling -- fit the instruction cache); then the dispatch parity cases
-  bash tools/gpu_visit.sh ${HUNT_TAG:-r04slow2} bench:--no-cpu-baseline py:h2c_small_probe.py env:ECGPU_TOWER=sums py:h2c_small_probe.py \
-       bench:--workload_slots_--no-cpu-baseline
+  bash tools/gpu_visit.sh ${HUNT_TAG:-r04slow2} bench:--no-cpu-baseline env:ECGPU_H2C_SPLIT_MAX=65536 bench:--workload_bls_--no-cpu-baseline_--no-aggregates \
+       unenv:ECGPU_H2C_SPLIT_MAX py:h2c_small_probe.py env:ECGPU_TOWER=sums py:h2c_small_probe.py
 fi
