@@ -629,6 +629,12 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     }
     {
         ProfScope ps("bls_pairing", s);
+        static const int ragged_tail = [] { const char* e = getenv("ECGPU_RAGGED_TAIL"); return e ? atoi(e) : 1; }();
+        static const u32 lane_round = [] {
+            hipDeviceProp_t prop;
+            return hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
+        }();
+        static const int g_m2_waves = [] { const char* e = getenv("ECGPU_M2_WAVES"); return e ? atoi(e) : 0; }();  // 2: the two-wave build of k_miller2 at every size
         // The three pairing paths over a sub-range [base, base + cnt) of the batch (every per-tuple array is indexed by tuple;
         // the key offsets are only ever differenced).
         auto run_lane = [&](u32 base, u32 cnt) {
@@ -651,7 +657,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             if (!fs) return ECGPU_ERR_OOM;
             {
                 ProfScope p2("bls_miller2", s);
-                hipLaunchKernelGGL(k_miller2, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s, (const A1*)agg + base, (const u8*)st_pk + base,
+                // up to half a round of lanes one wave per SIMD is all there is: the build with the whole register file
+                hipLaunchKernelGGL(2 * (u64)cnt <= lane_round && g_m2_waves != 2 ? k_miller2_w1 : k_miller2, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s,
+                                   (const A1*)agg + base, (const u8*)st_pk + base,
                                    d_pk_off ? d_pk_off + base : nullptr, (const A2*)hpts + base, (const A2*)sigpts + base, (const u8*)st_dec + base,
                                    (const u8*)st_grp + base, d_sigs96 + (size_t)96 * base, cnt, eth_variant, d_status + base, fs);
             }
@@ -669,11 +677,6 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         //   above                                       the lane kernel on the full rounds and on a tail of more than half a
         //                                               round; a shorter tail by the two rules above
         // On a box with slow instruction fetch: the lane groups at every size.  ECGPU_RAGGED_TAIL=0: no special tail.
-        static const int ragged_tail = [] { const char* e = getenv("ECGPU_RAGGED_TAIL"); return e ? atoi(e) : 1; }();
-        static const u32 lane_round = [] {
-            hipDeviceProp_t prop;
-            return hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
-        }();
         const bool slow_box = g_tower.load() == 2;  // large-code kernels crawl here: the 47 KB kernel at every size
         const bool auto_mode = g_pairing_mode == 3 || g_pairing_mode == 6;
         const u32 split_max = g_pairing_mode == 3 ? g_split_max_tuples : 0;  // auto1 (round 3's rule) has no split window

@@ -43,6 +43,8 @@ __global__ void k_finalexp(const Fp12* fs, u32 n, u8* status_out);
 // bls_pairing2_kernels.hip: the same check's Miller loop on two lanes per tuple, two waves per SIMD (bls_pair2.h)
 __global__ void k_miller2(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out, Fp12* fs);
+__global__ void k_miller2_w1(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
+                          const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out, Fp12* fs);
 __global__ void k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);
 __global__ void k_aggv_final(const u8* st_pk, u32 n_pks, u32 n_msgs, const u8* st_dec, const u8* st_grp, Fp12* fs, u8* status_out);
 

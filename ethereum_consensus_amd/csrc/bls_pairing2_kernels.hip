@@ -4,14 +4,21 @@
 //   k_miller2    lanes 2t, 2t + 1 = tuple t: status algebra, 2-pair Miller loop -> the Miller value f in memory
 //   (k_finalexp, bls_pairing_kernels.hip: one lane per tuple, final exponentiation of f, status)
 // (the e(pk, H(m)) == e(g1, sig) equation of /root/reference/ethereum-consensus/src/crypto/bls.rs:71,126)
+// bls_pairing2_kernels_w1.hip compiles this file again with the whole register file (k_miller2_w1): up to half a round of lanes
+// the two lanes per tuple are still ONE wave per SIMD, and 512 registers hold what 256 spill (17.6 GB of private-segment traffic
+// per 65 536-tuple launch, profiles/r04v3split_*).
 #define ECG_LANE_SLOTS 6
-#define ECG_BLS_WAVES 2
+#ifndef ECG_M2_WAVES
+#define ECG_M2_WAVES 2
+#define ECG_M2_NAME k_miller2
+#endif
+#define ECG_BLS_WAVES ECG_M2_WAVES
 #include "bls_kernels.h"
 #include "bls_pair2.h"
 
 namespace ecg {
 
-__global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller2(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts,
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_M2_WAVES) ECG_M2_NAME(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts,
                                                          const u8* st_dec, const u8* st_grp, const u8* sigs96, u32 n, int eth_variant,
                                                          u8* status_out, Fp12* fs) {
     const u32 lane = blockIdx.x * BLS_BLOCK + threadIdx.x;

@@ -67,11 +67,12 @@ ECG_HD Fp vm3_sum(const Vm3Regs& R, const u32* w) {
     return fp_sumprod<N>(a, b);
 }
 
-// the arithmetic of one lane in one round of class n (wave-uniform): its own result.  Two compiled sums (the generator pads a
+// the arithmetic of one lane in one round of class n (wave-uniform): its own result.  Three compiled sums -- 3, 4 and 7 products; round 2 / 3: 4 and 7 -- (the generator pads a
 // round of N products to the next class: unused slots multiply ZERO by ZERO): together with the interpreter loop they are the
-// whole hot code, ~40 KB -- inside the 64 KB instruction cache.
+// whole hot code, ~50 KB -- inside the 64 KB instruction cache.
 ECG_HD Fp vm3_own(u32 n, const Vm3Regs& R, const u32* w) {
     if (n == 0) return vm3_load(R, (w[0] >> 8) & 255);
+    if (n <= 3) return vm3_sum<3>(R, w);
     if (n <= 4) return vm3_sum<4>(R, w);
     return vm3_sum<7>(R, w);
 }

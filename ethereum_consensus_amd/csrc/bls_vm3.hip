@@ -101,6 +101,8 @@ ECG_D void vm3_run(const Vm3Desc& d, const Vm3Regs& R, u32 slot, bool idle = fal
         Fp own;
         if (n == 0)  // wave-uniform
             own = vm3_load(R, (w01.x >> 8) & 255);
+        else if (n <= 3)
+            own = vm3_round_sum<3>(R, w01);
         else if (n <= 4)
             own = vm3_round_sum<4>(R, w01);
         else

@@ -39,8 +39,10 @@ LIMIT = 600   # sum over the terms of bound(a) * bound(b), in units of p^2; the 
 MAXN = 7      # products per sum (descriptor: dst + 7 + 7 register numbers)
 MAXDER = 4    # derived outputs per lane per round
 CONST_BASE = 192  # register numbers >= CONST_BASE name the workgroup's shared constant area, not the tuple's own slice
-CLASSES = (4, 7)  # the sums the kernel carries compiled (csrc/bls_vm3.hip): a round of N products runs as the next class up.
-                  # Two bodies keep the hot loop at ~40 KB -- inside the 64 KB instruction cache -- for +5 % multiply-adds
+CLASSES = (3, 4, 7)  # the sums the kernel carries compiled (csrc/bls_vm3.hip): a round of N products runs as the next class up.
+                     # Round 2 / 3: (4, 7), ~40 KB of hot loop.  Round 4 adds the 3-term body (+7 KB, still inside the 64 KB
+                     # instruction cache): 195 of part A's 407 rounds have at most three terms per sum (the point arithmetic),
+                     # -7 % of its multiply slots; 6 -> 7 and 5 -> 7 stay padded (a 6-term body would not fit)
 
 
 # ------------------------------------------------------------------------------------------------------------------
