@@ -485,9 +485,9 @@ static const int g_h2c_finish_lanes = [] {
     const char* e = getenv("ECGPU_H2C_FINISH_LANES");
     return e ? atoi(e) : 2;
 }();
-static const u32 g_vm_max_tuples = [] {  // (round 3: 24 576, the crossover with the lane kernel's 22 ms; round 4: with the split path's 16.8 ms)
+static const u32 g_vm_max_tuples = [] {  // (round 3: 24 576, the crossover with the lane kernel's 22 ms; round 4: with the split path's 12.4 ms)
     const char* e = getenv("ECGPU_VM_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : 21504u;
+    return e ? (u32)strtoul(e, nullptr, 10) : 13312u;
 }();
 static const u32 g_split_max_tuples = [] {  // up to here two lanes per tuple are still ONE wave per SIMD for the Miller loop
     const char* e = getenv("ECGPU_SPLIT_MAX");
@@ -634,6 +634,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             hipDeviceProp_t prop;
             return hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
         }();
+        static const int g_finalexp_lanes = [] { const char* e = getenv("ECGPU_FINALEXP_LANES"); return e ? atoi(e) : 0; }();
         static const int g_m2_waves = [] { const char* e = getenv("ECGPU_M2_WAVES"); return e ? atoi(e) : 0; }();  // 2: the two-wave build of k_miller2 at every size
         // The three pairing paths over a sub-range [base, base + cnt) of the batch (every per-tuple array is indexed by tuple;
         // the key offsets are only ever differenced).
@@ -655,25 +656,33 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         auto run_split = [&](u32 base, u32 cnt) -> int {
             Fp12* fs = (Fp12*)ar.take((size_t)cnt * sizeof(Fp12));
             if (!fs) return ECGPU_ERR_OOM;
+            const bool one_wave = 2 * (u64)cnt <= lane_round && g_m2_waves != 2;
             {
                 ProfScope p2("bls_miller2", s);
                 // up to half a round of lanes one wave per SIMD is all there is: the build with the whole register file
-                hipLaunchKernelGGL(2 * (u64)cnt <= lane_round && g_m2_waves != 2 ? k_miller2_w1 : k_miller2, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s,
+                hipLaunchKernelGGL(one_wave ? k_miller2_w1 : k_miller2, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s,
                                    (const A1*)agg + base, (const u8*)st_pk + base,
                                    d_pk_off ? d_pk_off + base : nullptr, (const A2*)hpts + base, (const A2*)sigpts + base, (const u8*)st_dec + base,
                                    (const u8*)st_grp + base, d_sigs96 + (size_t)96 * base, cnt, eth_variant, d_status + base, fs);
             }
             {
                 ProfScope p3("bls_finalexp", s);
-                hipLaunchKernelGGL(k_finalexp, grid_for(cnt), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, cnt, d_status + base);
+                // on the lane pair as well (bls_finalexp2.h) where that is one wave per SIMD: 32 768 tuples 10.4 -> 6.3 ms; with two
+                // waves per SIMD it is 11.6 ms against the one-lane kernel's 10.4 (profiles/r04f2_*).  ECGPU_FINALEXP_LANES=1 | 2 forces.
+                if (g_finalexp_lanes == 2 || (g_finalexp_lanes == 0 && one_wave))
+                    hipLaunchKernelGGL(one_wave ? k_finalexp2_w1 : k_finalexp2, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, cnt,
+                                       d_status + base);
+                else
+                    hipLaunchKernelGGL(k_finalexp, grid_for(cnt), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, cnt, d_status + base);
             }
             return ECGPU_SUCCESS;
         };
         // Dispatch.  The lane kernel takes the whole register file: ONE wave per SIMD, a batch runs in rounds of
         // lane_round tuples (65 536 on this chip) at 22.3 ms each however full the round is.  In auto mode on a healthy box:
-        //   up to ECGPU_VM_MAX tuples                   the lane groups (latency 3.5 ms, 0.78 ms per 1 000 tuples)
-        //   up to ECGPU_SPLIT_MAX = half a round        the two-lane Miller loop, one wave per SIMD, + the one-lane final
-        //                                               exponentiation on half the SIMDs: 16.7 .. 17.2 ms (profiles/r04y_mid_size_*)
+        //   up to ECGPU_VM_MAX tuples                   the lane groups (latency 3.5 ms, ~0.55 ms per 1 000 tuples beyond 4 096)
+        //   up to ECGPU_SPLIT_MAX = half a round        Miller loop and final exponentiation on two lanes per tuple, one wave per
+        //                                               SIMD each: 12.3 .. 12.4 ms (profiles/r04f2_*; 16.4 with the one-lane final
+        //                                               exponentiation, profiles/r04y_mid_size_*)
         //   above                                       the lane kernel on the full rounds and on a tail of more than half a
         //                                               round; a shorter tail by the two rules above
         // On a box with slow instruction fetch: the lane groups at every size.  ECGPU_RAGGED_TAIL=0: no special tail.

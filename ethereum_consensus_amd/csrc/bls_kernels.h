@@ -40,6 +40,8 @@ __global__ void k_h2c_calls(const u8* msgs, const u64* msg_off, u32 n, A2* hpts)
 __global__ void k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out);
 __global__ void k_finalexp(const Fp12* fs, u32 n, u8* status_out);
+__global__ void k_finalexp2(const Fp12* fs, u32 n, u8* status_out);
+__global__ void k_finalexp2_w1(const Fp12* fs, u32 n, u8* status_out);
 // bls_pairing2_kernels.hip: the same check's Miller loop on two lanes per tuple, two waves per SIMD (bls_pair2.h)
 __global__ void k_miller2(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out, Fp12* fs);

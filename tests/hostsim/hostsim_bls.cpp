@@ -13,6 +13,7 @@
 #include "bls_vm3_prog.h"
 #include "bls_pair2.h"
 #include "bls_g2_pair2.h"
+#include "bls_finalexp2.h"
 #include <atomic>
 
 using namespace ecg;
@@ -317,12 +318,33 @@ void hs_pairing_split(const u8* p_xy, const int* p_inf, const u8* q_xy, const in
     std::thread t1(lane, 1u);
     lane(0u);
     t1.join();
-    if (miller_only) {
+    if (miller_only == 1) {
         out_fp12(f, out);
         return;
     }
     Fp12 e;
-    final_exponentiation(e, f);
+    if (miller_only == 2) {
+        // ... and the final exponentiation on the lane pair as well (bls_finalexp2.h: what k_finalexp2 runs); out[576] = the
+        // pair's verdict "is one" (must be the same on both lanes)
+        int verdict[2] = {-1, -1};
+        auto lane2 = [&](u32 s) {
+            t_pair_channel = &ch;
+            t_pair_lane = s;
+            H12 h, r;
+            h12_load(h, &f);
+            h_final_exponentiation(r, h);
+            verdict[s] = h12_is_one(r) ? 1 : 0;
+            h12_store(&e, r);
+        };
+        g_pair_arrivals[0] = 0;
+        g_pair_arrivals[1] = 0;
+        std::thread t2(lane2, 1u);
+        lane2(0u);
+        t2.join();
+        out[576] = (u8)(verdict[0] == verdict[1] ? verdict[0] : 0xee);
+    } else {
+        final_exponentiation(e, f);
+    }
     out_fp12(e, out);
 }
 // the one-lane Miller value, for comparison with the split one

@@ -648,17 +648,20 @@ def config2_workload(gpu, tmp_path_factory):
     ("sums", "split", 65536, 1, "split"),   # round 4: Miller loop on two lanes per tuple (k_miller2, two waves per SIMD) + k_finalexp
     ("sums", "split", 65535, 1, "split"),   # ... ragged: the last lane pair of the last wave is missing
     ("sums", "split", 4097, 1, "split"),    # ... and a small ragged batch (65 waves on 1 024 SIMDs)
+    ("sums", "split2", 65536, 1, "split"),  # ... and the final exponentiation on the lane pair as well (k_finalexp2, two waves per SIMD)
+    ("sums", "split2", 32768, 1, "split"),  # ... both kernels in their one-wave builds (k_miller2_w1 + k_finalexp2_w1: half a round of lanes)
+    ("sums", "split2", 4097, 1, "split"),   # ... ragged
     ("sums", "vm3", 8192, 1, "vm3"),        # the sum-of-products lane groups: the small-batch path
     ("sums", "vm3", 65536, 1, "vm3"),       # ... and at full size
     ("calls", "auto", 65536, 2, "vm3"),     # a box with slow instruction fetch: compact G2 stage kernels + lane groups at every size
     ("sums", "auto", 4096, 1, "vm3"),       # a small batch as dispatched by default: two-lane message stage + lane groups
     ("calls", "auto", 4096, 2, "vm3"),      # ... and on the compact-code build (k_h2c_map_calls / k_h2c_finish_calls, k_sig_calls)
     ("sums", "lane", 65535, 1, "lane"),     # a ragged batch on the lane kernel: the last wave is one lane short (lane slots, statuses)
-    ("sums", "auto", 21504, 1, "vm3"),      # the default dispatch on either side of ECGPU_VM_MAX: the last size of the lane groups ...
-    ("sums", "auto", 21505, 1, "split"),    # ... the first of the two-lane Miller loop (one wave per SIMD up to half a round of lanes) ...
+    ("sums", "auto", 13312, 1, "vm3"),      # the default dispatch on either side of ECGPU_VM_MAX: the last size of the lane groups ...
+    ("sums", "auto", 13313, 1, "split"),    # ... the first of the two-lane Miller loop (one wave per SIMD up to half a round of lanes) ...
     ("sums", "auto", 32768, 1, "split"),    # ... its last ...
     ("sums", "auto", 32769, 1, "lane"),     # ... and the first of the lane kernel (513 waves, the last with one lane)
-    ("sums", "auto1", 24577, 1, "lane"),    # round 3's rule (no split window), kept selectable
+    ("sums", "auto1", 13313, 1, "lane"),    # round 3's rule (no split window), kept selectable
     ("sums", "auto", 65536 + 4097, 1, "lane"),   # ragged batches beyond one round of lanes: 65 536 on the lane kernel, the tail on the lane groups
     ("sums", "auto", 65536 + 30001, 1, "lane"),  # ... a longer tail on the two-lane Miller loop
     ("sums", "lane", 65536 + 130, 1, "lane"),    # ... and the same shape forced through the lane kernel alone (a second round of three waves)
@@ -675,6 +678,8 @@ def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, 
     path, info = config2_workload
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ECGPU_TOWER=tower, ECGPU_PAIRING=pairing, PYTHONPATH=root)
+    if pairing == "split2":
+        env.update(ECGPU_PAIRING="split", ECGPU_FINALEXP_LANES="2")
     out = subprocess.run([sys.executable, "-m", "tests._bls_config2", "run", path, str(n), str(want_tower), want_path], env=env, cwd=root,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

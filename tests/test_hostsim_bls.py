@@ -477,3 +477,32 @@ def test_miller_loop_on_two_lanes_per_tuple_equals_the_one_lane_loop():
     L.hs_pairing_split(a1(pk) + a1(B.g1_neg(B.G1)), zero2, a2(H) + a2(sig), zero2, 0, out)
     assert f12_un(out.raw) == B.F12_ONE
     assert L.hs_column_overflows() == 0
+
+
+def test_final_exponentiation_on_two_lanes_per_tuple_equals_the_one_lane_one():
+    """csrc/bls_finalexp2.h (k_finalexp2): the final exponentiation on a lane pair -- easy part, the five exponentiations by x with
+    Granger-Scott and compressed squarings, decompression (an Fp2 inversion across the pair), Frobenius maps -- as two host threads
+    in lock step.  Its value equals the one-lane routine's coefficient by coefficient and the oracle's; the verdict `is one` is
+    the same on both lanes, true for a valid verification equation and false for a forged one."""
+    r = random.Random(37)
+    L = lib()
+    out, ref = ctypes.create_string_buffer(577), ctypes.create_string_buffer(577)
+    zero2 = (ctypes.c_int * 2)(0, 0)
+    for trial in range(2):
+        P1, Q1 = B.g1_mul(B.G1, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R))
+        P2, Q2 = B.g1_mul(B.G1, r.randrange(B.R)), B.g2_mul(B.G2, r.randrange(B.R))
+        L.hs_pairing_split(a1(P1) + a1(P2), zero2, a2(Q1) + a2(Q2), zero2, 2, out)
+        L.hs_pairing_split(a1(P1) + a1(P2), zero2, a2(Q1) + a2(Q2), zero2, 0, ref)
+        assert out.raw[:576] == ref.raw[:576] and out.raw[576] == 0
+        assert f12_un(out.raw[:576]) == B.final_exponentiation(B.f12_mul(B.miller_loop(P1, Q1), B.miller_loop(P2, Q2)))
+    sk = r.randrange(1, B.R)
+    H = B.hash_to_g2(b"two lanes per tuple, to the end")
+    pk, sig = B.g1_mul(B.G1, sk), B.g2_mul(H, sk)
+    L.hs_pairing_split(a1(pk) + a1(B.g1_neg(B.G1)), zero2, a2(H) + a2(sig), zero2, 2, out)
+    assert f12_un(out.raw[:576]) == B.F12_ONE and out.raw[576] == 1
+    L.hs_pairing_split(a1(pk) + a1(B.g1_neg(B.G1)), zero2, a2(H) + a2(B.g2_mul(H, sk + 1)), zero2, 2, out)
+    assert out.raw[576] == 0
+    # both pairs at infinity: the Miller value is 1, and so is its power
+    L.hs_pairing_split(a1(P1) + a1(P2), zero2, a2(None) + a2(None), (ctypes.c_int * 2)(1, 1), 2, out)
+    assert f12_un(out.raw[:576]) == B.F12_ONE and out.raw[576] == 1
+    assert L.hs_column_overflows() == 0
