@@ -541,11 +541,14 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     // two megabyte-sized instruction streams through one instruction cache: profiles/r02l_stage_overlap.txt).
     const bool key_heavy = d_pk_off && !reg && n_pks >= 4ull * n;
     const bool overlap_sides = g_side_overlap != 0 && !d_pk_off && !reg && g_tower.load() != 2;  // experiment: see g_side_overlap
-    // Small batches of any shape (round 4; before: only aggregates behind a registry or a long key list): at most 16 384
-    // tuples leave three quarters of the SIMDs idle under each stage, and the three stages do not depend on each other -- a
+    // Small batches of any shape (round 4; before: only aggregates behind a registry or a long key list): at most half a round
+    // of lanes leaves half of the SIMDs idle under each stage, and the three stages do not depend on each other -- a
     // lone verify_signature call is the sum of three latencies otherwise.  ECGPU_FORK_SMALL=0: the round-3 condition.
     static const int fork_small = [] { const char* e = getenv("ECGPU_FORK_SMALL"); return e ? atoi(e) : 1; }();
-    const bool fork = (n <= 16384 && (fork_small || (d_pk_off && (reg || key_heavy)))) || overlap_sides;
+    // (up to half a round of lanes: 32 768 tuples 19.3 -> 17.8 ms, 20 000 tuples 18.9 -> 16.3 with the stages side by side,
+    // profiles/r04f4_*; round 3 stopped at 16 384.  ECGPU_FORK_MAX overrides.)
+    static const u32 fork_max = [] { const char* e = getenv("ECGPU_FORK_MAX"); return e ? (u32)strtoul(e, nullptr, 10) : 32768u; }();
+    const bool fork = (n <= fork_max && (fork_small || (d_pk_off && (reg || key_heavy)))) || overlap_sides;
     hipStream_t s2 = s, s3 = s;  // message stage / signature stage
     if (fork) {
         int rc = ax.init();
