@@ -86,7 +86,8 @@ def effective_cores():
 
 
 # translation unit whose objects hold each kernel the roofline is quoted on (lib/build_manifest.json is keyed by it)
-KERNEL_UNIT = {"k_pairing": "bls_pairing_kernels.hip", "k_miller2": "bls_pairing2_kernels.hip", "k_finalexp": "bls_pairing_kernels.hip", "k_vm3_pair_a": "bls_vm3.hip",
+KERNEL_UNIT = {"k_pairing": "bls_pairing_kernels.hip", "k_miller2": "bls_pairing2_kernels.hip", "k_finalexp": "bls_pairing_kernels.hip", "k_finalexp2": "bls_finalexp2_kernels.hip",
+               "k_vm3_pair_a": "bls_vm3.hip",
                "k_vm3_pair_c": "bls_vm3.hip", "k_merkle_pass<2, ValidatorLeaves>": "merkle.hip"}
 
 

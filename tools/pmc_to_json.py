@@ -5,7 +5,7 @@ import glob
 import json
 import sys
 
-KERNELS = {"k_pairing": "ecg::k_pairing(", "k_miller2": "ecg::k_miller2(", "k_finalexp": "ecg::k_finalexp(", "k_vm3_pair_a": "ecg::k_vm3_pair_a(",
+KERNELS = {"k_pairing": "ecg::k_pairing(", "k_miller2": "ecg::k_miller2(", "k_finalexp": "ecg::k_finalexp(", "k_finalexp2": "ecg::k_finalexp2(", "k_vm3_pair_a": "ecg::k_vm3_pair_a(",
            "k_vm3_pair_c": "ecg::k_vm3_pair_c(", "k_merkle_pass<2, ValidatorLeaves>": "k_merkle_pass<2, ecg::ValidatorLeaves>"}
 
 
