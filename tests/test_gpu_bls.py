@@ -717,7 +717,8 @@ def mutated_workload(gpu, tmp_path_factory):
 
 
 @pytest.mark.parametrize("tower,pairing,want_tower,want_path", [("sums", "lane", 1, "lane"), ("sums", "vm3", 1, "vm3"), ("calls", "auto", 2, "vm3"),
-                                                                ("sums", "split", 1, "split")])
+                                                                ("sums", "split", 1, "split"), ("sums", "split2", 1, "split"),
+                                                                ("sums", "auto:30000", 1, "split")])
 def test_randomised_differential_parity_over_mutated_encodings(mutated_workload, tower, pairing, want_tower, want_path):
     """The negative space at scale: the whole 65 536-entry status vector of a batch in which every
     third tuple carries a seeded random mutation -- flag bits, x >= p, sign flips, swapped G2 halves, points outside the
@@ -730,12 +731,19 @@ def test_randomised_differential_parity_over_mutated_encodings(mutated_workload,
     import sys
     path, info = mutated_workload
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # "split2": the final exponentiation on the lane pair as well (k_finalexp2); "auto:30000": the first 30 000 tuples as the
+    # default dispatch runs them -- side stages forked over three queues, both halves of the check in their one-wave builds
+    n = 65536
+    if ":" in pairing:
+        pairing, n = pairing.split(":")[0], int(pairing.split(":")[1])
     env = dict(os.environ, ECGPU_TOWER=tower, ECGPU_PAIRING=pairing, PYTHONPATH=root)
-    out = subprocess.run([sys.executable, "-m", "tests._bls_config2", "run", path, "65536", str(want_tower), want_path], env=env, cwd=root,
+    if pairing == "split2":
+        env.update(ECGPU_PAIRING="split", ECGPU_FINALEXP_LANES="2")
+    out = subprocess.run([sys.executable, "-m", "tests._bls_config2", "run", path, str(n), str(want_tower), want_path], env=env, cwd=root,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
-    assert res["ok"] and res["n"] == 65536 and res["python_samples_checked"] >= 256, res
+    assert res["ok"] and res["n"] == n and res["python_samples_checked"] >= (256 if n == 65536 else 100), res
 
 
 def test_aggregate_verify_lengths_and_emptiness_against_both_oracles(gpu):
