@@ -12,7 +12,7 @@ of the same size (weak scaling); the only collective is the RCCL all-gather of t
 verify status bytes (bls) / of the 32-byte roots (merkle).  `--tuples 1048576 --scaling strong` is north_star's
 2^20-signature batch: the total is fixed and rank g verifies shard_range(2^20, g, N).
 The default line (N = 1, no flags) carries every configuration as a sub-record: "merkle", "aggregates_k2048", "block",
-"strong_2p20", "epoch", "slots".
+"strong_2p20", "epoch", "slots", "half_round_32768".
 """
 from __future__ import annotations
 
@@ -583,8 +583,11 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
     if path == 3:  # the sum-of-products lane groups ran the pairing check (ECGPU_PAIRING=vm3, or a box with slow instruction fetch)
         pairing_kernel = "k_vm3_pair_a + k_vm3_pair_c"
         ops["bls_pairing"] = (0, 0, vm3_multiplies_per_tuple())
-    if path == 5:  # Miller loop on two lanes per tuple (two waves per SIMD), final exponentiation on one: the same multiplies
-        pairing_kernel = "k_miller2 + k_finalexp"
+    if path == 5:  # Miller loop on two lanes per tuple; final exponentiation on one lane, or (up to half a round of lanes, or when
+        # ECGPU_FINALEXP_LANES=2) on the lane pair as well: the same multiplies either way
+        two = os.environ.get("ECGPU_FINALEXP_LANES", "0")
+        pair_too = two == "2" or (two == "0" and 2 * n <= 65536 and os.environ.get("ECGPU_M2_WAVES") != "2")
+        pairing_kernel = "k_miller2_w1 + k_finalexp2_w1" if pair_too and 2 * n <= 65536 else ("k_miller2 + k_finalexp2" if pair_too else "k_miller2 + k_finalexp")
     mults_per_sig = sum(m * 351 + s_ * 273 + x for m, s_, x in ops.values())
     stages = {}
     for tag in ops:
@@ -1244,6 +1247,11 @@ def main():
         a4 = copy.copy(args)
         a4.steps, a4.warmup = 64, 2
         line["slots"] = sub_record(finish(run_slots(a4, L, torch, dist, rank, world), a4, world, dist, torch))
+        # half a round of lanes (32 768 tuples of the same workload): the three side stages side by side on three hardware queues,
+        # Miller loop and final exponentiation on two lanes per tuple in their one-wave builds
+        a5 = copy.copy(args)
+        a5.steps, a5.warmup = 5, 2
+        line["half_round_32768"] = sub_record(finish(run_bls(a5, L, torch, dist, rank, world, n_total=32768, strong=False), a5, world, dist, torch))
     # box self-check (csrc/selfcheck.hip): 2^21 multiply-adds per lane as loops over 8 KB .. 1 MB of code.  On a healthy box
     # they take the same time; where the large ones are several times slower, so are the sums-of-products lane kernels, and
     # the library has switched that rank to its compact-code build.  Every rank checks its own GPU: with N > 1 the slowest

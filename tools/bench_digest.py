@@ -10,7 +10,7 @@ if "stage_ms" in r:
     print("  stages", {k: round(v, 2) for k, v in r["stage_ms"].items()}, "T mult/s", {k: round(v, 1) for k, v in r["valu_int"]["achieved"].items()})
 if r.get("pairing_parts_ms"):
     print("  pairing parts", {k: round(v, 2) for k, v in r["pairing_parts_ms"].items()})
-for key in ("aggregates_k2048", "merkle", "epoch", "slots", "strong_2p20", "merkle_strong", "merkle_sharded_emulated"):
+for key in ("aggregates_k2048", "merkle", "epoch", "slots", "strong_2p20", "half_round_32768", "merkle_strong", "merkle_sharded_emulated"):
     if key in d:
         e = d[key]
         print("  %s: %.3f ms/step  %.4g %s  check %s" % (key, e.get("ms_per_step", 0), e.get("value", 0), e.get("unit"), e.get("check")))
