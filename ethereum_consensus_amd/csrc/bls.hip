@@ -633,10 +633,14 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     {
         ProfScope ps("bls_pairing", s);
         static const int ragged_tail = [] { const char* e = getenv("ECGPU_RAGGED_TAIL"); return e ? atoi(e) : 1; }();
-        static const u32 lane_round = [] {
+        // lanes of one wave per SIMD on THIS device (per device: a process may drive different devices from different threads)
+        static std::atomic<u32> lane_rounds[MAX_DEVICES] = {};
+        u32 lane_round = lane_rounds[current_device()].load(std::memory_order_relaxed);
+        if (!lane_round) {
             hipDeviceProp_t prop;
-            return hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
-        }();
+            lane_round = hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
+            lane_rounds[current_device()].store(lane_round, std::memory_order_relaxed);
+        }
         static const int g_finalexp_lanes = [] { const char* e = getenv("ECGPU_FINALEXP_LANES"); return e ? atoi(e) : 0; }();
         static const int g_m2_waves = [] { const char* e = getenv("ECGPU_M2_WAVES"); return e ? atoi(e) : 0; }();  // 2: the two-wave build of k_miller2 at every size
         // The three pairing paths over a sub-range [base, base + cnt) of the batch (every per-tuple array is indexed by tuple;

@@ -11,6 +11,7 @@
 
 #include "merkle_driver.h"
 #include "state_plan.h"
+#include "state_tree_host.h"
 
 #include <cstdlib>
 
@@ -50,14 +51,14 @@ struct ShardTop {
 constexpr u32 SHARD_FIELD_SLOTS[N_SHARDED_LISTS] = {11, 12, 15, 16, 21};
 
 static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, StatePlan& plan, int fork, bool dev_check,
-                          u8* d_root, const u8* d_vroots, const u8* ext_roots, u8* d_field_roots, int* d_status, const u8* ext_src,
+                          u8* d_root, const ResidentTrees* trees, const u8* ext_roots, u8* d_field_roots, int* d_status, const u8* ext_src,
                           u64 ext_total, const u8* ext2_src = nullptr);
 
-// d_vroots != nullptr (resident state): the 32-byte hash_tree_root of every validator record is cached there and kept
-// current by the caller, so the registry enters the tree as a list of 2^20 ready chunks (1.0 M hash64) instead of 121-byte
-// records (9.4 M).
+// trees != nullptr (resident state): every big field with a cached tree (state_tree.h: interior nodes kept on the device,
+// brought up to date along dirty paths by the caller) enters the root as ONE finishing job over the <= 512 nodes of its
+// tree's top cached level -- no pass, no tile stage: a mainnet root is ~7 k hash64 here instead of 10.1 M.
 static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, const u8* h_fixed,
-                             int preset, u8* d_root, const u8* d_vroots = nullptr, int fork = FORK_DENEB, const u8* ext_roots = nullptr,
+                             int preset, u8* d_root, const ResidentTrees* trees = nullptr, int fork = FORK_DENEB, const u8* ext_roots = nullptr,
                              const u8* h_payload_fixed = nullptr, u8* d_field_roots = nullptr, int* d_status = nullptr,
                              const ShardTop* shard = nullptr) {
     StatePlan plan;
@@ -125,7 +126,7 @@ static int state_root_device(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n
         }
     }
     const bool dev_check = fork >= FORK_BELLATRIX && !h_payload_fixed && plan.payload_header_off != ~0ull;
-    return run_state_plan(s, c, d_ssz, n_bytes, plan, fork, dev_check, d_root, d_vroots, ext_roots, d_field_roots, d_status,
+    return run_state_plan(s, c, d_ssz, n_bytes, plan, fork, dev_check, d_root, trees, ext_roots, d_field_roots, d_status,
                           shard ? shard->d_all : nullptr, shard ? 32ull * N_SHARDED_LISTS * shard->world : 0, shard ? shard->d_keep : nullptr);
 }
 
@@ -181,18 +182,20 @@ static int state_shard_subroots_device(hipStream_t s, ThreadCtx* c, const u8* d_
 }
 
 static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_bytes, StatePlan& plan, int fork, bool dev_check,
-                          u8* d_root, const u8* d_vroots, const u8* ext_roots, u8* d_field_roots, int* d_status, const u8* ext_src,
+                          u8* d_root, const ResidentTrees* trees, const u8* ext_roots, u8* d_field_roots, int* d_status, const u8* ext_src,
                           u64 ext_total, const u8* ext2_src) {
-    std::vector<const u8*> fptr(plan.bigs.size());
-    for (size_t i = 0; i < plan.bigs.size(); i++) {
-        BigField& b = plan.bigs[i];
-        fptr[i] = d_ssz + b.src;
-        if (d_vroots && b.kind == LEAF_VALIDATORS) {
-            b.kind = LEAF_CHUNKS;
-            b.bytes = 32ull * b.n0;
-            fptr[i] = d_vroots;
+    // resident state: the cached fields leave the plan; each comes back further down as ONE unit of the tail
+    std::vector<std::pair<u32, u32>> cached;  // (tree slot = position in the plan, field-root chunk)
+    if (trees) {
+        std::vector<BigField> keep;
+        for (size_t i = 0; i < plan.bigs.size(); i++) {
+            if (i < TREE_MAX_FIELDS && trees->f[i].live) cached.push_back({(u32)i, plan.bigs[i].out_chunk});
+            else keep.push_back(plan.bigs[i]);
         }
+        plan.bigs.swap(keep);
     }
+    std::vector<const u8*> fptr(plan.bigs.size());
+    for (size_t i = 0; i < plan.bigs.size(); i++) fptr[i] = d_ssz + plan.bigs[i].src;
     // ---- device buffers --------------------------------------------------------------------------
     // Everything the root needs from the host -- the tail's plan, its zeroed tickets, the gather descriptors and the (zeroed)
     // small-chunk buffer -- is ONE block, uploaded by one copy from a pinned slot in front of the passes.  (Round 3 first put
@@ -221,6 +224,10 @@ static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_by
     // The device entry never sees the payload header on the host: the extra_data offset word the host entries check
     // (state_plan.h) is compared on the device (dev_check), and a mismatch poisons the root (32 x 0xFF) and sets *d_status.
     u64 hc = plan.small_hashes;
+    for (const auto& sc : cached) {  // finishing jobs over the cached trees' top levels (offsets relative to the small-chunk buffer)
+        plan.jobs[0].push_back(trees->job(sc.first, d_small, 32ull * sc.second));
+        hc += trees->job_hashes(sc.first);
+    }
     // Schedule (round 3): ONE stream.  The plan first (every tree is DESCRIBED here and launched further down), then the wide
     // passes -- the validator registry, 93 % of the hashes, and whatever other field is too wide for a tile stage --, then ONE launch for everything that is left: the tile stages of all fields, their
     // finishing jobs, the leaf containers, the nested containers and the state container, chained by arrival tickets inside the
@@ -359,15 +366,6 @@ static int run_state_plan(hipStream_t s, ThreadCtx* c, const u8* d_ssz, u64 n_by
     return ECGPU_SUCCESS;
 }
 
-// hash_tree_root of validator records into the resident state's cache: lane = record; idx == nullptr: records [0, n)
-__global__ void __launch_bounds__(256) k_validator_roots(ValidatorLeaves leaves, const u32* idx, u32 n, u8* vroots) {
-    const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const u64 v = idx ? idx[t] : t;
-    const Node r = leaves(v);
-    node_store(r, vroots + 32 * v);
-}
-
 // patch scatter: one workgroup per patch, byte copies (patches are small: a balance, a flag byte, a root)
 struct PatchDesc {
     u64 dst_off, src_off, len;
@@ -385,19 +383,11 @@ struct ecgpu_resident_state {
     u8* d_ssz = nullptr;   // encoding (cap_bytes allocated: lists grow in place, ecgpu_resident_state_append)
     u64 n_bytes = 0, cap_bytes = 0;
     u8* d_rootbuf = nullptr;  // 64 bytes: where the host-pointer root entry leaves its result
-    u64 vroots_cap = 0;       // validator-root cache capacity (records)
     std::vector<u8> h_fixed;  // host mirror of the fixed-size part (offsets and small fields): what the plan reads
-    // SURVEY.md 8f rank 2, first level: the root of every validator record, kept current by the patches.  93 % of a state
-    // root's hash64 are these 8 per validator, and a slot touches a handful of records.
-    u8* d_vroots = nullptr;
-    u64 vals_off = 0, n_vals = 0;       // byte offset / count of the validator records in the encoding
-    std::vector<u32> dirty;             // records whose cached root is stale (deduplicated at the next root)
-    bool all_dirty = true;
-    // device copy of the dirty list: owned by the state (one state must not be used from two threads / streams at once,
-    // include/ecgpu.h), double-buffered so that a root enqueued on a stream never overwrites the list of the previous one
-    u32* d_idx[2] = {nullptr, nullptr};
-    size_t d_idx_cap[2] = {0, 0};
-    int d_idx_turn = 0;
+    // every interior node of every big field's tree stays on the device (csrc/state_tree.h); a patch marks
+    // the level-0 entries it touches, a root re-hashes their paths and nothing else
+    ecg::ResidentTrees trees;
+    u64 last_climb_hashes = 0;  // hash64 the dirty-path climbs of the last host-pointer root performed (device counter)
 };
 
 using namespace ecg;
@@ -429,13 +419,11 @@ int ecgpu_resident_state_create_fork(int fork, int preset, const uint8_t* ssz, u
     ECG_HIP_CHECK(hipMalloc((void**)&st->d_ssz, st->cap_bytes));
     ECG_HIP_CHECK(hipMalloc((void**)&st->d_rootbuf, 64));
     ECG_HIP_CHECK(hipMemcpy(st->d_ssz, ssz, n_bytes, hipMemcpyHostToDevice));
-    for (const BigField& b : plan.bigs)
-        if (b.kind == LEAF_VALIDATORS) {
-            st->vals_off = b.src;
-            st->n_vals = b.n0;
-        }
-    st->vroots_cap = st->n_vals + (st->n_vals >> 6) + 1024;
-    ECG_HIP_CHECK(hipMalloc((void**)&st->d_vroots, 32 * st->vroots_cap));
+    rc = st->trees.sync_geometry(plan);  // allocates the trees; every field is built by the first root
+    if (rc) {
+        ecgpu_resident_state_destroy(st);
+        return rc;
+    }
     *out = st;
     return ECGPU_SUCCESS;
 }
@@ -512,7 +500,8 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
     if (remove == 0 && insert == 0) return ECGPU_SUCCESS;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
-    int rc = splice(st, s, c->arena(s), pos, remove, data, insert);
+    Arena& ar = c->arena(s);
+    int rc = splice(st, s, ar, pos, remove, data, insert);
     if (rc) return rc;
     // later fields start `insert - remove` bytes later: their offset words change on the host mirror and on the device
     const int64_t delta = (int64_t)insert - (int64_t)remove;
@@ -522,30 +511,40 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
             wr32(st->h_fixed.data() + vf[k].word, v);
             ECG_HIP_CHECK(hipMemcpyAsync(st->d_ssz + vf[k].word, st->h_fixed.data() + vf[k].word, 4, hipMemcpyHostToDevice, s));
         }
-    // the validator-root cache follows the registry
-    const u64 old_vals_off = st->vals_off, old_n = st->n_vals;
-    st->vals_off = rd32(st->h_fixed.data() + vf[2].word);
-    (void)old_vals_off;
-    if (fi == 2) {
-        const u64 new_n = truncate ? new_len_or_keep / 121 : old_n + add_len / 121;
-        if (new_n > st->vroots_cap) {
-            const u64 cap = new_n + (new_n >> 5) + 1024;
-            u8* nv = nullptr;
-            ECG_HIP_CHECK(hipMalloc((void**)&nv, 32 * cap));
-            if (old_n && !st->all_dirty) ECG_HIP_CHECK(hipMemcpyAsync(nv, st->d_vroots, 32 * old_n, hipMemcpyDeviceToDevice, s));
-            ECG_HIP_CHECK(hipStreamSynchronize(s));
-            ECG_HIP_CHECK(hipFree(st->d_vroots));
-            st->d_vroots = nv;
-            st->vroots_cap = cap;
-        }
-        for (u64 v = old_n; v < new_n && !st->all_dirty; v++) st->dirty.push_back((u32)v);
+    // the trees follow: every field's offset may have moved; the resized field's new entries are marked dirty (a field whose
+    // height changed, or that shrank, is rebuilt at the next root)
+    StatePlan plan;
+    if (!build_state_plan(st->fork, st->h_fixed.data(), st->n_bytes, st->preset, plan, nullptr, nullptr)) {
+        set_last_error(plan.error);
+        return ECGPU_ERR_BAD_ARG;
+    }
+    static const u32 field_chunk[9] = {7, 9, 11, 12, 15, 16, 21, 0, 27};  // var_fields order -> field-root chunk of the list
+    u32 slot = TREE_MAX_FIELDS;
+    for (u32 k = 0; k < plan.bigs.size() && k < TREE_MAX_FIELDS; k++)
+        if (plan.bigs[k].out_chunk == field_chunk[fi] && plan.bigs[k].mix) slot = k;
+    const u64 old_bytes = slot < TREE_MAX_FIELDS ? st->trees.f[slot].g.bytes : 0;
+    const bool was_live = slot < TREE_MAX_FIELDS && st->trees.f[slot].live;
+    const u32 old_H = was_live ? st->trees.f[slot].g.H : 0;
+    rc = st->trees.sync_geometry(plan);
+    if (rc) return rc;
+    if (was_live && st->trees.f[slot].live && !st->trees.f[slot].all_dirty && st->trees.f[slot].g.H == old_H) {
+        FieldTree& t = st->trees.f[slot];
         if (truncate) {
-            std::vector<u32> keep;
-            for (u32 v : st->dirty)
-                if (v < new_n) keep.push_back(v);
-            st->dirty.swap(keep);
+            t.all_dirty = true;
+        } else {
+            const u64 rec = leaf_record_bytes((LeafKind)t.g.kind);
+            std::vector<u64> pairs;
+            st->trees.collect_entries(slot, old_bytes / rec, (t.g.bytes - 1) / rec, pairs);
+            if (!pairs.empty()) {
+                ar.reset();
+                rc = ar.reserve(8 * pairs.size() + 4096);
+                if (rc) return rc;
+                u64* d_pairs = (u64*)ar.take(8 * pairs.size());
+                ECG_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), 8 * pairs.size(), hipMemcpyHostToDevice, s));
+                rc = st->trees.mark(s, d_pairs, (u32)pairs.size());
+                if (rc) return rc;
+            }
         }
-        st->n_vals = new_n;
     }
     ECG_HIP_CHECK(hipStreamSynchronize(s));
     return ECGPU_SUCCESS;
@@ -573,9 +572,7 @@ void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st) {
     (void)hipDeviceSynchronize();
     (void)hipFree(st->d_ssz);
     (void)hipFree(st->d_rootbuf);
-    (void)hipFree(st->d_vroots);
-    (void)hipFree(st->d_idx[0]);
-    (void)hipFree(st->d_idx[1]);
+    st->trees.release();
     delete st;
 }
 
@@ -628,7 +625,7 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     Arena& ar = c->arena(s);
     ar.reset();
     const u64 total = data_off[n];
-    rc = ar.reserve(total + n * sizeof(PatchDesc) + 4096);
+    rc = ar.reserve(total + n * sizeof(PatchDesc) + 8 * (total + 2ull * n) + 8192);  // data, descriptors, <= total + 2n marks
     if (rc) return rc;
     u8* d_data = ar.take(total ? total : 1);
     PatchDesc* d_desc = (PatchDesc*)ar.take(n * sizeof(PatchDesc));
@@ -637,17 +634,18 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     ECG_HIP_CHECK(hipMemcpyAsync(d_desc, descs.data(), n * sizeof(PatchDesc), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_apply_patches, dim3(n), dim3(64), 0, s, st->d_ssz, (const u8*)d_data, (const PatchDesc*)d_desc);
     ECG_HIP_CHECK(hipGetLastError());
-    for (u32 i = 0; i < n && !st->all_dirty; i++) {  // validator records these bytes belong to
-        const u64 lo = descs[i].dst_off, hi = descs[i].dst_off + descs[i].len;
-        const u64 v0 = st->vals_off, v1 = st->vals_off + 121 * st->n_vals;
-        if (!descs[i].len || hi <= v0 || lo >= v1) continue;
-        const u64 first = ((lo > v0 ? lo : v0) - v0) / 121, last = ((hi < v1 ? hi : v1) - 1 - v0) / 121;
-        if (st->dirty.size() + (last - first + 1) > st->n_vals / 8) {
-            st->all_dirty = true;  // cheaper to rebuild the cache in one full-width launch
-            st->dirty.clear();
-            break;
+    // the level-0 entries of the cached trees these bytes belong to: marked on the device (state_tree.h MARK)
+    {
+        std::vector<u64> pairs;
+        for (u32 i = 0; i < n; i++)
+            if (descs[i].len) st->trees.collect(descs[i].dst_off, descs[i].dst_off + descs[i].len, pairs);
+        if (!pairs.empty()) {
+            u64* d_pairs = (u64*)ar.take(8 * pairs.size());
+            if (!d_pairs) return ECGPU_ERR_OOM;
+            ECG_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), 8 * pairs.size(), hipMemcpyHostToDevice, s));
+            rc = st->trees.mark(s, d_pairs, (u32)pairs.size());
+            if (rc) return rc;
         }
-        for (u64 v = first; v <= last; v++) st->dirty.push_back((u32)v);
     }
     for (u32 i = 0; i < n; i++)  // host mirror of the fixed part
         for (u64 b = 0; b < descs[i].len; b++)
@@ -656,50 +654,21 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     return ECGPU_SUCCESS;
 }
 
-// bring the cached validator roots up to date on stream s (before the arena is reset by the root computation)
-static int refresh_validator_roots(ecgpu_resident_state* st, hipStream_t s, ThreadCtx* c) {
-    if (!st->n_vals) return ECGPU_SUCCESS;
-    const ValidatorLeaves leaves{st->d_ssz + st->vals_off, 121 * st->n_vals};
-    if (st->all_dirty) {
-        hipLaunchKernelGGL(k_validator_roots, dim3((u32)((st->n_vals + 255) / 256)), dim3(256), 0, s, leaves, (const u32*)nullptr,
-                           (u32)st->n_vals, st->d_vroots);
-        ECG_HIP_CHECK(hipGetLastError());
-        st->all_dirty = false;
-        st->dirty.clear();
-        return ECGPU_SUCCESS;
-    }
-    if (st->dirty.empty()) return ECGPU_SUCCESS;
-    std::sort(st->dirty.begin(), st->dirty.end());
-    st->dirty.erase(std::unique(st->dirty.begin(), st->dirty.end()), st->dirty.end());
-    // the index list travels through an allocation of the state's own: the arena belongs to the root computation that follows
-    const int turn = st->d_idx_turn ^= 1;
-    u32*& d_idx = st->d_idx[turn];
-    size_t& d_idx_cap = st->d_idx_cap[turn];
-    if (st->dirty.size() > d_idx_cap) {
-        if (d_idx) {
-            ECG_HIP_CHECK(hipDeviceSynchronize());
-            ECG_HIP_CHECK(hipFree(d_idx));
-        }
-        d_idx_cap = st->dirty.size() * 2 + 1024;
-        ECG_HIP_CHECK(hipMalloc((void**)&d_idx, d_idx_cap * sizeof(u32)));
-    }
-    ECG_HIP_CHECK(hipMemcpyAsync(d_idx, st->dirty.data(), st->dirty.size() * sizeof(u32), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_validator_roots, dim3((u32)((st->dirty.size() + 255) / 256)), dim3(256), 0, s, leaves, (const u32*)d_idx,
-                       (u32)st->dirty.size(), st->d_vroots);
-    ECG_HIP_CHECK(hipGetLastError());
-    st->dirty.clear();
-    return ECGPU_SUCCESS;
-}
-
+// Root of a resident state: (1) fields flagged for a rebuild are rebuilt level by level, (2) ONE climb launch re-hashes the
+// dirty paths of every other cached field, (3) the fused tail runs one finishing job per cached field (<= 512 nodes -> zero
+// ladder -> length mix-in), the small fields and the state container.
 int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, ecgpu_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!st || !d_root) return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
-    rc = refresh_validator_roots(st, s, c);
+    u64 rebuilt = 0;
+    rc = st->trees.update(s, st->d_ssz, &rebuilt);
     if (rc) return rc;
-    return state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots, st->fork);
+    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, &st->trees, st->fork);
+    c->last_hash64 += rebuilt;  // (the climbs' share is on the device: the host-pointer entry below adds it)
+    return rc;
 }
 
 int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
@@ -709,12 +678,21 @@ int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
     u8* d_root = st->d_rootbuf;
-    rc = refresh_validator_roots(st, s, c);
+    u64 rebuilt = 0;
+    rc = st->trees.update(s, st->d_ssz, &rebuilt);
     if (rc) return rc;
-    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, st->d_vroots, st->fork);
+    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, &st->trees, st->fork);
     if (rc) return rc;
-    ECG_HIP_CHECK(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, s));
+    // root and the climbs' hash counter come back in one copy
+    ECG_HIP_CHECK(hipMemcpyAsync(d_root + 32, st->trees.d_hashes(), 8, hipMemcpyDeviceToDevice, s));
+    ECG_HIP_CHECK(hipMemsetAsync(st->trees.d_hashes(), 0, 8, s));
+    rc = c->staging.reserve(64);
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipMemcpyAsync(c->staging.p, d_root, 40, hipMemcpyDeviceToHost, s));
     ECG_HIP_CHECK(hipStreamSynchronize(s));
+    std::memcpy(root, c->staging.p, 32);
+    std::memcpy(&st->last_climb_hashes, c->staging.p + 32, 8);
+    c->last_hash64 += rebuilt + st->last_climb_hashes;
     return ECGPU_SUCCESS;
 }
 

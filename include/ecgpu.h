@@ -363,9 +363,15 @@ int ecgpu_selfcheck_ifetch_sweep(double ms[4]);
  * check then runs on the lane groups at every batch size).  Decided once per process, at the first BLS call or here; the
  * environment variable ECGPU_TOWER=sums|calls overrides the self-check. */
 int ecgpu_bls_tower(void);
-/* Which kernels ran the pairing check of the calling thread's last verification: 1 = one lane per tuple (k_pairing),
- * 3 = 16 / 12-lane groups over Fp registers in LDS with sums of products (bls_vm3.hip); 0 = none yet.  ECGPU_PAIRING=lane|vm3
- * forces one (default: by batch size, ECGPU_VM_MAX).  (2 was round 2's Fp2 lane groups, removed.) */
+/* Which kernels ran the pairing check of the calling thread's last verification (for a ragged batch: of its full rounds):
+ *   0 = none yet
+ *   1 = one lane per tuple (k_pairing: Miller loop + final exponentiation in one kernel)
+ *   3 = 16 / 12-lane groups over Fp registers in LDS with sums of products (bls_vm3.hip)
+ *   5 = two lanes per tuple (k_miller2 + k_finalexp2 / k_finalexp: bls_pair2.h, bls_finalexp2.h)
+ *   7 = one Fp operation across a 16-lane row, limb per lane (bls_row.hip: the latency path of small batches)
+ * (2 was round 2's Fp2 lane groups, 4 and 6 never existed.)  ECGPU_PAIRING=auto|lane|vm3|split|row forces one path at every
+ * size; auto (default) chooses by batch size: rows up to ECGPU_ROW_MAX tuples, lane groups up to ECGPU_VM_MAX, two lanes per
+ * tuple up to ECGPU_SPLIT_MAX, the lane kernel above. */
 int ecgpu_bls_last_pairing_path(void);
 
 #ifdef __cplusplus

@@ -11,6 +11,7 @@
 #include "state_plan.h"
 #include "ssz_plan.h"
 #include "shuffle.h"
+#include "state_tree.h"
 
 using namespace ecg;
 
@@ -176,6 +177,65 @@ static void sim_merkleize(LeafKind kind, const u8* in, u64 in_bytes, u64 n0, u32
     }
     hs_tree_job(cur, sc.job_n, sc.job_level, depth, mix ? 1 : 0, mix_len, out);
     if (hashes) *hashes += sc.hashes;
+}
+
+// A resident field tree (csrc/state_tree.h) on the host: built over `before`, the encoding then becomes `after` (same entry count
+// or a longer one with the same tree height), the touched entries are MARKED in the order given (duplicates allowed), the dirty
+// list is CLIMBED in an order shuffled by `seed`, and the finishing job reduces level T to the root.  Threads run one after the
+// other here: what is checked is the ticket logic -- exactly the dirty paths re-hashed, every counter back at zero -- not the
+// memory model.  Returns the hash64 of the climbs; *left = counters / flags that are not zero afterwards (must be 0).
+u64 hs_tree_update(int kind, const u8* before, u64 bytes_before, u64 n0_before, const u8* after, u64 bytes_after, u64 n0_after, u32 depth,
+                   int mix, u64 mix_len, const u64* marks, u32 n_marks, u64 seed, u8* out_root, u32* left, u64* rebuild_hashes) {
+    TreeGeom g{};
+    g.kind = (u32)kind;
+    g.H = ceil_log2_u64(n0_after ? n0_after : 1);
+    g.T = tree_top_level(g.kind, g.H);
+    const u64 cap = 1ull << g.H;
+    std::vector<u8> lvl0(kind != LEAF_CHUNKS ? 32 * cap : 0), nodes(32 * cap);
+    std::vector<u32> cnt(cap, 0), flag((cap + 31) / 32, 0);
+    g.lvl0 = kind != LEAF_CHUNKS ? lvl0.data() : nullptr;
+    g.nodes = nodes.data();
+    g.cnt = cnt.data();
+    g.flag0 = flag.data();
+    g.src = before;
+    g.bytes = bytes_before;
+    g.n0 = n0_before;
+    if (g.lvl0)
+        for (u64 e = 0; e < g.n0; e++) node_store(tree_leaf(g, e), g.lvl0 + 32 * e);
+    for (u32 k = 0; k < g.T;) {  // the rebuild launches of ResidentTrees::update
+        const u32 D = g.T - k >= 3 ? 3 : g.T - k;
+        const u64 n_out = tree_level_count(g.n0, k + D);
+        for (u64 i = 0; i < n_out; i++) {
+            if (D == 3) (void)TreeSpan<3>::run(g, k, i, zt());
+            else if (D == 2) (void)TreeSpan<2>::run(g, k, i, zt());
+            else (void)TreeSpan<1>::run(g, k, i, zt());
+        }
+        k += D;
+    }
+    if (rebuild_hashes) *rebuild_hashes = tree_rebuild_hashes(g);
+    g.src = after;
+    g.bytes = bytes_after;
+    g.n0 = n0_after;
+    std::vector<u64> list(n_marks + 1);
+    u32 count = 0;
+    for (u32 i = 0; i < n_marks; i++) tree_mark(g, 3, marks[i], list.data(), &count, n_marks);
+    u64 x = seed | 1;
+    for (u32 i = count; i > 1; i--) {  // Fisher-Yates with a 64-bit LCG
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        std::swap(list[i - 1], list[(x >> 33) % i]);
+    }
+    u64 hashes = 0;
+    for (u32 i = 0; i < count; i++) {
+        if ((list[i] >> TREE_SLOT_SHIFT) != 3) return ~0ull;
+        hashes += tree_climb(g, list[i] & TREE_ENTRY_MASK, zt());
+    }
+    u32 bad = 0;
+    for (u32 c : cnt) bad += c != 0;
+    for (u32 f : flag) bad += f != 0;
+    if (left) *left = bad;
+    const u8* in = g.T == 0 ? g.lvl0 : g.nodes + 32 * tree_heap_off(g.H, g.T);
+    hs_tree_job(in, (u32)tree_level_count(g.n0, g.T), g.T, depth, mix, mix_len, out_root);
+    return hashes;
 }
 
 u64 hs_merkleize(int kind, const u8* in, u64 in_bytes, u64 n0, u32 depth, int mix, u64 mix_len, u8* out) {

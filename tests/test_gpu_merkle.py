@@ -759,3 +759,154 @@ def test_resident_state_lists_change_length(gpu):
     with pytest.raises(ssz.MerkleizationError):
         st.append(7, bytes(8))                 # the payload header is not a list
     st.close()
+
+
+# ---- the resident state's trees re-hash dirty paths only (csrc/state_tree.h) --------------------------
+VAR_INDEX = {"historical_roots": 0, "eth1_data_votes": 1, "validators": 2, "balances": 3, "previous_epoch_participation": 4,
+             "current_epoch_participation": 5, "inactivity_scores": 6, "historical_summaries": 8}
+ELEM = {"historical_roots": 32, "eth1_data_votes": 72, "validators": 121, "balances": 8, "previous_epoch_participation": 1,
+        "current_epoch_participation": 1, "inactivity_scores": 8, "historical_summaries": 64}
+
+
+def _random_step(r, st, m, fork):
+    """one randomly chosen mutation applied to the resident state `st` and to the host model `m`; returns its name"""
+    from ethereum_consensus_amd import synthetic
+    lists = [n for n in m.names if n in VAR_INDEX]
+    op = r.choice(["patch"] * 6 + ["add_validator", "add_validator", "append", "truncate", "rewrite", "rotate", "fixed", "nothing"])
+    if op == "patch":  # a block's worth of small writes: balances, flags, scores, records, roots
+        patches, used = [], set()
+        for _ in range(r.choice([1, 3, 40, 400])):
+            name = r.choice(lists)
+            if not m.var[name]:
+                continue
+            ln = r.choice([1, 8]) if ELEM[name] != 1 else 1
+            if name == "validators":
+                ln = r.choice([1, 8, 32, 121, 130])
+            ln = min(ln, len(m.var[name]))
+            off = m.start(name) + r.randrange(0, len(m.var[name]) - ln + 1)
+            if any(b in used for b in range(off, off + ln)):
+                continue
+            used.update(range(off, off + ln))
+            patches.append((off, r.randbytes(ln)))
+        st.patch(patches)
+        for off, b in patches:
+            m.write(off, b)
+    elif op == "fixed":  # slot, a block root, a state root, a randao mix, a slashing: the fixed part's big vectors and basic fields
+        patches = []
+        for name in r.sample(["slot", "block_roots", "state_roots", "randao_mixes", "slashings", "latest_block_header"], 3):
+            lo, hi = m.fixed_ranges[name]
+            ln = 8 if name in ("slot", "slashings") else 32
+            off = lo + ln * r.randrange((hi - lo) // ln)
+            patches.append((off, r.randbytes(ln)))
+        st.patch(patches)
+        for off, b in patches:
+            m.write(off, b)
+    elif op == "add_validator":  # a deposit
+        for _ in range(r.choice([1, 1, 2, 9])):
+            rec = synthetic.validators(1, seed=r.randrange(1 << 30)).tobytes()
+            bal = r.randrange(1 << 40)
+            st.add_validator(rec, bal)
+            m.var["validators"] += rec
+            m.var["balances"] += bal.to_bytes(8, "little")
+            m.var["previous_epoch_participation"] += b"\x00"
+            m.var["current_epoch_participation"] += b"\x00"
+            m.var["inactivity_scores"] += bytes(8)
+    elif op == "append":  # an eth1 vote per block, a summary / root per period
+        name = r.choice([n for n in ("eth1_data_votes", "historical_roots", "historical_summaries") if n in m.var])
+        data = r.randbytes(ELEM[name] * r.choice([1, 1, 3]))
+        if len(m.var[name]) + len(data) <= ELEM[name] * (32 if name == "eth1_data_votes" else 1 << 20):  # (minimal preset: 32 votes)
+            st.append(VAR_INDEX[name], data)
+            m.var[name] += data
+    elif op == "truncate":  # the eth1_data_votes reset; a list cut to a shorter length
+        name = r.choice([n for n in ("eth1_data_votes", "historical_roots", "balances") if n in m.var])
+        if name == "balances":
+            return op  # (balances never shrink on their own: only together with the registry -- not modelled)
+        keep = ELEM[name] * r.randrange(0, len(m.var[name]) // ELEM[name] + 1)
+        st.truncate(VAR_INDEX[name], keep)
+        del m.var[name][keep:]
+    elif op == "rewrite":  # an epoch's rewards: every balance changes in one patch (the tree is rebuilt, not climbed)
+        name = r.choice(["balances", "inactivity_scores"])
+        data = r.randbytes(len(m.var[name]))
+        if data:
+            st.patch([(m.start(name), data)])
+            m.write(m.start(name), data)
+    elif op == "rotate":  # the participation rotation of an epoch boundary
+        cur = bytes(m.var["current_epoch_participation"])
+        if cur:
+            st.patch([(m.start("previous_epoch_participation"), cur), (m.start("current_epoch_participation"), bytes(len(cur)))])
+            m.write(m.start("previous_epoch_participation"), cur)
+            m.write(m.start("current_epoch_participation"), bytes(len(cur)))
+    return op
+
+
+@pytest.mark.parametrize("fork,preset,n_val,steps", [("altair", "minimal", 700, 170), ("bellatrix", "minimal", 1100, 170),
+                                                      ("capella", "mainnet", 2500, 170), ("deneb", "minimal", 37, 170),
+                                                      ("deneb", "mainnet", 5000, 170), ("deneb", "minimal", 2040, 170)])
+def test_resident_state_randomised_patch_append_truncate_sequences(gpu, fork, preset, n_val, steps):
+    """1 020 randomised steps over every resident fork: after EVERY step the resident root (dirty paths climbed, rebuilt fields,
+    finishing jobs over the cached levels) equals ecgpu_htr_beacon_state of the re-serialized state, computed from scratch."""
+    from ethereum_consensus_amd import synthetic
+    from tests._statemodel import EncodingModel
+    ssz = gpu
+    import zlib
+    r = random.Random(zlib.crc32(f"{fork}/{preset}/{n_val}".encode()))
+    f = synthetic.state_fields(n_val, preset, seed=n_val)
+    f["_preset"] = preset
+    t, v = _fork_state_value(fork, f, r)
+    enc = t.serialize(v)
+    pid = ssz.MINIMAL if preset == "minimal" else ssz.MAINNET
+    st = ssz.ResidentBeaconStateDeneb(enc, pid, fork=fork)
+    m = EncodingModel(t, enc)
+    assert m.encoding() == enc
+    assert st.hash_tree_root() == t.htr(v)
+    seen = set()
+    for k in range(steps):
+        op = _random_step(r, st, m, fork)
+        seen.add(op)
+        if r.random() < 0.25:
+            continue  # several mutations between two roots
+        cur = m.encoding()
+        assert len(st) == len(cur), (k, op)
+        assert st.hash_tree_root() == ssz.hash_tree_root_beacon_state(fork, cur, pid), (k, op)
+    cur = m.encoding()
+    assert st.hash_tree_root() == ssz.hash_tree_root_beacon_state(fork, cur, pid)
+    assert {"patch", "add_validator", "rewrite", "rotate", "fixed"} <= seen
+    st.close()
+
+
+def test_resident_root_after_a_blocks_patches_rehashes_dirty_paths_only(gpu):
+    """BASELINE configs[4] at full size: a 2^20-validator mainnet state, 4 096 balances + 4 096 participation bytes patched.
+    The root equals the from-scratch root and costs <= 150 k hash64 (from scratch: 10.1 M; round 4's validator-root cache:
+    1.2 M) -- the count is taken on the device by the climbs themselves."""
+    from ethereum_consensus_amd import synthetic, _lib
+    ssz = gpu
+    L = _lib.load()
+    n = 1 << 20
+    f = synthetic.state_fields(n, "mainnet", seed=5)
+    enc = bytearray(synthetic.serialize_state(f))
+    st = ssz.ResidentBeaconStateDeneb(bytes(enc), ssz.MAINNET)
+    root0 = st.hash_tree_root()
+    assert root0 == ssz.hash_tree_root_beacon_state_deneb(bytes(enc), ssz.MAINNET)
+    fixed = int(L.ecgpu_beacon_state_deneb_fixed_size(ssz.MAINNET))
+    vals_off = fixed + len(f["historical_roots"].tobytes()) + 72 * len(f["eth1_data_votes"])
+    bal_off = vals_off + 121 * n
+    part_off = bal_off + 8 * n + n  # current_epoch_participation
+    r = random.Random(9)
+    for rnd_ in range(3):
+        idx = r.sample(range(n), 4096)
+        patches = [(bal_off + 8 * i, r.randrange(1 << 40).to_bytes(8, "little")) for i in idx]
+        patches += [(part_off + i, bytes([r.randrange(1, 8)])) for i in r.sample(range(n), 4096)]
+        if rnd_ == 2:  # ... and a few registry records (an exit, a slashing): 8 + 11 hash64 each
+            patches += [(vals_off + 121 * i + 88, b"\x01") for i in r.sample(range(n), 16)]
+        for off, b in patches:
+            enc[off:off + len(b)] = b
+        st.patch(patches)
+        root = st.hash_tree_root()
+        hashes = int(L.ecgpu_last_hash64_count())
+        assert root == ssz.hash_tree_root_beacon_state_deneb(bytes(enc), ssz.MAINNET)
+        assert hashes <= 150_000, hashes
+        assert hashes >= 4096 * 5  # (it did climb)
+    # nothing dirty: the root costs the finishing jobs and the small fields only
+    assert st.hash_tree_root() == root
+    assert int(L.ecgpu_last_hash64_count()) <= 12_000
+    st.close()

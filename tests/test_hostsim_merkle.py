@@ -171,3 +171,84 @@ def test_tile_stage_schedule(n0, limit):
     keys = rnd(48 * n0, n0 + 1)
     got, _ = hs.merkleize_scheduled(3, keys, n0, depth, False, 0)
     assert got == ssz.merkleize_chunks([ssz.merkleize_bytes(keys[48 * i: 48 * i + 48], 2) for i in range(n0)], limit)
+
+
+# ---- resident field trees: dirty-path re-hashing (csrc/state_tree.h) -----------------------------------
+REC = {0: 32, 2: 121, 3: 48, 4: 64, 5: 72}
+
+
+def _full_root(kind, data, n0, depth, mix, mix_len):
+    L = hs.lib()
+    L.hs_merkleize.restype = ctypes.c_uint64
+    L.hs_merkleize.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                               ctypes.c_uint64, ctypes.c_void_p]
+    out = ctypes.create_string_buffer(32)
+    L.hs_merkleize(kind, data, len(data), n0, depth, 1 if mix else 0, mix_len, out)
+    return out.raw
+
+
+def _tree_update(kind, before, n0_before, after, n0_after, depth, mix, mix_len, marks, seed):
+    L = hs.lib()
+    L.hs_tree_update.restype = ctypes.c_uint64
+    L.hs_tree_update.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64,
+                                 ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32,
+                                 ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    arr = (ctypes.c_uint64 * max(1, len(marks)))(*marks)
+    out = ctypes.create_string_buffer(32)
+    left = ctypes.c_uint32(99)
+    rebuilt = ctypes.c_uint64(0)
+    h = L.hs_tree_update(kind, before, len(before), n0_before, after, len(after), n0_after, depth, 1 if mix else 0, mix_len, arr, len(marks),
+                         seed, out, ctypes.byref(left), ctypes.byref(rebuilt))
+    assert h != 2 ** 64 - 1
+    return out.raw, h, left.value, rebuilt.value
+
+
+@pytest.mark.parametrize("kind,n", [(0, 2), (0, 3), (0, 5), (0, 64), (0, 1023), (0, 1024), (0, 1025), (0, 5000), (0, 70001),
+                                    (2, 2), (2, 3), (2, 511), (2, 513), (2, 1500), (2, 9000), (5, 7), (5, 2048), (4, 700), (3, 512), (3, 1536)])
+def test_resident_tree_rehashes_dirty_paths_only(kind, n):
+    r = random.Random(1000 * kind + n)
+    rec = REC[kind]
+    # a packed field's last chunk may be partial
+    nbytes = rec * n - (r.randrange(1, 31) if kind == 0 and n > 2 else 0)
+    before = bytearray(r.randbytes(nbytes))
+    depth = max(1, (n - 1).bit_length()) + r.randrange(0, 21)
+    mix = kind != 3
+    for trial, n_dirty in enumerate((0, 1, 2, min(n, 40), min(n, 700))):
+        after = bytearray(before)
+        touched = sorted(r.sample(range(n), n_dirty))
+        for e in touched:
+            lo, hi = rec * e, min(rec * e + rec, nbytes)
+            pos = r.randrange(lo, hi)
+            after[pos] ^= 1 + r.randrange(255)
+        marks = list(touched) + [r.choice(touched) for _ in range(len(touched) // 3)]  # duplicates are welcome
+        r.shuffle(marks)
+        root, hashes, left, rebuilt = _tree_update(kind, bytes(before), n, bytes(after), n, depth, mix, n, marks, seed=trial * 77 + n)
+        assert left == 0  # every counter and flag back at zero
+        assert root == _full_root(kind, bytes(after), n, depth, mix, n)
+        # only dirty paths: at most (leaf work + T) hash64 per dirty entry, and no more than a rebuild
+        H = max(1, (n - 1).bit_length())
+        T = max(H - 9, 1 if kind == 0 else 0)
+        per_leaf = {0: 0, 2: 8, 3: 1, 4: 1, 5: 3}[kind]
+        assert hashes <= n_dirty * (per_leaf + T)
+        assert hashes <= rebuilt
+        if n_dirty == 0:
+            assert hashes == 0
+        before = after
+
+
+@pytest.mark.parametrize("kind,n,grow", [(0, 1030, 7), (0, 1500, 548), (2, 600, 3), (2, 1025, 1023), (5, 100, 28), (4, 513, 1)])
+def test_resident_tree_follows_an_append(kind, n, grow):
+    """entries appended without changing the tree's height: the new entries (and a packed list's last partial chunk) are marked"""
+    r = random.Random(5000 + n)
+    rec = REC[kind]
+    unit = 8 if kind == 0 else rec  # balances: 8-byte elements packed four to a chunk
+    nb0 = unit * (n * (4 if kind == 0 else 1) - (1 if kind == 0 else 0))
+    nb1 = nb0 + unit * grow * (4 if kind == 0 else 1)
+    data = r.randbytes(nb1)
+    n0_0, n0_1 = (nb0 + rec - 1) // rec, (nb1 + rec - 1) // rec
+    assert (n0_0 - 1).bit_length() == (n0_1 - 1).bit_length()
+    depth = 40
+    marks = list(range(nb0 // rec, (nb1 - 1) // rec + 1))
+    root, hashes, left, _ = _tree_update(kind, data[:nb0], n0_0, data, n0_1, depth, True, nb1 // unit, marks, seed=n)
+    assert left == 0
+    assert root == _full_root(kind, data, n0_1, depth, True, nb1 // unit)

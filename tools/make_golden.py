@@ -25,12 +25,32 @@ def S(tag: bytes, i: int) -> bytes:
     return hashlib.sha256(b"ecgpu/v1/" + tag + b"/" + i.to_bytes(4, "little")).digest()
 
 
+# literals of the reference's tests (crypto/bls.rs:532,537,541; bin/ec/validator/keystores.rs:242,245)
+REF_CAN_SIGN_SK = "40094c5c6c378857eac09b8ec64c87182f58700c056a8b371ad0eb0a5b983d50"
+REF_CAN_SIGN_MSG = b"blst is such a blast"
+REF_CAN_SIGN_SIG = ("a01e49276730e4752eef31b0570c8707de501398dac70dd144438cd1bd05fb9b9bb3e1a9ceef0a68cc08904362cafa3f"
+                    "1005e5b699a41847fff6f5552260468846de5bdbf94a9aedeb29bc6cdb2c1d34922d9e9af4c0593a69ae978a90b5aba6")
+REF_EIP2335_SK = "000000000019d6689c085ae165831e934ff763ae46a2a6c172b3f1b60a8ce26f"
+REF_EIP2335_PK = "9612d7a727c9d0a22e185a1c768478dfe919cada9266988cb32359c11f2b7b27f4ae4040902382ae2910c15e2b420d07"
+
+
+def assert_oracles_reproduce_the_reference_literals(B, cbls):
+    """the pins: a golden file that stored oracle OUTPUT would pin nothing"""
+    sk = int(REF_CAN_SIGN_SK, 16)
+    assert B.sign(sk, REF_CAN_SIGN_MSG).hex() == REF_CAN_SIGN_SIG, "Python oracle does not reproduce test_can_sign"
+    assert cbls.sign(sk, REF_CAN_SIGN_MSG).hex() == REF_CAN_SIGN_SIG, "C++ oracle does not reproduce test_can_sign"
+    assert B.fast_aggregate_verify([B.sk_to_pk(sk)], REF_CAN_SIGN_MSG, bytes.fromhex(REF_CAN_SIGN_SIG)) == 0
+    assert B.sk_to_pk(int(REF_EIP2335_SK, 16)).hex() == REF_EIP2335_PK, "Python oracle does not reproduce the EIP-2335 key"
+    assert cbls.sk_to_pk(int(REF_EIP2335_SK, 16)).hex() == REF_EIP2335_PK, "C++ oracle does not reproduce the EIP-2335 key"
+
+
 def bls_fixture():
     """SURVEY.md 8(d) config 2 in miniature: 24 K = 1 tuples, every 3rd one damaged (the eight fault classes of the bench workload
     in order), statuses by both oracles; 12 randomly mutated tuples (tests/_blsmutate.py); a 3-key aggregate and its sum"""
     from oracle import bls12_381 as B, cbls
     from ethereum_consensus_amd import synthetic as syn
     from tests import _blsmutate as M
+    assert_oracles_reproduce_the_reference_literals(B, cbls)
     n = 24
     sks = [1 + int.from_bytes(S(b"sk", i), "big") % (B.R - 1) for i in range(n)]
     msgs = bytearray(b"".join(S(b"msg", i) for i in range(n)))
@@ -56,13 +76,15 @@ def bls_fixture():
     return {
         "source": "oracle/bls12_381.py == oracle/c/bls12_381.cpp (both asserted equal when this file was made)",
         "reference_vectors": {
+            # the LITERALS of the reference's own tests, copied from the files cited (not oracle output): the generator fails if
+            # the oracles do not reproduce them
             "test_can_sign (crypto/bls.rs:530-544)": {
-                "secret_key": "40094c5c6c378857eac09b8ec64c87182f58700c056a8b371ad0eb0a5b983d50", "message": b"blst is such a blast".hex(),
-                "signature": B.sign(int("40094c5c6c378857eac09b8ec64c87182f58700c056a8b371ad0eb0a5b983d50", 16), b"blst is such a blast").hex(),
-                "public_key (derived)": B.sk_to_pk(int("40094c5c6c378857eac09b8ec64c87182f58700c056a8b371ad0eb0a5b983d50", 16)).hex()},
+                "secret_key": REF_CAN_SIGN_SK, "message": REF_CAN_SIGN_MSG.hex(), "signature": REF_CAN_SIGN_SIG,
+                "origin": "literal of crypto/bls.rs:532,537; both oracles asserted to reproduce it",
+                "public_key (derived)": B.sk_to_pk(int(REF_CAN_SIGN_SK, 16)).hex()},
             "EIP-2335 key (bin/ec/validator/keystores.rs:240-249)": {
-                "secret_key": "000000000019d6689c085ae165831e934ff763ae46a2a6c172b3f1b60a8ce26f",
-                "public_key": B.sk_to_pk(int("000000000019d6689c085ae165831e934ff763ae46a2a6c172b3f1b60a8ce26f", 16)).hex()},
+                "secret_key": REF_EIP2335_SK, "public_key": REF_EIP2335_PK,
+                "origin": "literals of bin/ec/validator/keystores.rs:242,245; both oracles asserted to reproduce the key"},
             "group order (bin/ec/bls.rs:6-7)": "%x" % B.R},
         "k1_tuples": {"n": n, "fault_period": 3, "public_keys": bytes(pks).hex(), "messages": bytes(msgs).hex(), "signatures": bytes(sigs).hex(),
                       "statuses": list(want), "fault_kind": [int(k) for k in kinds]},
