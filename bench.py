@@ -971,7 +971,7 @@ def run_slots(args, L, torch, dist, rank, world, n_sync=512):
         t_root += t3 - t2
         tree_hashes.append(int(L.ecgpu_last_hash64_count()))
     lat["patch_ms"], lat["root_ms"] = t_patch / 8 * 1e3, t_root / 8 * 1e3
-    lat["hash64_per_root"] = max(tree_hashes)
+    lat["hash64_per_root"] = tree_hashes[-1]  # (the first host-pointer root also collects the count of the timed loop's device-entry roots)
     # the resident root after all those patches equals a from-scratch root of the patched encoding
     encb = bytearray(enc)
     applied = max(args.warmup, 2) + slots + 16
@@ -982,7 +982,7 @@ def run_slots(args, L, torch, dist, rank, world, n_sync=512):
     ok = all(g == wv for g, wv in statuses) and root_ok
     st.close()
     reg.close()
-    hashes_per_root = max(tree_hashes)
+    hashes_per_root = tree_hashes[-1]
     return dict(
         dt=dt, units_per_step=1, steps=slots, metric="slots_per_sec (sync-committee aggregate + state root per slot)", unit="slots/s", dtype="u32",
         config={"workload": f"per slot: eth_fast_aggregate_verify over ~95 % of a {n_sync}-key sync committee (validated-key registry) + root of "

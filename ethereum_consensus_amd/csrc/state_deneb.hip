@@ -388,6 +388,10 @@ struct ecgpu_resident_state {
     // the level-0 entries it touches, a root re-hashes their paths and nothing else
     ecg::ResidentTrees trees;
     u64 last_climb_hashes = 0;  // hash64 the dirty-path climbs of the last host-pointer root performed (device counter)
+    hipEvent_t patched = nullptr;  // recorded behind the last patch / length change on the stream it ran on
+    hipStream_t patch_stream = nullptr;
+    hipEvent_t rooted = nullptr;   // recorded behind the last root: a patch on another stream waits for it before it overwrites bytes
+    hipStream_t root_stream = nullptr;
 };
 
 using namespace ecg;
@@ -573,6 +577,8 @@ void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st) {
     (void)hipFree(st->d_ssz);
     (void)hipFree(st->d_rootbuf);
     st->trees.release();
+    if (st->patched) (void)hipEventDestroy(st->patched);
+    if (st->rooted) (void)hipEventDestroy(st->rooted);
     delete st;
 }
 
@@ -582,7 +588,12 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     if (rc) return rc;
     if (!st || (n && (!offsets || !data_off || !data))) return ECGPU_ERR_BAD_ARG;
     if (!n) return ECGPU_SUCCESS;
-    std::vector<PatchDesc> descs(n);
+    // (scratch vectors are the thread's: a slot's 4 096 patches are 200 KB of descriptors -- above malloc's mmap threshold, so a
+    // fresh vector per call is an mmap, its page faults and an munmap)
+    static thread_local std::vector<PatchDesc> descs;
+    static thread_local std::vector<u64> pairs;
+    descs.resize(n);
+    pairs.clear();
     for (u32 i = 0; i < n; i++) {
         if (data_off[i + 1] < data_off[i]) return ECGPU_ERR_BAD_ARG;
         const u64 len = data_off[i + 1] - data_off[i];
@@ -625,32 +636,49 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     Arena& ar = c->arena(s);
     ar.reset();
     const u64 total = data_off[n];
-    rc = ar.reserve(total + n * sizeof(PatchDesc) + 8 * (total + 2ull * n) + 8192);  // data, descriptors, <= total + 2n marks
-    if (rc) return rc;
-    u8* d_data = ar.take(total ? total : 1);
-    PatchDesc* d_desc = (PatchDesc*)ar.take(n * sizeof(PatchDesc));
-    if (!d_data || !d_desc) return ECGPU_ERR_OOM;
-    if (total) ECG_HIP_CHECK(hipMemcpyAsync(d_data, data, total, hipMemcpyHostToDevice, s));
-    ECG_HIP_CHECK(hipMemcpyAsync(d_desc, descs.data(), n * sizeof(PatchDesc), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_apply_patches, dim3(n), dim3(64), 0, s, st->d_ssz, (const u8*)d_data, (const PatchDesc*)d_desc);
-    ECG_HIP_CHECK(hipGetLastError());
     // the level-0 entries of the cached trees these bytes belong to: marked on the device (state_tree.h MARK)
-    {
-        std::vector<u64> pairs;
-        for (u32 i = 0; i < n; i++)
-            if (descs[i].len) st->trees.collect(descs[i].dst_off, descs[i].dst_off + descs[i].len, pairs);
-        if (!pairs.empty()) {
-            u64* d_pairs = (u64*)ar.take(8 * pairs.size());
-            if (!d_pairs) return ECGPU_ERR_OOM;
-            ECG_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), 8 * pairs.size(), hipMemcpyHostToDevice, s));
-            rc = st->trees.mark(s, d_pairs, (u32)pairs.size());
-            if (rc) return rc;
-        }
+    for (u32 i = 0; i < n; i++)
+        if (descs[i].len) st->trees.collect(descs[i].dst_off, descs[i].dst_off + descs[i].len, pairs);
+    // ONE block travels: descriptors | marks | bytes.  Up to 1 MB it goes through a slot of the pinned upload ring -- one truly
+    // asynchronous copy, and the caller's buffers are free when this returns (round 4: three pageable copies and a stream
+    // synchronisation, 0.19 ms for a slot's 4 096 patches); a larger one (an epoch's rewrite of every balance) is copied
+    // from where it lies, and the call waits for it.
+    const size_t off_pairs = n * sizeof(PatchDesc), off_data = off_pairs + 8 * pairs.size(), block = off_data + total;
+    rc = ar.reserve(block + 8192);
+    if (rc) return rc;
+    u8* d_block = ar.take(block ? block : 1);
+    if (!d_block) return ECGPU_ERR_OOM;
+    const bool ring = block <= (1u << 20);
+    if (ring) {
+        u8* h_block;
+        hipEvent_t copied;
+        rc = c->uploads.acquire(block, &h_block, &copied);
+        if (rc) return rc;
+        std::memcpy(h_block, descs.data(), off_pairs);
+        if (!pairs.empty()) std::memcpy(h_block + off_pairs, pairs.data(), 8 * pairs.size());
+        if (total) std::memcpy(h_block + off_data, data, total);
+        ECG_HIP_CHECK(hipMemcpyAsync(d_block, h_block, block, hipMemcpyHostToDevice, s));
+        ECG_HIP_CHECK(hipEventRecord(copied, s));
+    } else {
+        ECG_HIP_CHECK(hipMemcpyAsync(d_block, descs.data(), off_pairs, hipMemcpyHostToDevice, s));
+        if (!pairs.empty()) ECG_HIP_CHECK(hipMemcpyAsync(d_block + off_pairs, pairs.data(), 8 * pairs.size(), hipMemcpyHostToDevice, s));
+        if (total) ECG_HIP_CHECK(hipMemcpyAsync(d_block + off_data, data, total, hipMemcpyHostToDevice, s));
+    }
+    if (st->rooted && st->root_stream != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, st->rooted, 0));
+    hipLaunchKernelGGL(k_apply_patches, dim3(n), dim3(64), 0, s, st->d_ssz, (const u8*)(d_block + off_data), (const PatchDesc*)d_block);
+    ECG_HIP_CHECK(hipGetLastError());
+    if (!pairs.empty()) {
+        rc = st->trees.mark(s, (const u64*)(d_block + off_pairs), (u32)pairs.size());
+        if (rc) return rc;
     }
     for (u32 i = 0; i < n; i++)  // host mirror of the fixed part
         for (u64 b = 0; b < descs[i].len; b++)
             if (descs[i].dst_off + b < st->h_fixed.size()) st->h_fixed[descs[i].dst_off + b] = data[descs[i].src_off + b];
-    ECG_HIP_CHECK(hipStreamSynchronize(s));
+    // a root may be asked for on another stream (ecgpu_resident_state_root_dev): it waits for this event, not the host
+    if (!st->patched) ECG_HIP_CHECK(hipEventCreateWithFlags(&st->patched, hipEventDisableTiming));
+    ECG_HIP_CHECK(hipEventRecord(st->patched, s));
+    st->patch_stream = s;
+    if (!ring) ECG_HIP_CHECK(hipStreamSynchronize(s));
     return ECGPU_SUCCESS;
 }
 
@@ -663,11 +691,16 @@ int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, e
     if (!st || !d_root) return ECGPU_ERR_BAD_ARG;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
+    if (st->patched && st->patch_stream != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, st->patched, 0));
     u64 rebuilt = 0;
     rc = st->trees.update(s, st->d_ssz, &rebuilt);
     if (rc) return rc;
     rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, &st->trees, st->fork);
     c->last_hash64 += rebuilt;  // (the climbs' share is on the device: the host-pointer entry below adds it)
+    if (rc) return rc;
+    if (!st->rooted) ECG_HIP_CHECK(hipEventCreateWithFlags(&st->rooted, hipEventDisableTiming));
+    ECG_HIP_CHECK(hipEventRecord(st->rooted, s));
+    st->root_stream = s;
     return rc;
 }
 
@@ -678,6 +711,7 @@ int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
     u8* d_root = st->d_rootbuf;
+    if (st->patched && st->patch_stream != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, st->patched, 0));
     u64 rebuilt = 0;
     rc = st->trees.update(s, st->d_ssz, &rebuilt);
     if (rc) return rc;

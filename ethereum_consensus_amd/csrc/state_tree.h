@@ -10,16 +10,20 @@
 //   levels 1 .. T   every interior node, heap layout (level k at node offset 2^H - 2^(H-k+1)), T = H - 9: the level with at
 //             most 512 nodes, where the fused tail's finishing job (merkle.hip run_tree_job: LDS levels, zero ladder, length
 //             mix-in) takes over -- those last <= 511 + ladder hash64 are a dependent chain whatever is cached;
-//   cnt       one counter per interior node: dirty children still on their way (0 outside an update);
-//   flag0     one bit per level-0 entry: marked dirty since the last root.
-// MARK (at patch time, one thread per touched entry): set the entry's bit -- the first to set it appends the entry to the dirty
-// list -- then walk up adding 1 to each ancestor's counter and stop at the first ancestor that was already marked: afterwards
-// every dirty node's counter holds the number of its dirty children (1 or 2).
-// CLIMB (at root time, one thread per dirty-list entry): recompute the entry's level-0 node, then walk up: subtract 1 from the
-// parent's counter; whoever takes it from 2 to 1 stops (the sibling's subtree is still on its way and will carry on), whoever
-// takes it to 0 loads the sibling, hashes and continues.  Nobody waits, every counter is back at zero when the kernel ends,
-// and exactly the nodes on dirty paths are re-hashed: 4 096 dirty balances of 2^20 cost ~ 4 096 x 6 + 4 096 hash64 instead of
-// 2^18.
+//   flag0     one bit per level-0 entry: marked dirty since the last root;
+//   REGIONS   the subtree under each level-T node (2^T entries) is a region with a dirty list of its own (rlist / rcount).
+// MARK (at patch time, one thread per touched entry): set the entry's bit; the first to set it appends the entry to its
+// region's list, and the first entry of a region appends the region to the ACTIVE list.
+// CLIMB (at root time, ONE WORKGROUP PER ACTIVE REGION): counters for the region's 2^T - 1 interior nodes live in LDS.  Pass 1:
+// every dirty entry walks up adding 1 to each ancestor's counter and stops at the first ancestor already marked -- afterwards a
+// dirty node's counter holds the number of its dirty children.  Pass 2: every dirty entry recomputes its level-0 node and walks
+// up: subtract 1 from the parent's counter; whoever takes it from 2 to 1 stops (the sibling's subtree is still on its way and
+// will carry on), whoever takes it to 0 loads the sibling, hashes and continues.  Nobody waits, and exactly the nodes on dirty
+// paths are re-hashed: 4 096 dirty balances of 2^20 cost ~ 4 096 x 6 + 4 096 hash64 instead of 2^18.
+// A region is one workgroup on purpose: tickets and node hand-over stay inside a CU (LDS atomics, workgroup-scope fences).  The
+// first version of this file climbed with one thread per dirty entry anywhere on the chip and device-scope tickets: every level
+// then costs an L2 write-back and an invalidate across the 8 XCDs -- 16 us per level against the 5 us of the hash64 itself
+// (profiles/r05b_resident_probe.txt: 143 us for 9 levels).
 // The same routines are compiled by g++ into tests/hostsim (sequential threads in seeded order) -- test_hostsim_merkle.py.
 #pragma once
 #include "merkle.h"
@@ -30,6 +34,8 @@ namespace ecg {
 constexpr u32 TREE_TOP_LOG = 9;     // the finishing job takes <= 2^9 nodes (TREEJOB_MAX_NODES)
 constexpr u32 TREE_MAX_FIELDS = 20;
 constexpr u64 TREE_MIN_ENTRIES = 2;
+constexpr u32 TREE_MAX_T = 13;      // a region's counters are 4 x 2^T bytes of LDS: fields up to 2^22 entries are cached
+constexpr u32 TREE_ACTIVE_CAP = TREE_MAX_FIELDS << TREE_TOP_LOG;  // every region of every field
 
 struct TreeGeom {
     const u8* src;  // the field's bytes in the encoding (moves when an earlier list changes length)
@@ -37,8 +43,9 @@ struct TreeGeom {
     u64 n0;         // level-0 entries: elements (record kinds) or 32-byte chunks (LEAF_CHUNKS)
     u8* lvl0;       // element roots, 2^H x 32 B (record kinds); null for LEAF_CHUNKS
     u8* nodes;      // levels 1 .. H, heap layout, 2^H x 32 B
-    u32* cnt;       // same layout, one u32 per node
     u32* flag0;     // 2^H bits
+    u32* rcount;    // 2^(H-T) regions: dirty entries listed
+    uint16_t* rlist;  // region r: entries rlist[r << T .. ), each the entry's index inside the region
     u32 kind, H, T;
     u32 skip;       // 1: the field is rebuilt from scratch before this climb; its stale dirty-list entries are ignored
 };
@@ -67,7 +74,7 @@ ECG_D u32 tree_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }
 ECG_D u32 tree_atomic_sub(u32* p, u32 v) { return atomicSub(p, v); }
 ECG_D u32 tree_atomic_or(u32* p, u32 v) { return atomicOr(p, v); }
 ECG_D u32 tree_atomic_and(u32* p, u32 v) { return atomicAnd(p, v); }
-ECG_D void tree_fence() { __threadfence(); }
+ECG_D void tree_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 #else
 inline u32 tree_atomic_add(u32* p, u32 v) { const u32 o = *p; *p = o + v; return o; }
 inline u32 tree_atomic_sub(u32* p, u32 v) { const u32 o = *p; *p = o - v; return o; }
@@ -103,36 +110,57 @@ ECG_HD Node tree_node(const TreeGeom& g, u32 k, u64 i, const ZeroTable* zt) {
 
 constexpr u32 TREE_SLOT_SHIFT = 56;
 constexpr u64 TREE_ENTRY_MASK = (1ull << TREE_SLOT_SHIFT) - 1;
+ECG_HD u64 tree_local_off(u32 T, u32 k) { return (1ull << T) - (2ull << (T - k)); }  // a region's counter of level k >= 1, node 0
 
 // MARK: one thread per (field slot, entry) the host derived from a patch; duplicates welcome
-ECG_HD void tree_mark(const TreeGeom& g, u32 slot, u64 e, u64* list, u32* list_count, u32 list_cap) {
+ECG_HD void tree_mark(const TreeGeom& g, u32 slot, u64 e, u32* active, u32* active_count) {
     const u32 bit = 1u << (e & 31);
     if (tree_atomic_or(&g.flag0[e >> 5], bit) & bit) return;
-    const u32 at = tree_atomic_add(list_count, 1u);
-    if (at < list_cap) list[at] = ((u64)slot << TREE_SLOT_SHIFT) | e;  // (the host keeps the bound below the capacity)
-    u64 i = e;
-    for (u32 k = 1; k <= g.T; k++) {
-        i >>= 1;
-        if (tree_atomic_add(&g.cnt[tree_heap_off(g.H, k) + i], 1u) != 0) return;  // marked from here on up already
+    const u64 r = e >> g.T;
+    const u32 at = tree_atomic_add(&g.rcount[r], 1u);  // (< 2^T: an entry is listed once between two roots)
+    g.rlist[(r << g.T) + at] = (uint16_t)(e & ((1ull << g.T) - 1));
+    if (at == 0) {
+        const u32 a = tree_atomic_add(active_count, 1u);
+        if (a < TREE_ACTIVE_CAP) active[a] = (slot << 16) | (u32)r;  // (a region is listed once: never more than all of them)
     }
 }
 
-// CLIMB: one thread per dirty-list entry; returns the hash64 it performed
-ECG_HD u32 tree_climb(const TreeGeom& g, u64 e, const ZeroTable* zt) {
-    if (g.skip) return 0;
+// CLIMB pass 1, per dirty entry of region: count the dirty children of every ancestor inside the region (lcnt: 2^T zeroed
+// counters in LDS)
+ECG_HD void tree_region_count(const TreeGeom& g, u32* lcnt, u32 le) {
+    u32 i = le;
+    for (u32 k = 1; k <= g.T; k++) {
+        i >>= 1;
+        if (tree_atomic_add(&lcnt[tree_local_off(g.T, k) + i], 1u) != 0) return;  // counted from here on up already
+    }
+}
+// CLIMB pass 2, per dirty entry: returns the hash64 it performed
+ECG_HD u32 tree_region_climb(const TreeGeom& g, u32* lcnt, u64 region, u32 le, const ZeroTable* zt) {
+    const u64 e = (region << g.T) + le;
     tree_atomic_and(&g.flag0[e >> 5], ~(1u << (e & 31)));
     u32 hashes = tree_leaf_hashes(g.kind);
     Node x = tree_leaf(g, e);
     if (g.lvl0) node_store(x, g.lvl0 + 32ull * e);
     u64 i = e;
+    u32 li = le;
     for (u32 k = 1; k <= g.T; k++) {
         const u64 p = i >> 1;
-        tree_fence();  // release: the node stored above is visible before the ticket is given up
-        const u32 before = tree_atomic_sub(&g.cnt[tree_heap_off(g.H, k) + p], 1u);
+        li >>= 1;
+        tree_fence();  // release (workgroup): the node stored above is visible to the region's other waves before the ticket is given up
+        const u32 before = tree_atomic_sub(&lcnt[tree_local_off(g.T, k) + li], 1u);
         if (before != 1) return hashes;  // 2: the sibling's subtree is still on its way and carries on from here
         tree_fence();  // acquire: the sibling's node
         const Node sib = tree_node(g, k - 1, i ^ 1, zt);
-        x = (i & 1) ? hash64(sib, x) : hash64(x, sib);
+        // ONE call for the wave: operands selected per lane.  (`odd ? hash64(sib, x) : hash64(x, sib)` is two calls under
+        // complementary masks -- a wave holding a left and a right child ran every level twice: profiles/r05g_*)
+        const bool odd = (i & 1) != 0;
+        Node l, r;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            l.w[q] = odd ? sib.w[q] : x.w[q];
+            r.w[q] = odd ? x.w[q] : sib.w[q];
+        }
+        x = hash64(l, r);
         hashes++;
         node_store(x, g.nodes + 32ull * (tree_heap_off(g.H, k) + p));
         i = p;

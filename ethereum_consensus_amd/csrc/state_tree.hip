@@ -1,32 +1,56 @@
 // Resident field trees: kernels and host management (see state_tree.h for the algorithm, state_deneb.hip for the caller).
 #include "state_tree_host.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace ecg {
 
-// one wave per workgroup: a climb is a dependent chain of hash64 per lane, and 128 waves of dirty entries spread over 128 CUs
-// run at the lone-wave rate instead of sharing SIMDs
+// ONE WAVE per region: a region holds ~8 dirty entries of a slot's 4 096, its climb is one dependent chain, and the 1 024 active regions of a
+// slot are then one wave per SIMD of the chip.  (With 256 threads per region the four waves of a workgroup share a CU and every
+// workgroup's ACTIVE wave is its first: four chains per SIMD, 269 us instead of 70 -- profiles/r05c_resident_probe.txt.)
 constexpr int CLIMB_BLOCK = 64;
 
-__global__ void __launch_bounds__(256) k_tree_mark(TreeTable tab, const u64* pairs, u32 n, u64* list, u32* count, u32 cap) {
+__global__ void __launch_bounds__(256) k_tree_mark(TreeTable tab, const u64* pairs, u32 n, u32* active, u32* count) {
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const u64 p = pairs[t];
     const u32 slot = (u32)(p >> TREE_SLOT_SHIFT);
-    tree_mark(tab.f[slot], slot, p & TREE_ENTRY_MASK, list, count, cap);
+    tree_mark(tab.f[slot], slot, p & TREE_ENTRY_MASK, active, count);
 }
 
-__global__ void __launch_bounds__(CLIMB_BLOCK) k_tree_climb(TreeTable tab, const u64* list, const u32* count, u32 cap,
-                                                            const ZeroTable* zt, unsigned long long* hashes) {
-    const u32 t = blockIdx.x * CLIMB_BLOCK + threadIdx.x;
-    u32 n = *count;
-    if (n > cap) n = cap;
-    if (t >= n) return;
+// one workgroup per active region (state_tree.h CLIMB): the region's counters in LDS (4 x 2^T bytes, dynamic)
+// development aid (ECGPU_TREE_TRACE=1, tools/resident_probe.py): 100 MHz timestamps per region workgroup: start, lists counted, climbed
+__device__ unsigned long long g_tree_trace[3 * 2048];
+__global__ void __launch_bounds__(CLIMB_BLOCK) k_tree_climb(TreeTable tab, const u32* active, const u32* count, const ZeroTable* zt,
+                                                            unsigned long long* hashes, int trace) {
+    extern __shared__ u32 lcnt[];
+    __shared__ u32 n_sh;
+    u32 n_active = *count;
+    if (n_active > TREE_ACTIVE_CAP) n_active = TREE_ACTIVE_CAP;
+    if (blockIdx.x >= n_active) return;
+    const u32 a = active[blockIdx.x];
+    const TreeGeom& g = tab.f[a >> 16];
+    const u32 region = a & 0xffffu;
+    if (g.skip) return;  // (a field that is rebuilt this time: the rebuild has cleared its lists)
     __builtin_amdgcn_s_setprio(3);
-    const u64 p = list[t];
-    const u32 h = tree_climb(tab.f[(u32)(p >> TREE_SLOT_SHIFT)], p & TREE_ENTRY_MASK, zt);
+    if (trace && threadIdx.x == 0 && blockIdx.x < 2048) g_tree_trace[3 * blockIdx.x] = wall_clock64();
+    if (threadIdx.x == 0) n_sh = g.rcount[region];
+    for (u32 i = threadIdx.x; i < (1u << g.T); i += CLIMB_BLOCK) lcnt[i] = 0;
+    __syncthreads();
+    const u32 n = n_sh;
+    const uint16_t* list = g.rlist + ((u64)region << g.T);
+    for (u32 j = threadIdx.x; j < n; j += CLIMB_BLOCK) tree_region_count(g, lcnt, list[j]);
+    __syncthreads();
+    if (threadIdx.x == 0) g.rcount[region] = 0;  // the list is consumed
+    if (trace && threadIdx.x == 0 && blockIdx.x < 2048) g_tree_trace[3 * blockIdx.x + 1] = wall_clock64();
+    u32 h = 0;
+    for (u32 j = threadIdx.x; j < n; j += CLIMB_BLOCK) h += tree_region_climb(g, lcnt, region, list[j], zt);
     if (h) atomicAdd(hashes, (unsigned long long)h);
+    if (trace && blockIdx.x < 2048) {
+        __syncthreads();
+        if (threadIdx.x == 0) g_tree_trace[3 * blockIdx.x + 2] = wall_clock64();
+    }
 }
 
 // rebuild: element roots of a record kind
@@ -50,12 +74,12 @@ void ResidentTrees::release() {
         if (t.block) (void)hipFree(t.block);
         t = FieldTree();
     }
-    if (d_list) (void)hipFree(d_list);
+    if (d_active) (void)hipFree(d_active);
     if (d_count) (void)hipFree(d_count);
-    d_list = nullptr;
+    d_active = nullptr;
     d_count = nullptr;
-    list_cap = bound_total = 0;
-    n_slots = 0;
+    bound_total = 0;
+    n_slots = max_T = 0;
 }
 
 int ResidentTrees::sync_geometry(const StatePlan& plan) {
@@ -64,12 +88,12 @@ int ResidentTrees::sync_geometry(const StatePlan& plan) {
         return ECGPU_ERR_BAD_ARG;
     }
     n_slots = (u32)plan.bigs.size();
-    u64 want_cap = 1024;
+    max_T = 0;
     for (u32 s = 0; s < n_slots; s++) {
         const BigField& b = plan.bigs[s];
         FieldTree& t = f[s];
-        const bool cache = b.n0 >= TREE_MIN_ENTRIES && b.kind != LEAF_NODES;
         const u32 H = ceil_log2_u64(b.n0 ? b.n0 : 1);
+        const bool cache = b.n0 >= TREE_MIN_ENTRIES && b.kind != LEAF_NODES && tree_top_level((u32)b.kind, H) <= TREE_MAX_T;
         if (!cache) {
             if (t.block) {
                 ECG_HIP_CHECK(hipDeviceSynchronize());
@@ -89,16 +113,18 @@ int ResidentTrees::sync_geometry(const StatePlan& plan) {
             }
             const u64 cap = 1ull << H;
             const bool records = b.kind != LEAF_CHUNKS;
-            const size_t b_lvl0 = records ? up256(32 * cap) : 0, b_nodes = up256(32 * cap), b_cnt = up256(4 * cap),
-                         b_flag = up256(4 * ((cap + 31) / 32));
-            ECG_HIP_CHECK(hipMalloc((void**)&t.block, b_lvl0 + b_nodes + b_cnt + b_flag));
+            const u32 T = tree_top_level((u32)b.kind, H);
+            const size_t b_lvl0 = records ? up256(32 * cap) : 0, b_nodes = up256(32 * cap), b_flag = up256(4 * ((cap + 31) / 32)),
+                         b_rcount = up256(4 * (cap >> T)), b_rlist = up256(2 * cap);
+            ECG_HIP_CHECK(hipMalloc((void**)&t.block, b_lvl0 + b_nodes + b_flag + b_rcount + b_rlist));
             t.g.lvl0 = records ? t.block : nullptr;
             t.g.nodes = t.block + b_lvl0;
-            t.g.cnt = (u32*)(t.block + b_lvl0 + b_nodes);
-            t.g.flag0 = (u32*)(t.block + b_lvl0 + b_nodes + b_cnt);
+            t.g.flag0 = (u32*)(t.block + b_lvl0 + b_nodes);  // flag0 and rcount are adjacent: one memset clears both
+            t.g.rcount = (u32*)(t.block + b_lvl0 + b_nodes + b_flag);
+            t.g.rlist = (uint16_t*)(t.block + b_lvl0 + b_nodes + b_flag + b_rcount);
             t.g.kind = (u32)b.kind;
             t.g.H = H;
-            t.g.T = tree_top_level(t.g.kind, H);
+            t.g.T = T;
             t.live = true;
             t.all_dirty = true;
         }
@@ -109,23 +135,13 @@ int ResidentTrees::sync_geometry(const StatePlan& plan) {
         t.depth = b.depth;
         t.mix = b.mix;
         t.mix_len = b.mix_len;
-        want_cap += t.share();
+        if (t.g.T > max_T) max_T = t.g.T;
     }
     if (!d_count) {
         ECG_HIP_CHECK(hipMalloc((void**)&d_count, 64));
         ECG_HIP_CHECK(hipMemset(d_count, 0, 64));
     }
-    if (want_cap > list_cap) {
-        u64* nl = nullptr;
-        ECG_HIP_CHECK(hipMalloc((void**)&nl, 8 * want_cap));
-        if (d_list) {
-            ECG_HIP_CHECK(hipDeviceSynchronize());
-            ECG_HIP_CHECK(hipMemcpy(nl, d_list, 8 * list_cap, hipMemcpyDeviceToDevice));
-            ECG_HIP_CHECK(hipFree(d_list));
-        }
-        d_list = nl;
-        list_cap = want_cap;
-    }
+    if (!d_active) ECG_HIP_CHECK(hipMalloc((void**)&d_active, 4 * TREE_ACTIVE_CAP));
     return ECGPU_SUCCESS;
 }
 
@@ -139,7 +155,14 @@ void ResidentTrees::collect_entries(u32 slot, u64 first, u64 last, std::vector<u
     }
     t.bound += cnt;
     bound_total += cnt;
-    for (u64 e = first; e <= last; e++) pairs.push_back(((u64)slot << TREE_SLOT_SHIFT) | e);
+    for (u64 e = first; e <= last; e++) {
+        pairs.push_back(((u64)slot << TREE_SLOT_SHIFT) | e);
+        const u64 r = e >> t.g.T;
+        if (!(t.region_bits[r >> 6] >> (r & 63) & 1)) {
+            t.region_bits[r >> 6] |= 1ull << (r & 63);
+            active_regions++;
+        }
+    }
 }
 
 void ResidentTrees::collect(u64 lo, u64 hi, std::vector<u64>& pairs) {
@@ -169,7 +192,7 @@ static TreeTable make_table(const ResidentTrees& R, const u8* d_ssz) {
 int ResidentTrees::mark(hipStream_t s, const u64* d_pairs, u32 n) {
     if (!n) return ECGPU_SUCCESS;
     const TreeTable tab = make_table(*this, nullptr);
-    hipLaunchKernelGGL(k_tree_mark, dim3((n + 255) / 256), dim3(256), 0, s, tab, d_pairs, n, d_list, d_count, (u32)list_cap);
+    hipLaunchKernelGGL(k_tree_mark, dim3((n + 255) / 256), dim3(256), 0, s, tab, d_pairs, n, d_active, d_count);
     ECG_HIP_CHECK(hipGetLastError());
     return ECGPU_SUCCESS;
 }
@@ -183,8 +206,8 @@ int ResidentTrees::update(hipStream_t s, const u8* d_ssz, u64* hashes) {
         TreeGeom g = tab.f[sl];
         g.skip = 0;
         const u64 cap = 1ull << g.H;
-        // counters and flags of a field that is rebuilt start from zero: marks made before it was flagged are void
-        ECG_HIP_CHECK(hipMemsetAsync(g.cnt, 0, 4 * cap + up256(4 * ((cap + 31) / 32)) + (up256(4 * cap) - 4 * cap), s));
+        // flags and region lists of a field that is rebuilt start from zero: marks made before it was flagged are void
+        ECG_HIP_CHECK(hipMemsetAsync(g.flag0, 0, up256(4 * ((cap + 31) / 32)) + up256(4 * (cap >> g.T)), s));
         ProfScope ps("merkle_tree_rebuild", s);
         if (g.lvl0) hipLaunchKernelGGL(k_tree_leaves, dim3((unsigned)((g.n0 + 255) / 256)), dim3(256), 0, s, g);
         for (u32 k = 0; k < g.T;) {
@@ -199,19 +222,34 @@ int ResidentTrees::update(hipStream_t s, const u8* d_ssz, u64* hashes) {
         ECG_HIP_CHECK(hipGetLastError());
         if (hashes) *hashes += tree_rebuild_hashes(g);
     }
-    if (bound_total) {
-        const u64 n = bound_total < list_cap ? bound_total : list_cap;
+    if (active_regions) {
+        // one single-wave workgroup per active region, and LDS claimed so that a CU takes four of them -- one per SIMD: a
+        // climb is a dependent chain of hash64, and chains that share a SIMD take turns (at 8 KB of LDS the dispatcher packed
+        // the 1 024 regions of a slot several to a SIMD: 25 us per level instead of 6, profiles/r05e_resident_probe_trace.txt)
+        const u32 n = active_regions < TREE_ACTIVE_CAP ? active_regions : TREE_ACTIVE_CAP;
+        // (36 KB + the few static bytes: four fit a CU's 160 KB, a fifth does not; at 40 KB only three did and a quarter of a
+        // slot's regions started 70 us late)
+        static const u32 claim_kb = [] { const char* e = getenv("ECGPU_TREE_LDS_KB"); return e ? (u32)atoi(e) : 36u; }();
+        const u32 lds = (4u << max_T) > claim_kb * 1024 ? (4u << max_T) : claim_kb * 1024;
         ProfScope ps("merkle_tree_climb", s);
-        hipLaunchKernelGGL(k_tree_climb, dim3((unsigned)((n + CLIMB_BLOCK - 1) / CLIMB_BLOCK)), dim3(CLIMB_BLOCK), 0, s, tab, (const u64*)d_list,
-                           (const u32*)d_count, (u32)list_cap, zt, d_hashes());
+        static const int trace = [] { const char* e = getenv("ECGPU_TREE_TRACE"); return e ? atoi(e) : 0; }();
+        if (trace) {
+            void* tr = nullptr;
+            ECG_HIP_CHECK(hipGetSymbolAddress(&tr, HIP_SYMBOL(g_tree_trace)));
+            ECG_HIP_CHECK(hipMemsetAsync(tr, 0, sizeof(g_tree_trace), s));
+        }
+        hipLaunchKernelGGL(k_tree_climb, dim3(n), dim3(CLIMB_BLOCK), lds, s, tab, (const u32*)d_active, (const u32*)d_count, zt,
+                           d_hashes(), trace);
         ECG_HIP_CHECK(hipGetLastError());
         ECG_HIP_CHECK(hipMemsetAsync(d_count, 0, 4, s));
     }
     for (u32 sl = 0; sl < TREE_MAX_FIELDS; sl++) {
         f[sl].all_dirty = false;
         f[sl].bound = 0;
+        std::memset(f[sl].region_bits, 0, sizeof(f[sl].region_bits));
     }
     bound_total = 0;
+    active_regions = 0;
     return ECGPU_SUCCESS;
 }
 
@@ -242,3 +280,9 @@ u64 ResidentTrees::job_hashes(u32 slot) const {
 }
 
 }  // namespace ecg
+
+extern "C" int ecgpu_debug_tree_trace(unsigned long long* out /* 3 x 2048 */) {
+    ECG_HIP_CHECK(hipDeviceSynchronize());
+    ECG_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ecg::g_tree_trace), sizeof(ecg::g_tree_trace)));
+    return ECGPU_SUCCESS;
+}

@@ -18,15 +18,18 @@ struct FieldTree {
     bool live = false;       // cached (>= TREE_MIN_ENTRIES level-0 entries)
     bool all_dirty = true;   // rebuilt from scratch at the next root
     u64 bound = 0;           // dirty-list entries this field may hold (pairs handed to mark since the last root)
-    u64 share() const { return (1ull << g.H) / 8 > 64 ? (1ull << g.H) / 8 : 64; }  // its share of the list; beyond: all_dirty
+    u64 region_bits[8] = {};  // regions with a mark since the last root (<= 512): the climb launch gets one workgroup per set bit
+    u64 share() const { return (1ull << g.H) / 8 > 64 ? (1ull << g.H) / 8 : 64; }  // beyond this many marks a rebuild is cheaper: all_dirty
 };
 
 struct ResidentTrees {
     FieldTree f[TREE_MAX_FIELDS];  // slot = position of the field in StatePlan::bigs (stable for a fork)
     u32 n_slots = 0;
-    u64* d_list = nullptr;         // dirty list: (slot << 56) | entry
-    u32* d_count = nullptr;        // [0] entries in the list; [2..3] u64: hash64 performed by climbs since it was last cleared
-    u64 list_cap = 0, bound_total = 0;
+    u32* d_active = nullptr;       // active regions: (slot << 16) | region, TREE_ACTIVE_CAP entries
+    u32* d_count = nullptr;        // [0] active regions listed; [2..3] u64: hash64 performed by climbs since it was last cleared
+    u64 bound_total = 0;           // dirty entries handed to mark since the last root (>= active regions)
+    u32 active_regions = 0;        // regions marked since the last root, counted on the host: the device list has as many entries
+    u32 max_T = 0;                 // largest region height among the live fields: LDS of the climb launch
 
     // after create and after every length change: field offsets / counts from the plan; a field whose height changed (or that
     // is new) is reallocated and rebuilt at the next root

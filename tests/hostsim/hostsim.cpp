@@ -192,11 +192,13 @@ u64 hs_tree_update(int kind, const u8* before, u64 bytes_before, u64 n0_before, 
     g.T = tree_top_level(g.kind, g.H);
     const u64 cap = 1ull << g.H;
     std::vector<u8> lvl0(kind != LEAF_CHUNKS ? 32 * cap : 0), nodes(32 * cap);
-    std::vector<u32> cnt(cap, 0), flag((cap + 31) / 32, 0);
+    std::vector<u32> flag((cap + 31) / 32, 0), rcount(cap >> g.T, 0);
+    std::vector<uint16_t> rlist(cap, 0);
     g.lvl0 = kind != LEAF_CHUNKS ? lvl0.data() : nullptr;
     g.nodes = nodes.data();
-    g.cnt = cnt.data();
     g.flag0 = flag.data();
+    g.rcount = rcount.data();
+    g.rlist = rlist.data();
     g.src = before;
     g.bytes = bytes_before;
     g.n0 = n0_before;
@@ -216,22 +218,28 @@ u64 hs_tree_update(int kind, const u8* before, u64 bytes_before, u64 n0_before, 
     g.src = after;
     g.bytes = bytes_after;
     g.n0 = n0_after;
-    std::vector<u64> list(n_marks + 1);
-    u32 count = 0;
-    for (u32 i = 0; i < n_marks; i++) tree_mark(g, 3, marks[i], list.data(), &count, n_marks);
-    u64 x = seed | 1;
-    for (u32 i = count; i > 1; i--) {  // Fisher-Yates with a 64-bit LCG
-        x = x * 6364136223846793005ull + 1442695040888963407ull;
-        std::swap(list[i - 1], list[(x >> 33) % i]);
-    }
-    u64 hashes = 0;
-    for (u32 i = 0; i < count; i++) {
-        if ((list[i] >> TREE_SLOT_SHIFT) != 3) return ~0ull;
-        hashes += tree_climb(g, list[i] & TREE_ENTRY_MASK, zt());
-    }
+    std::vector<u32> active(TREE_ACTIVE_CAP);
+    u32 n_active = 0;
+    for (u32 i = 0; i < n_marks; i++) tree_mark(g, 3, marks[i], active.data(), &n_active);
+    u64 x = seed | 1, hashes = 0;
     u32 bad = 0;
-    for (u32 c : cnt) bad += c != 0;
+    std::vector<u32> lcnt(1u << g.T);
+    for (u32 a = 0; a < n_active; a++) {  // one "workgroup" per active region (k_tree_climb)
+        if ((active[a] >> 16) != 3) return ~0ull;
+        const u32 region = active[a] & 0xffffu, n = g.rcount[region];
+        std::vector<uint16_t> list(g.rlist + ((u64)region << g.T), g.rlist + ((u64)region << g.T) + n);
+        std::fill(lcnt.begin(), lcnt.end(), 0u);
+        for (u32 j = 0; j < n; j++) tree_region_count(g, lcnt.data(), list[j]);
+        g.rcount[region] = 0;
+        for (u32 i = n; i > 1; i--) {  // pass 2 in an order shuffled by a 64-bit LCG
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(list[i - 1], list[(x >> 33) % i]);
+        }
+        for (u32 j = 0; j < n; j++) hashes += tree_region_climb(g, lcnt.data(), region, list[j], zt());
+        for (u32 c : lcnt) bad += c != 0;
+    }
     for (u32 f : flag) bad += f != 0;
+    for (u32 c : rcount) bad += c != 0;
     if (left) *left = bad;
     const u8* in = g.T == 0 ? g.lvl0 : g.nodes + 32 * tree_heap_off(g.H, g.T);
     hs_tree_job(in, (u32)tree_level_count(g.n0, g.T), g.T, depth, mix, mix_len, out_root);
