@@ -429,6 +429,7 @@ static const int g_pairing_mode = [] {
     if (e && !strcmp(e, "vm3")) return 4;
     if (e && !strcmp(e, "split")) return 5;   // two lanes per tuple for the Miller loop (k_miller2) + k_finalexp, every size
     if (e && !strcmp(e, "auto1")) return 6;   // round 3's dispatch: lane groups up to ECGPU_VM_MAX tuples, the one-lane kernel above
+    if (e && !strcmp(e, "row")) return 7;     // round 5: the row machine (bls_row.hip) at every size
     return 3;
 }();
 // Which build of the G2 stage kernels runs: 1 = sums of products (bls_g2_kernels.hip), 2 = the compact-code tower
@@ -484,6 +485,13 @@ static const int g_side_overlap = [] {
 static const int g_h2c_finish_lanes = [] {
     const char* e = getenv("ECGPU_H2C_FINISH_LANES");
     return e ? atoi(e) : 2;
+}();
+// Up to this many tuples the pairing check runs on the row machine (round 5, bls_row.hip: one workgroup per tuple, one Fp
+// operation per 16-lane row): a lone check 3.45 -> ~0.7 ms.  Its throughput is below the lane groups' (3 of 16 lanes idle, two
+// barriers per round), so it hands over where the lane groups' latency catches up (profiles/r05*_row_*).
+static const u32 g_row_max_tuples = [] {
+    const char* e = getenv("ECGPU_ROW_MAX");
+    return e ? (u32)strtoul(e, nullptr, 10) : 512u;
 }();
 static const u32 g_vm_max_tuples = [] {  // (round 3: 24 576, the crossover with the lane kernel's 22 ms; round 4: with the split path's 12.4 ms)
     const char* e = getenv("ECGPU_VM_MAX");
@@ -696,9 +704,20 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         const bool slow_box = g_tower.load() == 2;  // large-code kernels crawl here: the 47 KB kernel at every size
         const bool auto_mode = g_pairing_mode == 3 || g_pairing_mode == 6;
         const u32 split_max = g_pairing_mode == 3 ? g_split_max_tuples : 0;  // auto1 (round 3's rule) has no split window
-        auto small_path = [&](u32 cnt) { return cnt <= g_vm_max_tuples ? 3 : cnt <= split_max ? 5 : 1; };
+        auto run_row = [&](u32 base, u32 cnt) -> int {
+            u32* xfer = (u32*)ar.take(vm3_xfer_bytes(cnt));
+            if (!xfer) return ECGPU_ERR_OOM;
+            return row_pairing_launch(s, (const A1*)agg + base, (const u8*)st_pk + base, d_pk_off ? d_pk_off + base : nullptr, (const A2*)hpts + base,
+                                      (const A2*)sigpts + base, (const u8*)st_dec + base, (const u8*)st_grp + base, d_sigs96 + (size_t)96 * base, cnt,
+                                      eth_variant, d_status + base, xfer);
+        };
+        const u32 row_max = g_pairing_mode == 3 ? g_row_max_tuples : 0;  // (auto1 = round 3's rule: no row machine)
+        auto small_path = [&](u32 cnt) { return cnt <= row_max ? 7 : cnt <= g_vm_max_tuples ? 3 : cnt <= split_max ? 5 : 1; };
         int rc = ECGPU_SUCCESS;
-        if (g_pairing_mode == 4 || (auto_mode && slow_box)) {
+        if (g_pairing_mode == 7 || (auto_mode && slow_box && n <= row_max)) {
+            t_last_pairing_path = 7;  // (its hot loop is ~30 KB of code: inside the instruction cache, like the lane groups')
+            rc = run_row(0, n);
+        } else if (g_pairing_mode == 4 || (auto_mode && slow_box)) {
             t_last_pairing_path = 3;
             rc = run_vm3(0, n);
         } else if (g_pairing_mode == 5 || (g_pairing_mode == 3 && g_split_default)) {
@@ -709,7 +728,8 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             run_lane(0, n);
         } else if (n <= lane_round) {
             t_last_pairing_path = small_path(n);
-            if (t_last_pairing_path == 3) rc = run_vm3(0, n);
+            if (t_last_pairing_path == 7) rc = run_row(0, n);
+            else if (t_last_pairing_path == 3) rc = run_vm3(0, n);
             else if (t_last_pairing_path == 5) rc = run_split(0, n);
             else run_lane(0, n);
         } else {
@@ -718,7 +738,8 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             const int tail = ragged_tail && rem ? small_path(rem) : 1;
             const u32 full = tail == 1 ? n : n - rem;
             run_lane(0, full);
-            if (tail == 3) rc = run_vm3(full, rem);
+            if (tail == 7) rc = run_row(full, rem);
+            else if (tail == 3) rc = run_vm3(full, rem);
             else if (tail == 5) rc = run_split(full, rem);
         }
         if (rc) return rc;

@@ -27,14 +27,6 @@ constexpr int VM3_TPW_A = 64 / VM3_G_A, VM3_TPW_C = 64 / VM3_G_C;  // tuples per
 constexpr u32 XFER3_REGS = 16;          // per tuple: f (12 Fp, w-power order), d, -, 1/d, -
 constexpr u32 XFER3_STRIDE = XFER3_REGS * VM3_REG_DW;
 
-struct Vm3Desc {
-    const u32* prog;       // rounds x LANES x 8 descriptor dwords
-    const u32* hdr;        // rounds header words
-    const u32* const_reg;  // nconst register numbers
-    const u32* const_val;  // nconst x 13 limbs (Montgomery)
-    u32 rounds, nreg, nconst, nin, nout;
-    u32 in_reg[16], out_reg[16];
-};
 static Vm3Desc g_vm3_a_dev[MAX_DEVICES], g_vm3_c_dev[MAX_DEVICES];  // program tables live in each device's memory
 #define g_vm3_a g_vm3_a_dev[current_device()]
 #define g_vm3_c g_vm3_c_dev[current_device()]
@@ -63,10 +55,14 @@ static int upload3(const unsigned int* h, size_t n, const u32** d) {
         for (int i = 0; i < ECG_VM3_##T##_NOUT; i++) D.out_reg[i] = ECG_VM3_##T##_OUT[i];                                    \
     } while (0)
 
+const Vm3Desc& vm3_program(int part) { return part == 0 ? g_vm3_a : g_vm3_c; }
+
 int init_vm3_tables() {
     static_assert(ECG_VM3_A_NIN == 10 && ECG_VM3_A_NOUT == 14 && ECG_VM3_C_NIN == 14 && ECG_VM3_C_NOUT == 12, "program interface");
     static_assert(VM3_G_A <= 64 && VM3_G_A % 2 == 0 && VM3_G_C <= 64 && VM3_G_C % 2 == 0, "results travel in lane pairs; lanes beyond TPW groups of a wave idle");
     static_assert(ECG_VM3_CONST_BASE == VM3_CONST_BASE, "generator and kernel agree on where the constants start");
+    static_assert(ECG_VM3_A_LANES == VM3_SLOTS_A && ECG_VM3_C_LANES == VM3_SLOTS_C, "the row machine (bls_row.hip) runs the same programs");
+    static_assert(XFER3_STRIDE == VM3_XFER_STRIDE, "one transfer layout for both machines");
     VM3_FILL(g_vm3_a, A);
     VM3_FILL(g_vm3_c, C);
     return ECGPU_SUCCESS;
@@ -228,6 +224,10 @@ __global__ void __launch_bounds__(64) k_vm3_pair_c(Vm3Desc d, const u32* xfer, c
 }
 
 size_t vm3_xfer_bytes(u32 n) { return (size_t)n * XFER3_STRIDE * 4 + 256; }
+
+void vm3_launch_inv(hipStream_t s, u32* xfer, u32 n) {
+    hipLaunchKernelGGL(k_vm3_inv, dim3((n + BLS_BLOCK - 1) / BLS_BLOCK), dim3(BLS_BLOCK), 0, s, xfer, n);
+}
 
 int vm3_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts,
                        const u8* st_dec, const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer) {

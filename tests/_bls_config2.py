@@ -17,7 +17,7 @@ import random
 import sys
 import time
 
-PATH_NAMES = {0: "none", 1: "lane", 3: "vm3", 5: "split"}
+PATH_NAMES = {0: "none", 1: "lane", 3: "vm3", 5: "split", 7: "row"}
 
 
 def prepare(n: int, path: str, n_samples: int = 72) -> dict:

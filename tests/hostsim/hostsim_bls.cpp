@@ -2,6 +2,7 @@
 // kernels run -- TEST INFRASTRUCTURE ONLY (see hostsim.cpp).  Values cross this boundary as
 // big-endian canonical integers so that the tests can compare with oracle/bls12_381.py directly.
 #include <cstring>
+#include <array>
 #include <vector>
 
 #define ECG_COUNT_OPS 1
@@ -10,6 +11,7 @@
 #include <thread>
 
 #include "bls_vm3.h"
+#include "bls_row.h"
 #include "bls_vm3_prog.h"
 #include "bls_pair2.h"
 #include "bls_g2_pair2.h"
@@ -405,6 +407,79 @@ int hs_vm3_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
     for (int k = 0; k < 6; k++) *c[k] = Fp2{vm3_load(Cr, ECG_VM3_C_OUT[2 * k]), vm3_load(Cr, ECG_VM3_C_OUT[2 * k + 1])};
     out_fp12(e, out576);
     return fp12_is_one(e) ? 1 : 0;
+}
+
+// The same programs on the ROW machine (csrc/bls_row.h: one Fp operation across a 16-lane row, limb per lane), with the kernel's
+// schedule: every row pair of the tuple computes from the register file as it was before the round (k_row_pair_*: up to the first
+// barrier), then every row pair writes (up to the second).  A row pair = the 32 host lanes of rv32.
+static void row_run_host(const unsigned int* prog, const unsigned int* hdr, u32 rounds, u32 slots, const RowFile& F) {
+    rv32 p_limb;
+    for (int l = 0; l < ROW_SIM; l++) p_limb.v[l] = (l & 15) < 13 ? blsc::P[l & 15] : 0u;
+    std::vector<RowResult> res(slots / 2);
+    std::vector<std::array<rv32, 8>> ws(slots / 2);
+    for (u32 r = 0; r < rounds; r++) {
+        const u32 n = hdr[r] & 255, nder = (hdr[r] >> 8) & 255;
+        for (u32 pr = 0; pr < slots / 2; pr++) {
+            rv32 w[8];
+            for (int q = 0; q < 8; q++)
+                for (int l = 0; l < ROW_SIM; l++) w[q].v[l] = prog[((size_t)r * slots + 2 * pr + (l >> 4)) * VM3_DESC_DW + q];
+            res[pr] = row_round_compute(F, n, nder, w, p_limb);
+            for (int q = 0; q < 8; q++) ws[pr][q] = w[q];
+        }
+        for (u32 pr = 0; pr < slots / 2; pr++) {
+            rv32 w[8];
+            for (int q = 0; q < 8; q++) w[q] = ws[pr][q];
+            row_round_store(F, n, nder, w, res[pr]);
+        }
+    }
+}
+static void row_file_init(std::vector<u32>& lds, u32 nreg, u32 nconst, const unsigned int* const_reg, const unsigned int* const_val) {
+    lds.assign((size_t)(nreg + 64) * ROW_REG_DW, 0xdeadbeefu);  // (unwritten registers are poison: a program never reads them)
+    for (u32 i = 0; i < ROW_REG_DW; i++) lds[i] = 0;
+    for (u32 c = 0; c < nconst; c++)
+        for (u32 k = 0; k < ROW_REG_DW; k++) lds[(size_t)(nreg + const_reg[c] - VM3_CONST_BASE) * ROW_REG_DW + k] = k < 13 ? const_val[c * 13 + k] : 0u;
+}
+static void row_put_host(std::vector<u32>& lds, u32 reg, const Fp& x) {
+    for (u32 k = 0; k < ROW_REG_DW; k++) lds[(size_t)reg * ROW_REG_DW + k] = k < 13 ? x.l[k] : 0u;
+}
+int hs_row_pairing(const u8* p_xy, const u8* h_xy, const u8* s_xy, u8* out576) {
+    g_ecg_column_overflows = 0;
+    std::vector<u32> LA, LC;
+    row_file_init(LA, ECG_VM3_A_NREG, ECG_VM3_A_NCONST, ECG_VM3_A_CONST_REG, ECG_VM3_A_CONST_VAL);
+    row_file_init(LC, ECG_VM3_C_NREG, ECG_VM3_C_NCONST, ECG_VM3_C_CONST_REG, ECG_VM3_C_CONST_VAL);
+    A1 p = in_a1(p_xy, 0);
+    A2 h = in_a2(h_xy, 0), sg = in_a2(s_xy, 0);
+    const Fp in[10] = {p.x, p.y, h.x.c0, h.x.c1, h.y.c0, h.y.c1, sg.x.c0, sg.x.c1, sg.y.c0, sg.y.c1};
+    for (int k = 0; k < 10; k++) row_put_host(LA, ECG_VM3_A_IN[k], in[k]);
+    row_run_host(ECG_VM3_A_PROG, ECG_VM3_A_HDR, ECG_VM3_A_ROUNDS, ECG_VM3_A_LANES, RowFile{LA.data(), ECG_VM3_A_NREG});
+    for (int k = 0; k < 12; k++) row_put_host(LC, ECG_VM3_C_IN[k], row_image_to_fp(LA.data() + (size_t)ECG_VM3_A_OUT[k] * ROW_REG_DW));
+    row_put_host(LC, ECG_VM3_C_IN[12], fp_inv(row_image_to_fp(LA.data() + (size_t)ECG_VM3_A_OUT[12] * ROW_REG_DW)));
+    row_put_host(LC, ECG_VM3_C_IN[13], fp_zero());
+    row_run_host(ECG_VM3_C_PROG, ECG_VM3_C_HDR, ECG_VM3_C_ROUNDS, ECG_VM3_C_LANES, RowFile{LC.data(), ECG_VM3_C_NREG});
+    Fp12 e;
+    Fp2* c[6] = {&e.c0.c0, &e.c1.c0, &e.c0.c1, &e.c1.c1, &e.c0.c2, &e.c1.c2};
+    for (int k = 0; k < 6; k++)
+        *c[k] = Fp2{row_image_to_fp(LC.data() + (size_t)ECG_VM3_C_OUT[2 * k] * ROW_REG_DW),
+                    row_image_to_fp(LC.data() + (size_t)ECG_VM3_C_OUT[2 * k + 1] * ROW_REG_DW)};
+    out_fp12(e, out576);
+    if (g_ecg_column_overflows) return -1;  // a lane's 64-bit accumulator overflowed
+    return fp12_is_one(e) ? 1 : 0;
+}
+
+// one sum of products on the row machine against the one-lane routine: raw limbs in, limbs (<= 2^30) out
+u64 hs_row_sumprod_raw(int n, const u32* a, const u32* b, u32* out) {
+    g_ecg_column_overflows = 0;
+    rv32 av[7], bv[7][13], p_limb;
+    for (int l = 0; l < ROW_SIM; l++) p_limb.v[l] = (l & 15) < 13 ? blsc::P[l & 15] : 0u;
+    for (int k = 0; k < 7; k++) {
+        for (int l = 0; l < ROW_SIM; l++) av[k].v[l] = (k < n && (l & 15) < 13) ? a[13 * k + (l & 15)] : 0u;
+        for (int i = 0; i < 13; i++) bv[k][i] = rv_splat(k < n ? b[13 * k + i] : 0u);
+    }
+    const rv32 r = row_sumprod<7>(av, bv, p_limb);
+    for (int i = 0; i < 16; i++) out[i] = r.v[i];
+    for (int i = 0; i < 16; i++)
+        if (r.v[16 + i] != r.v[i]) return ~0ull;  // both rows of the pair ran the same sum
+    return g_ecg_column_overflows;
 }
 
 u64 hs_sumprod_raw(int n, const u32* a, const u32* b, u32* out) {

@@ -95,6 +95,54 @@ def _sumprod(avals, bvals):
     return ov, sum(int(out[i]) << (30 * i) for i in range(13))
 
 
+def _row_sumprod(alimbs, blimbs):
+    """one sum of products on the row machine (csrc/bls_row.h row_sumprod: limb j of every operand in lane j of a 16-lane row)"""
+    n = len(alimbs)
+    arr = (ctypes.c_uint32 * (13 * n))
+    out = (ctypes.c_uint32 * 16)()
+    L = lib()
+    L.hs_row_sumprod_raw.restype = ctypes.c_uint64
+    ov = L.hs_row_sumprod_raw(n, arr(*[w for v in alimbs for w in v]), arr(*[w for v in blimbs for w in v]), out)
+    return ov, [int(x) for x in out]
+
+
+def test_row_machine_sum_of_products_equals_the_one_lane_sum():
+    """row_sumprod (13 iterations of multiply-adds into ONE accumulator per lane, quotient digit from lane 0, window shifted one
+    lane down, two carry passes) returns the same integer < 2p as fp_sumprod for 1 .. 7 products -- for normalised operands, for
+    lazy ones (limbs == 2^30, the row machine's own output format), for the largest bounds the generator admits -- and no
+    lane's 64-bit accumulator ever overflows."""
+    r = random.Random(77)
+    R = 1 << 390
+    Rinv = pow(R, -1, P)
+
+    def lazy(v):  # a representation of v with some limbs pushed to exactly 2^30 (borrowing one from the limb above)
+        l = _limbs(v)
+        for i in range(12):
+            if l[i] == 0 and l[i + 1] > 0 and r.random() < 0.9:
+                l[i], l[i + 1] = 1 << 30, l[i + 1] - 1
+        return l
+
+    for n in range(1, 8):
+        for trial in range(40):
+            # sum of bound products <= 600 p^2 (tools/gen_bls_vm3.py LIMIT): bounds up to 2^9 p on one side
+            ka = [r.choice([1, 2, 2, 4, 9]) for _ in range(n)]
+            kb = [max(1, min(512, 600 // (n * k))) if trial % 3 == 0 else r.choice([1, 2]) for k in ka]
+            av = [r.randrange(k * P) if trial % 5 else k * P - 1 - r.randrange(3) for k in ka]
+            bv = [r.randrange(k * P) if trial % 7 else k * P - 1 for k in kb]
+            if trial == 1:
+                av = [sum(0x3FFFFFFF << (30 * i) for i in range(12)) + (1 << 360)] * n  # saturated low limbs
+            ov1, want = _sumprod(av, bv)
+            assert ov1 == 0
+            assert want % P == sum(a * b for a, b in zip(av, bv)) * Rinv % P
+            al = [lazy(v) if trial % 2 else _limbs(v) for v in av]
+            bl = [lazy(v) if trial % 4 >= 2 else _limbs(v) for v in bv]
+            ov, limbs = _row_sumprod(al, bl)
+            assert ov == 0, (n, trial)
+            assert limbs[13:] == [0, 0, 0]
+            assert all(x <= (1 << 30) for x in limbs[:12])
+            assert sum(x << (30 * i) for i, x in enumerate(limbs[:13])) == want, (n, trial)
+
+
 def _lin_raw(op, a, b=None):
     arr = ctypes.c_uint32 * 13
     out = arr()
@@ -394,7 +442,7 @@ def test_fast_aggregate_verify_status_algebra(variant):
         assert got == C.oracle_fav(pks, msg, sig, eth), (len(pks), eth)
 
 
-@pytest.mark.parametrize("entry", ["hs_vm3_pairing"])
+@pytest.mark.parametrize("entry", ["hs_vm3_pairing", "hs_row_pairing"])
 def test_lane_group_vm_pairing_programs(entry):
     """The generated lane-group programs (tools/gen_bls_vm3.py: Fp registers, sums of products with derived outputs) executed
     with the kernels' lock-step semantics and the kernels' own limb arithmetic: e(P, H) e(-g1, S) after the final
