@@ -482,16 +482,21 @@ static const int g_side_overlap = [] {
 // ECGPU_H2C_FINISH_LANES=1: the one-lane (round 3) end of the small-batch message stage.  Default: the lane pair -- on a box
 // with slow instruction fetch as well (its hot loop, one 43 KB doubling, fits the instruction cache: a slot 11.0 -> 8.2 ms
 // there, profiles/r04slow_*).
-static const int g_h2c_finish_lanes = [] {
+static const int g_h2c_finish_lanes = [] {  // (round 5 default: 16 = a row per message up to ECGPU_H2C_ROW_MAX messages, the lane pair above)
     const char* e = getenv("ECGPU_H2C_FINISH_LANES");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 16;
+}();
+static const u32 g_h2c_row_max = [] {
+    const char* e = getenv("ECGPU_H2C_ROW_MAX");
+    return e ? (u32)strtoul(e, nullptr, 10) : 4096u;
 }();
 // Up to this many tuples the pairing check runs on the row machine (round 5, bls_row.hip: one workgroup per tuple, one Fp
-// operation per 16-lane row): a lone check 3.45 -> ~0.7 ms.  Its throughput is below the lane groups' (3 of 16 lanes idle, two
-// barriers per round), so it hands over where the lane groups' latency catches up (profiles/r05*_row_*).
+// operation per 16-lane row): a lone check 3.45 -> 1.0 ms, 1 024 tuples 3.4 -> 2.3 ms.  Its throughput is below the lane groups'
+// (3 of 16 lanes idle, two barriers per round): 3.9 ms at 2 048 tuples against 3.5 -- it hands over where the lane groups'
+// latency catches up (profiles/r05i_probe_row_machine.txt).
 static const u32 g_row_max_tuples = [] {
     const char* e = getenv("ECGPU_ROW_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : 512u;
+    return e ? (u32)strtoul(e, nullptr, 10) : 1024u;
 }();
 static const u32 g_vm_max_tuples = [] {  // (round 3: 24 576, the crossover with the lane kernel's 22 ms; round 4: with the split path's 12.4 ms)
     const char* e = getenv("ECGPU_VM_MAX");
@@ -602,7 +607,11 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             hipLaunchKernelGGL(calls ? k_h2c_map_calls : k_h2c_map, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, h2c_maps);
             // ... and its end -- the addition of the two maps, the cofactor clearing, the affine conversion: a 3.5 ms chain on
             // one lane -- on a lane PAIR (bls_g2_pair2.h): half the Fp2 components, 0.57 of the instructions, per lane
-            if (g_h2c_finish_lanes == 1)
+            // (round 5) ... or on a ROW of 16 lanes, limb per lane (bls_rowcurve.h: 0.57 of the instructions per lane became
+            // ~0.2; up to 4 096 messages that is still at most one wave per SIMD)
+            if (g_h2c_finish_lanes == 16 && n <= g_h2c_row_max)
+                launch_h2c_finish_row(s2, (const J2*)h2c_maps, n, hpts);
+            else if (g_h2c_finish_lanes == 1)
                 hipLaunchKernelGGL(calls ? k_h2c_finish_calls : k_h2c_finish, grid_for(n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
             else
                 hipLaunchKernelGGL(k_h2c_finish2, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);

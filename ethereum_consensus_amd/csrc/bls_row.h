@@ -58,6 +58,30 @@ ROW_FN rv32 rv_from_next(rv32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (i
 ROW_FN rv32 rv_from_prev(rv32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); }  // row_shr:1
 // the same lane of the other row of the pair (rows 2m, 2m + 1 of a wave)
 ROW_FN rv32 rv_partner(rv32 x) { return (u32)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u) ^ 16u) << 2), (int)x); }
+// lane I of the lane's own row
+template <int I>
+ROW_FN rv32 rv_bcast(rv32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + I, 0xf, 0xf, true); }  // row_newbcast:I
+ROW_FN rv32 rv_or(rv32 a, rv32 b) { return a | b; }
+ROW_FN rv32 rv_xor(rv32 a, rv32 b) { return a ^ b; }
+ROW_FN rv32 rv_shl(rv32 a, u32 n) { return a << n; }
+ROW_FN rv32 rv_eq(rv32 a, rv32 b) { return a == b ? 1u : 0u; }
+ROW_FN rv32 rv_sar(rv32 a, u32 n) { return (u32)((int32_t)a >> n); }
+// 1 in every lane of the row if x != 0 in any of its lanes (the rows of a wave decide independently)
+ROW_FN rv32 rv_row_any(rv32 x) {
+    const u64 m = __builtin_amdgcn_ballot_w64(x != 0);
+    return ((m >> (threadIdx.x & 48u)) & 0xffffull) != 0 ? 1u : 0u;
+}
+ROW_FN bool rv_test(rv32 c) { return c != 0; }  // a row-uniform condition as a branch condition
+// exact carry propagation over limbs <= 2^30: a limb == 2^30 generates, a limb == 2^30 - 1 propagates; the chain is resolved by
+// ONE 64-bit addition of the two ballots (rows end in zero limbs, which neither generate nor propagate)
+// (limbs 0 .. 11 come out < 2^30; the top limb, lane 12, takes its carry and keeps every bit -- it may be a signed dword)
+ROW_FN rv32 rv_carry_exact(rv32 v) {
+    const bool low = (threadIdx.x & 15u) < 12;
+    const u64 g = __builtin_amdgcn_ballot_w64(low && (v >> 30) != 0), pr = __builtin_amdgcn_ballot_w64(low && v == FP_MASK);
+    const u64 y = g << 1, cin = ((pr + y) ^ pr ^ y) | y;
+    const u32 t = v + (u32)((cin >> (threadIdx.x & 63u)) & 1ull);
+    return low ? (t & FP_MASK) : t;
+}
 ROW_FN rv32 rv_lds_read(const u32* lds, rv32 dw) { return lds[dw]; }
 ROW_FN void rv_lds_read4(const u32* lds, rv32 dw, rv32* out) {  // 16-byte aligned
     const uint4 q = *reinterpret_cast<const uint4*>(lds + dw);
@@ -109,6 +133,36 @@ ROW_FN rv32 rv_bcast0(rv32 x) { rv32 r; ROW_EACH r.v[l_] = x.v[l_ & ~15]; return
 ROW_FN rv32 rv_from_next(rv32 x) { rv32 r; ROW_EACH r.v[l_] = (l_ & 15) == 15 ? 0u : x.v[l_ + 1]; return r; }
 ROW_FN rv32 rv_from_prev(rv32 x) { rv32 r; ROW_EACH r.v[l_] = (l_ & 15) == 0 ? 0u : x.v[l_ - 1]; return r; }
 ROW_FN rv32 rv_partner(rv32 x) { rv32 r; ROW_EACH r.v[l_] = x.v[l_ ^ 16]; return r; }
+template <int I>
+ROW_FN rv32 rv_bcast(rv32 x) { rv32 r; ROW_EACH r.v[l_] = x.v[(l_ & ~15) + I]; return r; }
+ROW_FN rv32 rv_or(rv32 a, rv32 b) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] | b.v[l_]; return r; }
+ROW_FN rv32 rv_xor(rv32 a, rv32 b) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] ^ b.v[l_]; return r; }
+ROW_FN rv32 rv_shl(rv32 a, u32 n) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] << n; return r; }
+ROW_FN rv32 rv_eq(rv32 a, rv32 b) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] == b.v[l_] ? 1u : 0u; return r; }
+ROW_FN rv32 rv_sar(rv32 a, u32 n) { rv32 r; ROW_EACH r.v[l_] = (u32)((int32_t)a.v[l_] >> n); return r; }
+ROW_FN rv32 rv_row_any(rv32 x) {
+    rv32 r;
+    ROW_EACH {
+        u32 any = 0;
+        for (int q = 0; q < 16; q++) any |= x.v[(l_ & ~15) + q];
+        r.v[l_] = any ? 1u : 0u;
+    }
+    return r;
+}
+// (the host runs the SAME computation on both simulated rows wherever a condition steers control flow: lane 0 speaks for both)
+ROW_FN bool rv_test(rv32 c) { return c.v[0] != 0; }
+ROW_FN rv32 rv_carry_exact(rv32 v) {
+    rv32 r;
+    for (int row = 0; row < ROW_SIM; row += 16) {
+        u32 c = 0;
+        for (int q = 0; q < 16; q++) {
+            const u32 t = v.v[row + q] + c;
+            r.v[row + q] = q < 12 ? (t & FP_MASK) : t;
+            c = q < 12 ? t >> 30 : 0;
+        }
+    }
+    return r;
+}
 ROW_FN rv32 rv_lds_read(const u32* lds, rv32 dw) { rv32 r; ROW_EACH r.v[l_] = lds[dw.v[l_]]; return r; }
 ROW_FN void rv_lds_read4(const u32* lds, rv32 dw, rv32* out) {
     ROW_EACH for (int q = 0; q < 4; q++) out[q].v[l_] = lds[dw.v[l_] + q];
@@ -157,7 +211,8 @@ ROW_FN rv32 row_derive(rv32 own, rv32 par, rv32 c_own, rv32 c_par, rv32 k, rv32 
     rv32 v = rv_add(rv_and(rv_lo(t), mask), rv_from_prev(hi));
     hi = rv_sel(below_top, rv_shr(v, 30), zero);
     v = rv_add(rv_and(v, mask), rv_from_prev(hi));
-    return v;
+    // exact limbs below the top: a limb == 2^30 left standing would let a value below 2^360 come out with top limb -1
+    return rv_carry_exact(v);
 }
 
 // ---- one round of a program for one row ---------------------------------------------------------------------------------------
@@ -166,9 +221,16 @@ struct RowFile {
     u32* lds;
     u32 nreg;
 };
-ROW_FN rv32 row_reg_dw(const RowFile& F, rv32 r) {  // first dword of register r (numbers from VM3_CONST_BASE name constants)
+// first dword of register r.  The kernels run a copy of the program whose register numbers ARE positions in the file
+// (bls_row.hip row_programs: constants renumbered behind the registers); the host simulator runs the generator's numbering,
+// where numbers from VM3_CONST_BASE name constants.
+ROW_FN rv32 row_reg_dw(const RowFile& F, rv32 r) {
+#if defined(__HIPCC__)
+    return r << 4;
+#else
     const rv32 is_own = rv_lt(r, VM3_CONST_BASE);
     return rv_mul_lo(rv_sel(is_own, r, rv_add(rv_sub(r, rv_splat(VM3_CONST_BASE)), rv_splat(F.nreg))), rv_splat(ROW_REG_DW));
+#endif
 }
 struct RowResult {
     rv32 own, der[4];

@@ -6,6 +6,9 @@
 #include "bls_verify.h"
 #include "bls_vm_host.h"
 
+#include <mutex>
+#include <vector>
+
 namespace ecg {
 
 // rows per tuple = lane slots of the program (16: Miller loops, 12: final exponentiation)
@@ -108,10 +111,53 @@ __global__ void __launch_bounds__(192) k_row_pair_c(Vm3Desc d, const u32* xfer, 
     }
 }
 
+// The row machine's copy of a program: register numbers are positions in ITS register file (the program's constants, numbers
+// from VM3_CONST_BASE up, sit behind the nreg registers of the tuple), so an operand's image starts at dword 16 x its byte --
+// the interpreter does not spend five instructions per operand telling constants from registers.
+static Vm3Desc g_row_prog[MAX_DEVICES][2];
+static bool g_row_prog_ready[MAX_DEVICES] = {};
+static int row_programs() {
+    const int dev = current_device();
+    if (g_row_prog_ready[dev]) return ECGPU_SUCCESS;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_row_prog_ready[dev]) return ECGPU_SUCCESS;
+    for (int part = 0; part < 2; part++) {
+        Vm3Desc d = vm3_program(part);
+        const u32 slots = part == 0 ? VM3_SLOTS_A : VM3_SLOTS_C;
+        const size_t n_dw = (size_t)d.rounds * slots * VM3_DESC_DW;
+        if (d.nreg + d.nconst > 255) {
+            set_last_error("row machine: register file does not fit a byte");
+            return ECGPU_ERR_BAD_ARG;
+        }
+        std::vector<u32> h(n_dw);
+        ECG_HIP_CHECK(hipMemcpy(h.data(), d.prog, n_dw * 4, hipMemcpyDeviceToHost));
+        auto remap = [&](u32 r) { return r >= VM3_CONST_BASE ? d.nreg + (r - VM3_CONST_BASE) : r; };
+        auto remap_word = [&](u32 w, u32 from_byte) {
+            u32 o = w;
+            for (u32 b = from_byte; b < 4; b++) o = (o & ~(255u << (8 * b))) | (remap((w >> (8 * b)) & 255u) << (8 * b));
+            return o;
+        };
+        for (size_t i = 0; i < n_dw; i += VM3_DESC_DW) {
+            for (int q = 0; q < 4; q++) h[i + q] = remap_word(h[i + q], 0);  // dst, a0 .. a6, b0 .. b6 (+ one unused byte)
+            // (derived outputs name own registers only: byte 0 of w4 .. w7 is never a constant)
+        }
+        u32* dp = nullptr;
+        ECG_HIP_CHECK(hipMalloc((void**)&dp, n_dw * 4));
+        ECG_HIP_CHECK(hipMemcpy(dp, h.data(), n_dw * 4, hipMemcpyHostToDevice));
+        d.prog = dp;
+        g_row_prog[dev][part] = d;
+    }
+    g_row_prog_ready[dev] = true;
+    return ECGPU_SUCCESS;
+}
+
 int row_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                        const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer) {
     if (!n) return ECGPU_SUCCESS;
-    const Vm3Desc &pa = vm3_program(0), &pc = vm3_program(1);
+    int rc = row_programs();
+    if (rc) return rc;
+    const Vm3Desc &pa = g_row_prog[current_device()][0], &pc = g_row_prog[current_device()][1];
     const size_t lds_a = (size_t)(pa.nreg + pa.nconst) * ROW_REG_DW * 4, lds_c = (size_t)(pc.nreg + pc.nconst) * ROW_REG_DW * 4;
     {
         ProfScope p("bls_row_a", s);

@@ -12,6 +12,7 @@
 
 #include "bls_vm3.h"
 #include "bls_row.h"
+#include "bls_rowcurve.h"
 #include "bls_vm3_prog.h"
 #include "bls_pair2.h"
 #include "bls_g2_pair2.h"
@@ -256,6 +257,50 @@ void hs_hash_to_g2_pair2(const u8* msg, u64 len, u8* xy, int* inf) {
     out_a2(h, xy);
     *inf = (int)h.inf;
 }
+// the end of the message stage on a ROW (bls_rowcurve.h, k_h2c_finish_row): the two maps on one lane each, then the addition,
+// the cofactor clearing and the affine conversion with one point per 16-lane row -- the same routines on the host's lane vectors
+void hs_hash_to_g2_row(const u8* msg, u64 len, u8* xy, int* inf) {
+    g_ecg_column_overflows = 0;
+    J2 q0, q1;
+    hash_to_g2_map(q0, msg, (size_t)len, 0);
+    hash_to_g2_map(q1, msg, (size_t)len, 1);
+    std::vector<u32> tab(16 * ROW_REG_DW, 0);
+    A2 h;
+    std::memset(&h, 0, sizeof(h));
+    r_hash_to_g2_finish(&h, &q0, &q1, tab.data());
+    out_a2(h, xy);
+    *inf = g_ecg_column_overflows ? -1 : (int)h.inf;
+}
+// row field operations on raw limbs (13 x u32 in, 13 out): 0 add 1 sub 2 neg 3 mul 4 sqr 5 canon 6 sub_dbl 7 pow_pm3d4 8 is_zero 9 eq
+int hs_rowfield_op(int op, const u32* a, const u32* b, u32* out) {
+    g_ecg_column_overflows = 0;
+    const RowK K = row_k();
+    Fp fa, fb;
+    for (int i = 0; i < 13; i++) fa.l[i] = a[i], fb.l[i] = b ? b[i] : 0;
+    const RFp x = rfp_load(&fa), y = rfp_load(&fb);
+    RFp r = rfp_zero();
+    int rc = 0;
+    std::vector<u32> tab(16 * ROW_REG_DW, 0);
+    switch (op) {
+        case 0: r = rfp_add(x, y, K); break;
+        case 1: r = rfp_sub(x, y, K); break;
+        case 2: r = rfp_neg(x, K); break;
+        case 3: r = rfp_mul(x, y, K); break;
+        case 4: r = rfp_sqr(x, K); break;
+        case 5: r = rfp_canon(x, K); break;
+        case 6: r = rfp_sub_dbl(x, y, K); break;
+        case 7: r = rfp_pow_pm3d4(x, tab.data(), K); break;
+        case 8: rc = rfp_is_zero(x, K) ? 1 : 0; break;
+        case 9: rc = rfp_eq(x, y, K) ? 1 : 0; break;
+        default: return -2;
+    }
+    for (int i = 0; i < 16; i++) {
+        out[i] = r.v.v[i];
+        if (r.v.v[16 + i] != r.v.v[i]) return -3;  // both simulated rows ran the same computation
+    }
+    return g_ecg_column_overflows ? -1 : rc;
+}
+
 void hs_hash_to_g2(const u8* msg, u64 len, u8* xy, int* inf) {
     A2 h;
     hash_to_g2(h, msg, (size_t)len);

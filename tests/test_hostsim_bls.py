@@ -143,6 +143,65 @@ def test_row_machine_sum_of_products_equals_the_one_lane_sum():
             assert sum(x << (30 * i) for i, x in enumerate(limbs[:13])) == want, (n, trial)
 
 
+def _rowfield(op, a, b=None):
+    """one Fp operation of csrc/bls_rowfield.h on the host's lane vectors: raw limbs in, (rc, limbs) out"""
+    arr = ctypes.c_uint32 * 13
+    out = (ctypes.c_uint32 * 16)()
+    rc = lib().hs_rowfield_op(op, arr(*a), arr(*b) if b is not None else None, out)
+    assert rc >= 0, rc
+    return rc, [int(x) for x in out]
+
+
+def test_row_field_operations_against_integers():
+    """bls_rowfield.h: Fp with one limb per lane of a 16-lane row -- additions / subtractions / negations (signed limbs resolved in
+    two biased passes, comparisons by the sign of the top limb of an exactly carried difference), products, the exponentiation
+    chain, canonical forms and zero tests -- on random values, on the edges of [0, 2p] and on lazy limb patterns (limbs == 2^30)."""
+    r = random.Random(5)
+    R = 1 << 390
+    Rinv = pow(R, -1, P)
+
+    def val(l):
+        return sum(x << (30 * i) for i, x in enumerate(l[:13]))
+
+    def lazy(v):
+        l = _limbs(v)
+        for i in range(11):
+            if l[i] == 0 and l[i + 1] > 0 and r.random() < 0.9:
+                l[i], l[i + 1] = 1 << 30, l[i + 1] - 1
+        return l
+
+    edge = [0, 1, 2, P - 1, P, P + 1, 2 * P - 1, 2 * P, (1 << 360) - 1, 1 << 360, (1 << 360) + 1, P - (1 << 330), P + (1 << 30),
+            sum(0x3FFFFFFF << (30 * i) for i in range(12)), sum(0x3FFFFFFF << (30 * i) for i in range(12)) + (1 << 360)]
+    edge = [v for v in edge if v <= 2 * P]
+    vals = edge + [r.randrange(2 * P) for _ in range(25)]
+    for a in vals:
+        for rep in (_limbs, lazy):
+            al = rep(a)
+            rc, c = _rowfield(5, al)                           # canon
+            assert val(c) == a % P and all(x < (1 << 30) for x in c[:12]) and c[13:] == [0, 0, 0]
+            assert _rowfield(8, al)[0] == int(a % P == 0)      # is_zero
+            _, n = _rowfield(2, al)                            # neg
+            assert val(n) <= 2 * P and val(n) % P == (-a) % P
+            _, q = _rowfield(4, al)                            # sqr
+            assert val(q) < 2 * P and val(q) % P == a * a * Rinv % P
+            for b in r.sample(vals, 6) + [a, (2 * P - a) % (2 * P + 1)]:
+                bl = rep(b)
+                _, s_ = _rowfield(0, al, bl)
+                assert val(s_) < 2 * P + 1 and val(s_) % P == (a + b) % P
+                _, d = _rowfield(1, al, bl)
+                assert val(d) < 2 * P + 1 and val(d) % P == (a - b) % P
+                _, m = _rowfield(3, al, bl)
+                assert val(m) < 2 * P and val(m) % P == a * b * Rinv % P
+                assert _rowfield(9, al, bl)[0] == int((a - b) % P == 0)
+                if a < 2 * P and b < 2 * P:
+                    _, sd = _rowfield(6, al, bl)
+                    assert val(sd) < 2 * P + 1 and val(sd) % P == (a - 2 * b) % P
+    for a in [r.randrange(2 * P) for _ in range(4)] + [1, P - 1]:   # a^((p-3)/4) on Montgomery residues: (aR)^e R^(1-e)
+        _, w = _rowfield(7, _limbs(a))
+        e = (P - 3) // 4
+        assert val(w) % P == pow(a * Rinv % P, e, P) * R % P
+
+
 def _lin_raw(op, a, b=None):
     arr = ctypes.c_uint32 * 13
     out = arr()
@@ -355,6 +414,9 @@ def test_expand_message_and_hash_to_g2():
         xy3 = ctypes.create_string_buffer(192)  # ... whose second half runs on a lane PAIR (k_h2c_finish2, bls_g2_pair2.h)
         L.hs_hash_to_g2_pair2(msg, len(msg), xy3, ctypes.byref(inf))
         assert xy3.raw == xy.raw and inf.value == 0
+        xy4 = ctypes.create_string_buffer(192)  # ... or on a 16-lane ROW, limb per lane (k_h2c_finish_row, bls_rowcurve.h)
+        L.hs_hash_to_g2_row(msg, len(msg), xy4, ctypes.byref(inf))
+        assert xy4.raw == xy.raw and inf.value == 0
     # crypto/bls.rs:530-544 test_can_sign through the lane programs: [sk] H(msg) compressed
     xy = ctypes.create_string_buffer(192)
     inf = ctypes.c_int(0)

@@ -47,7 +47,7 @@ def run(n):
         dt = time.time() - t0
         bad = int((d_st != 0).sum().item())
         line = f"  verify iter {it}: {1e3*dt:.1f} ms  -> {n/dt:.0f} sigs/s, bad={bad}"
-        for tag in ("bls_pk_validate", "bls_sig", "bls_h2c", "bls_pairing", "bls_vm_a", "bls_vm_inv", "bls_vm_c", "bls_vm3_a", "bls_vm3_inv", "bls_vm3_c"):
+        for tag in ("bls_pk_validate", "bls_sig", "bls_h2c", "bls_pairing", "bls_vm3_a", "bls_vm3_inv", "bls_vm3_c", "bls_row_a", "bls_row_inv", "bls_row_c"):
             ms, cnt = _lib.prof_read(tag)
             line += f" | {tag} {ms:.1f}"
         print(line, flush=True)
