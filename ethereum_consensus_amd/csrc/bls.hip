@@ -486,6 +486,10 @@ static const int g_h2c_finish_lanes = [] {  // (round 5 default: 16 = a row per 
     const char* e = getenv("ECGPU_H2C_FINISH_LANES");
     return e ? atoi(e) : 16;
 }();
+static const int g_row_stages = [] {  // ECGPU_ROW_STAGES=0: the SSWU maps and the signature's subgroup check stay on one lane each
+    const char* e = getenv("ECGPU_ROW_STAGES");
+    return e ? atoi(e) : 1;
+}();
 static const u32 g_h2c_row_max = [] {
     const char* e = getenv("ECGPU_H2C_ROW_MAX");
     return e ? (u32)strtoul(e, nullptr, 10) : 4096u;
@@ -595,8 +599,16 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     // (Up to 131 071 most SIMDs still hold ONE wave, which the full-file build runs faster -- but the full-file build then
     // needs a second round for the rest: 70 000 tuples 4.7 + 11.3 ms against 4.2 + 9.8, profiles/r04y_ragged_*.)
     const bool two_waves = g_tower.load() != 2 && (g_g2_waves == 2 || (g_g2_waves == 0 && n > 65536u) || overlap_sides);
+    // (round 5) small batches: the decoding on one lane per signature, the psi subgroup check -- a 63-doubling chain -- with one
+    // signature per 16-lane ROW (bls_rowcurve.h); likewise the two SSWU maps of a message on a row each
+    const bool rows = g_row_stages && n <= g_h2c_row_max;
     auto run_sig = [&] {
         ProfScope ps("bls_sig", s3);
+        if (rows) {
+            hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_decode_calls : k_sig_decode, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts, st_dec);
+            launch_sig_group_row(s3, (const A2*)sigpts, (const u8*)st_dec, n, st_grp);
+            return;
+        }
         hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : two_waves ? k_sig_w2 : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts,
                            st_dec, st_grp);
     };
@@ -604,7 +616,8 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         ProfScope ps("bls_h2c", s2);
         const bool calls = g_tower.load() == 2;
         if (h2c_maps) {  // two lanes per message while that still leaves SIMDs idle
-            hipLaunchKernelGGL(calls ? k_h2c_map_calls : k_h2c_map, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, h2c_maps);
+            if (rows) launch_h2c_map_row(s2, d_msgs, d_msg_off, n, h2c_maps);
+            else hipLaunchKernelGGL(calls ? k_h2c_map_calls : k_h2c_map, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, d_msgs, d_msg_off, n, h2c_maps);
             // ... and its end -- the addition of the two maps, the cofactor clearing, the affine conversion: a 3.5 ms chain on
             // one lane -- on a lane PAIR (bls_g2_pair2.h): half the Fp2 components, 0.57 of the instructions, per lane
             // (round 5) ... or on a ROW of 16 lanes, limb per lane (bls_rowcurve.h: 0.57 of the instructions per lane became

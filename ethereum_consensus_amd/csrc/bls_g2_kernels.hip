@@ -23,6 +23,16 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig)(const 
     st_grp[i] = sg;
 }
 
+// the decoding alone (small batches: the subgroup check then runs on rows, bls_row_g2.hip k_sig_group_row)
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig_decode)(const u8* sigs96, u32 n, A2* pts, u8* st_dec) {
+    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    A2 p;
+    const u8 sd = (u8)g2_decompress(p, sigs96 + 96 * (size_t)i);
+    pts[i] = p;
+    st_dec[i] = sd;
+}
+
 // msg_off == nullptr: message i = msgs + 32 i (32 bytes)
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c)(const u8* msgs, const u64* msg_off, u32 n, A2* hpts) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;

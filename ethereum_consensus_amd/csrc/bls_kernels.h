@@ -38,6 +38,10 @@ __global__ void k_h2c_calls(const u8* msgs, const u64* msg_off, u32 n, A2* hpts)
 
 // bls_row_g2.hip: side stages of a small batch with one point per 16-lane row
 void launch_h2c_finish_row(hipStream_t s, const J2* maps, u32 n, A2* hpts);
+void launch_h2c_map_row(hipStream_t s, const u8* msgs, const u64* msg_off, u32 n, J2* maps);
+void launch_sig_group_row(hipStream_t s, const A2* pts, const u8* st_dec, u32 n, u8* st_grp);
+__global__ void k_sig_decode(const u8* sigs96, u32 n, A2* pts, u8* st_dec);  // bls_g2_kernels.hip: Signature::try_from alone
+__global__ void k_sig_decode_calls(const u8* sigs96, u32 n, A2* pts, u8* st_dec);
 
 // bls_pairing_kernels.hip
 __global__ void k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,

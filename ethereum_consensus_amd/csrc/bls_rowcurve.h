@@ -5,6 +5,7 @@
 // (/root/reference/ethereum-consensus/src/crypto/bls.rs:71,126).
 #pragma once
 #include "bls_rowfield.h"
+#include "bls_h2c.h"
 
 namespace ecg {
 
@@ -72,6 +73,176 @@ ROW_FN RFp2 rfp2_inv(const RFp2& a, u32* tab) {
     const RFp ni = rfp_mul(t, n, K);
     return RFp2{rfp_mul(a.c0, ni, K), rfp_mul(rfp_neg(a.c1, K), ni, K)};
 }
+// a value every lane of the row holds in full (computed by the one-lane routines, the same in all lanes) -> limb per lane
+ROW_FN RFp rfp_of(const Fp& x) {
+#if defined(__HIPCC__)
+    const u32 l = threadIdx.x & 15u;
+    u32 v = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) v = l == (u32)i ? x.l[i] : v;
+    return RFp{v};
+#else
+    return RFp{row_const_limb(x.l)};
+#endif
+}
+ROW_FN RFp2 rfp2_of(const Fp2& x) { return RFp2{rfp_of(x.c0), rfp_of(x.c1)}; }
+
+// ---- square roots, signs ------------------------------------------------------------------------------------------------------
+// s with s^2 == a (true) for a square; s = a^((p+1)/4) either way (fp_sqrt)
+ROW_FN bool rfp_sqrt(const RFp& a, RFp& s, u32* tab, const RowK& K) {
+    s = rfp_mul(rfp_pow_pm3d4(a, tab, K), a, K);
+    return rfp_eq(rfp_sqr(s, K), a, K);
+}
+// fp2_sqrt_with_norm_root (bls_fp.h): s^2 = norm(a), a1 != 0; ONE exponentiation
+ROW_FN bool rfp2_sqrt_with_norm_root(const RFp2& a, const RFp& s, RFp2& r, u32* tab, const RowK& K) {
+    const RFp inv2 = rfp_const(blsc::INV2);
+    const RFp d = rfp_mul(rfp_add(a.c0, s, K), inv2, K);
+    const RFp t = rfp_pow_pm3d4(d, tab, K);
+    const RFp c = rfp_mul(t, d, K);
+    const RFp ha1t = rfp_mul(rfp_mul(a.c1, inv2, K), t, K);
+    const bool first = rfp_eq(rfp_sqr(c, K), d, K);
+    r.c0 = first ? c : rfp_neg(ha1t, K);
+    r.c1 = first ? ha1t : c;
+    return f_eq(f_sqr(r), a);
+}
+// fp2_sqrt (bls_fp.h): any root; true iff a is a square
+ROW_FN bool rfp2_sqrt(const RFp2& a, RFp2& r, u32* tab, const RowK& K) {
+    if (rfp_is_zero(a.c1, K)) {
+        RFp s;
+        if (rfp_sqrt(a.c0, s, tab, K)) {
+            r = RFp2{s, rfp_zero()};
+            return true;
+        }
+        const bool ok = rfp_sqrt(rfp_neg(a.c0, K), s, tab, K);
+        r = RFp2{rfp_zero(), s};
+        return ok;
+    }
+    rv32 bv[2][13];
+    rfp_spread(bv[0], a.c0);
+    rfp_spread(bv[1], a.c1);
+    const rv32 sq[2] = {a.c0.v, a.c1.v};
+    const RFp n{row_sumprod<2>(sq, bv, K.p)};
+    RFp s;
+    if (!rfp_sqrt(n, s, tab, K)) return false;
+    return rfp2_sqrt_with_norm_root(a, s, r, tab, K);
+}
+// the canonical integer (out of Montgomery form): limbs exact, in [0, p)
+ROW_FN RFp rfp_to_raw(const RFp& a, const RowK& K) {
+    const RFp one_raw{rv_eq(K.lane, rv_splat(0))};  // the integer 1: limb 0 = 1
+    return rfp_canon(rfp_mul(a, one_raw, K), K);
+}
+// RFC 9380 sgn0 (m = 2)
+ROW_FN u32 rfp2_sgn0(const RFp2& a, const RowK& K) {
+    const RFp r0 = rfp_to_raw(a.c0, K), r1 = rfp_to_raw(a.c1, K);
+    const bool z0 = !rv_test(rv_row_any(r0.v));
+    const u32 b0 = rv_test(rv_and(rv_bcast<0>(r0.v), rv_splat(1))) ? 1u : 0u, b1 = rv_test(rv_and(rv_bcast<0>(r1.v), rv_splat(1))) ? 1u : 0u;
+    return b0 | ((z0 ? 1u : 0u) & b1);
+}
+// raw > (p - 1) / 2 (the ZCash sign of an Fp)
+ROW_FN bool rfp_lex_largest(const RFp& a, const RowK& K) {
+    const RFp raw = rfp_to_raw(a, K);
+    const rv32 half = row_const_limb(blsc::HALF_P);
+    // half - raw < 0  <=>  raw > half: signed limbs, exact carries, sign of the top limb
+    rv64 t = rv_mad64s(rv_splat(1), half, rv_zero64());
+    t = rv_mad64s(rv_splat((u32)-1), raw.v, t);
+    return rv_test(rv_shr(rv_bcast<12>(r_norm_signed(t, K)), 31));
+}
+ROW_FN bool rfp2_lex_largest(const RFp2& a, const RowK& K) {
+    if (!rfp_is_zero(a.c1, K)) return rfp_lex_largest(a.c1, K);
+    return rfp_lex_largest(a.c0, K);
+}
+
+// ---- the SSWU map and the 3-isogeny on a row (map_to_curve_g2 of bls_h2c.h, step by step) -------------------------------------
+ROW_FN RFp2 rfp2_horner(const Fp2* c, int deg, const RFp2& x) {
+    RFp2 acc = rfp2_const(c[deg]);
+    for (int i = deg - 1; i >= 0; i--) acc = f_add(f_mul(acc, x), rfp2_const(c[i]));
+    return acc;
+}
+ROW_FN RFp rfp_norm(const RFp2& a, const RowK& K) {
+    rv32 bv[2][13];
+    rfp_spread(bv[0], a.c0);
+    rfp_spread(bv[1], a.c1);
+    const rv32 sq[2] = {a.c0.v, a.c1.v};
+    return RFp{row_sumprod<2>(sq, bv, K.p)};
+}
+// u, 1 / tv2(u) and sgn0(u) come from the one-lane prologue (every lane of the row computed them in full)
+ROW_FN void r_map_to_curve_g2(RJ2& r, const RFp2& u, const RFp2& tv2_inv, bool tv2_zero, u32 sgn_u, u32* tab) {
+    const RowK K = row_k();
+    const RFp2 tv1 = f_mul(rfp2_const(blsc::SSWU_Z), f_sqr(u));
+    RFp2 x1;
+    if (tv2_zero) {
+        x1 = rfp2_const(blsc::SSWU_B_OVER_ZA);
+    } else {
+        RFp2 one;
+        f_set_one(one);
+        x1 = f_mul(rfp2_const(blsc::SSWU_MB_OVER_A), f_add(one, tv2_inv));
+    }
+    const RFp2 A = rfp2_const(blsc::SSWU_A), B = rfp2_const(blsc::SSWU_B);
+    const RFp2 gx1 = f_add(f_add(f_mul(f_sqr(x1), x1), f_mul(A, x1)), B);
+    const RFp2 x2 = f_mul(tv1, x1);
+    const RFp2 gx2 = f_add(f_add(f_mul(f_sqr(x2), x2), f_mul(A, x2)), B);
+    const RFp n1 = rfp_norm(gx1, K);
+    RFp sn;
+    const bool sq1 = rfp_sqrt(n1, sn, tab, K);
+    if (!sq1) {
+        const RFp m = rfp_norm(tv1, K);
+        const RFp v = rfp_mul(rfp_const(blsc::SQRT_M5), rfp_norm(u, K), K);
+        sn = rfp_mul(rfp_mul(m, sn, K), v, K);
+    }
+    RFp2 x = sq1 ? x1 : x2, y;
+    const RFp2 g = sq1 ? gx1 : gx2;
+    bool ok = !rfp_is_zero(g.c1, K) && rfp2_sqrt_with_norm_root(g, sn, y, tab, K);
+    if (!ok) {
+        x = x1;
+        if (!rfp2_sqrt(gx1, y, tab, K)) {
+            x = x2;
+            (void)rfp2_sqrt(gx2, y, tab, K);
+        }
+    }
+    if (sgn_u != rfp2_sgn0(y, K)) y = f_neg(y);
+    const RFp2 xn = rfp2_horner(blsc::ISO_XNUM, 3, x), xd = rfp2_horner(blsc::ISO_XDEN, 2, x);
+    const RFp2 yn = rfp2_horner(blsc::ISO_YNUM, 3, x), yd = rfp2_horner(blsc::ISO_YDEN, 3, x);
+    if (f_is_zero(xd) || f_is_zero(yd)) {
+        jac_set_inf(r);
+        return;
+    }
+    const RFp2 yd2 = f_sqr(yd);
+    r.x = f_mul(f_mul(xn, xd), yd2);
+    r.y = f_mul(f_mul(f_mul(y, yn), f_mul(f_sqr(xd), xd)), yd2);
+    r.z = f_mul(xd, yd);
+}
+// one map of one message: the one-lane prologue (expand_message_xmd, the field element, 1 / tv2: every lane of the row computes
+// them in full, which costs a lone wave nothing) and the map on the row; the point goes to memory with exact limbs
+ROW_FN void r_hash_to_g2_map(J2* out, const u8* msg, size_t msg_len, int j, u32* tab) {
+    Fp2 u0, u1;
+    hash_to_field2(u0, u1, msg, msg_len);
+    const Fp2 u = j ? u1 : u0;
+    Fp2 t = sswu_tv2(u);
+    const bool tz = fp2_is_zero(t);
+    if (tz) t = fp2_one();
+    const Fp2 ti = fp2_inv(t);
+    RJ2 q;
+    r_map_to_curve_g2(q, rfp2_of(u), rfp2_of(ti), tz, fp2_sgn0(u), tab);
+    rfp_store(&out->x.c0, q.x.c0);
+    rfp_store(&out->x.c1, q.x.c1);
+    rfp_store(&out->y.c0, q.y.c0);
+    rfp_store(&out->y.c1, q.y.c1);
+    rfp_store(&out->z.c0, q.z.c0);
+    rfp_store(&out->z.c1, q.z.c1);
+}
+
+// the psi subgroup check of a decoded signature on a row (g2_in_subgroup of bls_curve.h): psi(Q) == [x] Q
+ROW_FN bool r_g2_in_subgroup(const A2* q) {
+    if (q->inf) return true;
+    Aff<RFp2> a{rfp2_load(&q->x), rfp2_load(&q->y), 0u};
+    RJ2 Q, t, ps;
+    jac_from_aff(Q, a);
+    jac_mul_xabs_aff(t, a);
+    jac_neg(t, t);
+    r_g2_psi(ps, Q);
+    return jac_eq(ps, t);
+}
+
 // q0 + q1, cofactor, affine: the row's H(m) to memory (pointers uniform over the row)
 ROW_FN void r_hash_to_g2_finish(A2* out, const J2* q0, const J2* q1, u32* tab) {
     RJ2 a{rfp2_load(&q0->x), rfp2_load(&q0->y), rfp2_load(&q0->z)};

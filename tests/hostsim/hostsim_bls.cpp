@@ -259,18 +259,50 @@ void hs_hash_to_g2_pair2(const u8* msg, u64 len, u8* xy, int* inf) {
 }
 // the end of the message stage on a ROW (bls_rowcurve.h, k_h2c_finish_row): the two maps on one lane each, then the addition,
 // the cofactor clearing and the affine conversion with one point per 16-lane row -- the same routines on the host's lane vectors
-void hs_hash_to_g2_row(const u8* msg, u64 len, u8* xy, int* inf) {
+// which: 0 = only the end on a row (the two maps by the one-lane routines), 1 = the SSWU maps on rows as well (k_h2c_map_row)
+void hs_hash_to_g2_row(const u8* msg, u64 len, u8* xy, int* inf, int which) {
     g_ecg_column_overflows = 0;
     J2 q0, q1;
-    hash_to_g2_map(q0, msg, (size_t)len, 0);
-    hash_to_g2_map(q1, msg, (size_t)len, 1);
     std::vector<u32> tab(16 * ROW_REG_DW, 0);
+    if (which) {
+        r_hash_to_g2_map(&q0, msg, (size_t)len, 0, tab.data());
+        r_hash_to_g2_map(&q1, msg, (size_t)len, 1, tab.data());
+    } else {
+        hash_to_g2_map(q0, msg, (size_t)len, 0);
+        hash_to_g2_map(q1, msg, (size_t)len, 1);
+    }
     A2 h;
     std::memset(&h, 0, sizeof(h));
     r_hash_to_g2_finish(&h, &q0, &q1, tab.data());
     out_a2(h, xy);
     *inf = g_ecg_column_overflows ? -1 : (int)h.inf;
 }
+// the psi subgroup check of a decoded signature on a row (k_sig_group_row): 1 in G2, 0 not; affine point canonical big-endian
+int hs_g2_in_subgroup_row(const u8* xy) {
+    g_ecg_column_overflows = 0;
+    const A2 q = in_a2(xy, 0);
+    const int r = r_g2_in_subgroup(&q) ? 1 : 0;
+    return g_ecg_column_overflows ? -1 : r;
+}
+// Fp2 square root / signs on a row against the one-lane routines: out = root (canonical big-endian c0 | c1); returns
+// is_square | sgn0(a) << 1 | lex_largest(a) << 2
+int hs_rowfield_sqrt(const u8* a96, u8* out96) {
+    g_ecg_column_overflows = 0;
+    const Fp2 a = in_fp2(a96);
+    const RowK K = row_k();
+    std::vector<u32> tab(16 * ROW_REG_DW, 0);
+    const RFp2 ra = rfp2_load(&a);
+    RFp2 r;
+    f_set_zero(r);
+    const bool sq = rfp2_sqrt(ra, r, tab.data(), K);
+    Fp2 o;
+    rfp_store(&o.c0, r.c0);
+    rfp_store(&o.c1, r.c1);
+    out_fp2(o, out96);
+    if (g_ecg_column_overflows) return -1;
+    return (sq ? 1 : 0) | (int)(rfp2_sgn0(ra, K) << 1) | (rfp2_lex_largest(ra, K) ? 4 : 0);
+}
+
 // row field operations on raw limbs (13 x u32 in, 13 out): 0 add 1 sub 2 neg 3 mul 4 sqr 5 canon 6 sub_dbl 7 pow_pm3d4 8 is_zero 9 eq
 int hs_rowfield_op(int op, const u32* a, const u32* b, u32* out) {
     g_ecg_column_overflows = 0;

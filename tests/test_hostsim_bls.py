@@ -202,6 +202,37 @@ def test_row_field_operations_against_integers():
         assert val(w) % P == pow(a * Rinv % P, e, P) * R % P
 
 
+def test_row_field_square_roots_signs_and_the_subgroup_check():
+    """bls_rowcurve.h: fp2_sqrt / sgn0 / the ZCash sign on a row against integers, and the psi subgroup check of a decoded
+    signature (k_sig_group_row) on points inside and outside G2 -- including the real-only and imaginary-only roots."""
+    r = random.Random(31)
+    L = lib()
+    out = ctypes.create_string_buffer(96)
+    cases = [(r.randrange(P), r.randrange(P)) for _ in range(12)]
+    cases += [(r.randrange(P), 0) for _ in range(4)] + [(0, r.randrange(P)) for _ in range(2)] + [(0, 0), (1, 0), (P - 1, 0), (0, 1)]
+    cases += [B.f2_sqr((r.randrange(P), r.randrange(P))) for _ in range(8)]  # squares for sure
+    for a in cases:
+        rc = L.hs_rowfield_sqrt(b48(a[0]) + b48(a[1]), out)
+        assert rc >= 0
+        root = (int.from_bytes(out.raw[:48], "big"), int.from_bytes(out.raw[48:], "big"))
+        is_sq = B.f2_sqrt(a) is not None
+        assert (rc & 1) == int(is_sq), a
+        if is_sq:
+            assert B.f2_sqr(root) == (a[0] % P, a[1] % P)
+        sgn0 = (a[0] & 1) | (int(a[0] == 0) & (a[1] & 1))
+        assert (rc >> 1) & 1 == sgn0
+        lex = (a[1] > (P - 1) // 2) if a[1] != 0 else (a[0] > (P - 1) // 2)
+        assert (rc >> 2) & 1 == int(lex)
+    L.hs_g2_in_subgroup_row.restype = ctypes.c_int
+    for k in range(4):
+        Q = B.g2_mul(B.G2, r.randrange(1, B.R))
+        assert L.hs_g2_in_subgroup_row(a2(Q)) == 1
+    from tests import _blscases as C
+    for k in range(4):
+        Q = C.rand_g2_curve_point(r)  # on E2, outside G2
+        assert L.hs_g2_in_subgroup_row(a2(Q)) == 0
+
+
 def _lin_raw(op, a, b=None):
     arr = ctypes.c_uint32 * 13
     out = arr()
@@ -415,8 +446,11 @@ def test_expand_message_and_hash_to_g2():
         L.hs_hash_to_g2_pair2(msg, len(msg), xy3, ctypes.byref(inf))
         assert xy3.raw == xy.raw and inf.value == 0
         xy4 = ctypes.create_string_buffer(192)  # ... or on a 16-lane ROW, limb per lane (k_h2c_finish_row, bls_rowcurve.h)
-        L.hs_hash_to_g2_row(msg, len(msg), xy4, ctypes.byref(inf))
+        L.hs_hash_to_g2_row(msg, len(msg), xy4, ctypes.byref(inf), 0)
         assert xy4.raw == xy.raw and inf.value == 0
+        xy5 = ctypes.create_string_buffer(192)  # ... with the two SSWU maps on rows as well (k_h2c_map_row)
+        L.hs_hash_to_g2_row(msg, len(msg), xy5, ctypes.byref(inf), 1)
+        assert xy5.raw == xy.raw and inf.value == 0
     # crypto/bls.rs:530-544 test_can_sign through the lane programs: [sk] H(msg) compressed
     xy = ctypes.create_string_buffer(192)
     inf = ctypes.c_int(0)
