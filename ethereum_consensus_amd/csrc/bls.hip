@@ -492,7 +492,7 @@ static const int g_row_stages = [] {  // ECGPU_ROW_STAGES=0: the SSWU maps and t
 }();
 static const u32 g_h2c_row_max = [] {
     const char* e = getenv("ECGPU_H2C_ROW_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : 4096u;
+    return e ? (u32)strtoul(e, nullptr, 10) : 1024u;  // (4 096 messages on rows: 3.2 ms against the lane pair's 2.9, profiles/r05l_probe.txt)
 }();
 // Up to this many tuples the pairing check runs on the row machine (round 5, bls_row.hip: one workgroup per tuple, one Fp
 // operation per 16-lane row): a lone check 3.45 -> 1.0 ms, 1 024 tuples 3.4 -> 2.3 ms.  Its throughput is below the lane groups'
@@ -621,7 +621,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             // ... and its end -- the addition of the two maps, the cofactor clearing, the affine conversion: a 3.5 ms chain on
             // one lane -- on a lane PAIR (bls_g2_pair2.h): half the Fp2 components, 0.57 of the instructions, per lane
             // (round 5) ... or on a ROW of 16 lanes, limb per lane (bls_rowcurve.h: 0.57 of the instructions per lane became
-            // ~0.2; up to 4 096 messages that is still at most one wave per SIMD)
+            // ~0.2; for up to ECGPU_H2C_ROW_MAX messages)
             if (g_h2c_finish_lanes == 16 && n <= g_h2c_row_max)
                 launch_h2c_finish_row(s2, (const J2*)h2c_maps, n, hpts);
             else if (g_h2c_finish_lanes == 1)

