@@ -118,6 +118,49 @@ __global__ void __launch_bounds__(64) k_dep_add3(u32* out) {
     out[blockIdx.x * 64 + threadIdx.x] = a0;
 }
 
+// round 5, VERDICT item 5(a): would 52-bit limbs on the FP64 unit be cheaper than 30-bit limbs on v_mad_u64_u32?  v_fma_f64 on eight
+// independent accumulators; a product of two 52-bit limbs needs TWO of them (the high part, then the low part by an FMA with the
+// negated high part) where a product of 30-bit limbs is one v_mad_u64_u32 -- 8 x 8 x 2 = 128 FMAs against 13 x 13 = 169 multiply-adds
+// per schoolbook product, so the FMA would have to issue at least as fast as the integer multiply-add to win anything
+__global__ void __launch_bounds__(64) k_fma_f64(u32* out) {
+    double a0 = threadIdx.x + 1.0, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double b = 1.0000001 + blockIdx.x * 1e-9, c = 1e-3 * threadIdx.x;
+    for (int t = 0; t < TRIPS; t++) {
+        REP8(asm volatile("v_fma_f64 %0, %0, %8, %9\n\tv_fma_f64 %1, %1, %8, %9\n\tv_fma_f64 %2, %2, %8, %9\n\tv_fma_f64 %3, %3, %8, %9\n\t"
+                          "v_fma_f64 %4, %4, %8, %9\n\tv_fma_f64 %5, %5, %8, %9\n\tv_fma_f64 %6, %6, %8, %9\n\tv_fma_f64 %7, %7, %8, %9"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                          : "v"(b), "v"(c));)
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = (u32)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+// the cross-lane moves of the row machine (csrc/bls_row.h): a DPP row broadcast / row shift per eight, and ds_bpermute
+__global__ void __launch_bounds__(64) k_mov_dpp(u32* out) {
+    u32 a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    for (int t = 0; t < TRIPS; t++) {
+        REP8(asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                          "v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                          "v_mov_b32_dpp %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %6 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                          "v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+// the inner step of a row sum of products as a DEPENDENT chain (what one iteration of row_sumprod<1> costs a lone wave):
+// mad, broadcast of the low dword, mul_lo, and, mad, shift, and, row shift, add -- per eight "instructions" of the table: one step
+__global__ void __launch_bounds__(64) k_row_step(u32* out) {
+    u64 acc = threadIdx.x;
+    const u32 a = threadIdx.x * 2654435761u + 1u, b = blockIdx.x * 40503u + 7u, p = 0x3fffaaabu;
+    for (int t = 0; t < TRIPS * 8; t++) {  // the compiler's own sequence for one iteration of csrc/bls_row.h row_sumprod<1>
+        acc = (u64)a * b + acc;
+        const u32 m = ((u32)__builtin_amdgcn_update_dpp(0, (int)(u32)acc, 0x150, 0xf, 0xf, true) * 0x3ffcfffdu) & 0x3fffffffu;
+        acc = (u64)m * p + acc;
+        const u64 hi = acc >> 30;
+        acc = hi + (u32)__builtin_amdgcn_update_dpp(0, (int)((u32)acc & 0x3fffffffu), 0x101, 0xf, 0xf, true);
+        asm volatile("" : "+v"(acc));
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = (u32)acc;
+}
+
 struct Case {
     const char* name;
     void (*fn)(u32*);
@@ -137,7 +180,8 @@ int main() {
                           {"v_and_b32", k_and_b32},         {"v_bitop3_b32", k_bitop3_b32},   {"v_alignbit_b32", k_alignbit_b32},
                           {"v_lshrrev_b32", k_lshrrev_b32}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_perm_b32", k_perm_b32},
                           {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_lo_u32", k_mul_lo_u32},   {"v_mul_hi_u32", k_mul_hi_u32},
-                          {"v_mad_u64_u32", k_mad_u64_u32}, {"8 mad + s_nop", k_mad_u64_u32_nop}, {"sha256 round mix", k_sha_mix},  {"v_add3 dependent", k_dep_add3}};
+                          {"v_mad_u64_u32", k_mad_u64_u32}, {"8 mad + s_nop", k_mad_u64_u32_nop}, {"sha256 round mix", k_sha_mix},  {"v_add3 dependent", k_dep_add3},
+                          {"v_fma_f64", k_fma_f64},         {"v_mov_b32_dpp", k_mov_dpp},     {"row step / 8", k_row_step}};
     for (const Case& c : cases) {
         printf("%-18s", c.name);
         for (int wps = 1; wps <= 8; wps *= 2) {
