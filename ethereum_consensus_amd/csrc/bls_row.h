@@ -72,6 +72,13 @@ ROW_FN rv32 rv_row_any(rv32 x) {
     return ((m >> (threadIdx.x & 48u)) & 0xffffull) != 0 ? 1u : 0u;
 }
 ROW_FN bool rv_test(rv32 c) { return c != 0; }  // a row-uniform condition as a branch condition
+// a row PAIR (rows 2m, 2m + 1 of a wave: the two components of an Fp2 value, bls_rowpair.h): which row the lane is in, and
+// "any lane of the pair"
+ROW_FN rv32 rv_pair_row() { return (threadIdx.x >> 4) & 1u; }
+ROW_FN rv32 rv_pair_any(rv32 x) {
+    const u64 m = __builtin_amdgcn_ballot_w64(x != 0);
+    return ((m >> (threadIdx.x & 32u)) & 0xffffffffull) != 0 ? 1u : 0u;
+}
 // exact carry propagation over limbs <= 2^30: a limb == 2^30 generates, a limb == 2^30 - 1 propagates; the chain is resolved by
 // ONE 64-bit addition of the two ballots (rows end in zero limbs, which neither generate nor propagate)
 // (limbs 0 .. 11 come out < 2^30; the top limb, lane 12, takes its carry and keeps every bit -- it may be a signed dword)
@@ -151,6 +158,12 @@ ROW_FN rv32 rv_row_any(rv32 x) {
 }
 // (the host runs the SAME computation on both simulated rows wherever a condition steers control flow: lane 0 speaks for both)
 ROW_FN bool rv_test(rv32 c) { return c.v[0] != 0; }
+ROW_FN rv32 rv_pair_row() { rv32 r; ROW_EACH r.v[l_] = (l_ >> 4) & 1; return r; }
+ROW_FN rv32 rv_pair_any(rv32 x) {
+    u32 any = 0;
+    ROW_EACH any |= x.v[l_];
+    return rv_splat(any ? 1u : 0u);
+}
 ROW_FN rv32 rv_carry_exact(rv32 v) {
     rv32 r;
     for (int row = 0; row < ROW_SIM; row += 16) {

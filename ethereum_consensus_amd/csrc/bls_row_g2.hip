@@ -5,11 +5,12 @@
 
 namespace ecg {
 
+// a ROW PAIR per message (bls_rowpair.h: one component of every Fp2 coordinate per row): 126 doublings of ~1 500 instructions
 __global__ void __launch_bounds__(64) k_h2c_finish_row(const J2* maps, u32 n, A2* hpts) {
     __shared__ __attribute__((aligned(16))) u32 tab[4][16 * ROW_REG_DW];
-    const u32 row = threadIdx.x >> 4, i = blockIdx.x * 4 + row;
+    const u32 row = threadIdx.x >> 4, i = blockIdx.x * 2 + (row >> 1);
     if (i >= n) return;
-    r_hash_to_g2_finish(&hpts[i], &maps[2 * (size_t)i], &maps[2 * (size_t)i + 1], tab[row]);
+    r_hash_to_g2_finish<RP2>(&hpts[i], &maps[2 * (size_t)i], &maps[2 * (size_t)i + 1], tab[row]);
 }
 
 // row t = map (t & 1) of message t >> 1: expand_message_xmd + field element + 1 / tv2 by the one-lane routines in every lane, the
@@ -25,21 +26,21 @@ __global__ void __launch_bounds__(64) k_h2c_map_row(const u8* msgs, const u64* m
 }
 // row t = signature t, already decoded (k_sig_decode): the psi subgroup check of verify (crypto/bls.rs:71,126)
 __global__ void __launch_bounds__(64) k_sig_group_row(const A2* pts, const u8* st_dec, u32 n, u8* st_grp) {
-    const u32 row = threadIdx.x >> 4, i = blockIdx.x * 4 + row;
+    const u32 row = threadIdx.x >> 4, i = blockIdx.x * 2 + (row >> 1);  // a row pair per signature
     if (i >= n) return;
     u8 g = 0;
-    if (st_dec[i] == 0 && !r_g2_in_subgroup(&pts[i])) g = ECGPU_POINT_NOT_IN_GROUP;
-    if ((threadIdx.x & 15u) == 0) st_grp[i] = g;
+    if (st_dec[i] == 0 && !r_g2_in_subgroup<RP2>(&pts[i])) g = ECGPU_POINT_NOT_IN_GROUP;
+    if ((threadIdx.x & 31u) == 0) st_grp[i] = g;
 }
 
 void launch_h2c_map_row(hipStream_t s, const u8* msgs, const u64* msg_off, u32 n, J2* maps) {
     hipLaunchKernelGGL(k_h2c_map_row, dim3((2 * n + 3) / 4), dim3(64), 0, s, msgs, msg_off, n, maps);
 }
 void launch_sig_group_row(hipStream_t s, const A2* pts, const u8* st_dec, u32 n, u8* st_grp) {
-    hipLaunchKernelGGL(k_sig_group_row, dim3((n + 3) / 4), dim3(64), 0, s, pts, st_dec, n, st_grp);
+    hipLaunchKernelGGL(k_sig_group_row, dim3((n + 1) / 2), dim3(64), 0, s, pts, st_dec, n, st_grp);
 }
 void launch_h2c_finish_row(hipStream_t s, const J2* maps, u32 n, A2* hpts) {
-    hipLaunchKernelGGL(k_h2c_finish_row, dim3((n + 3) / 4), dim3(64), 0, s, maps, n, hpts);
+    hipLaunchKernelGGL(k_h2c_finish_row, dim3((n + 1) / 2), dim3(64), 0, s, maps, n, hpts);
 }
 
 }  // namespace ecg

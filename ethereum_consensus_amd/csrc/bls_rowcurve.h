@@ -4,12 +4,13 @@
 // as a kernel for small batches.  hash_to_curve is what blst performs inside every verify call
 // (/root/reference/ethereum-consensus/src/crypto/bls.rs:71,126).
 #pragma once
-#include "bls_rowfield.h"
+#include "bls_rowpair.h"
 #include "bls_h2c.h"
 
 namespace ecg {
 
 typedef Jac<RFp2> RJ2;
+typedef Jac<RP2> PJ2;
 
 // memory <-> row: limb j of a 13-limb image goes to lane j (the pointer is the same for every lane of the row)
 ROW_FN RFp rfp_load(const Fp* src) {
@@ -32,16 +33,18 @@ ROW_FN void rfp_store(Fp* dst, const RFp& a) {  // exact limbs of the representa
 #endif
 }
 
-// psi(x, y, z) = (conj(x) PSI_X, conj(y) PSI_Y, conj(z))
-ROW_FN void r_g2_psi(RJ2& r, const RJ2& p) {
-    r.x = f_mul(rfp2_conj(p.x), rfp2_const(blsc::PSI_X));
-    r.y = f_mul(rfp2_conj(p.y), rfp2_const(blsc::PSI_Y));
-    r.z = rfp2_conj(p.z);
+// psi(x, y, z) = (conj(x) PSI_X, conj(y) PSI_Y, conj(z)); F = RFp2 (a point per row) or RP2 (a point per row pair)
+template <class F>
+ROW_FN void r_g2_psi(Jac<F>& r, const Jac<F>& p) {
+    r.x = f_mul(f_conj(p.x), f_const2((const F*)nullptr, blsc::PSI_X));
+    r.y = f_mul(f_conj(p.y), f_const2((const F*)nullptr, blsc::PSI_Y));
+    r.z = f_conj(p.z);
 }
 // [x^2 - x - 1] P + [x - 1] psi(P) + psi^2(2P), term by term as g2_clear_cofactor (bls_h2c.h)
-ECG_HD_NOINLINE void r_g2_clear_cofactor(RJ2& r, const RJ2& p_in) {
-    const RJ2 p = p_in;
-    RJ2 t1, t2, t3, n;
+template <class F>
+ECG_HD_NOINLINE void r_g2_clear_cofactor(Jac<F>& r, const Jac<F>& p_in) {
+    const Jac<F> p = p_in;
+    Jac<F> t1, t2, t3, n;
     jac_mul_xabs(t1, p);
     jac_neg(t1, t1);  // [x] P
     r_g2_psi(t2, p);  // psi(P)
@@ -73,6 +76,20 @@ ROW_FN RFp2 rfp2_inv(const RFp2& a, u32* tab) {
     const RFp ni = rfp_mul(t, n, K);
     return RFp2{rfp_mul(a.c0, ni, K), rfp_mul(rfp_neg(a.c1, K), ni, K)};
 }
+ROW_FN RFp2 f_inv_tab(const RFp2& a, u32* tab) { return rfp2_inv(a, tab); }
+ROW_FN RFp2 f_load2(const RFp2*, const Fp2* src) { return rfp2_load(src); }
+ROW_FN void f_store2(Fp2* dst, const RFp2& a) {
+    rfp_store(&dst->c0, a.c0);
+    rfp_store(&dst->c1, a.c1);
+}
+ROW_FN bool f_first_lane(const RFp2*) {
+#if defined(__HIPCC__)
+    return (threadIdx.x & 15u) == 0;
+#else
+    return true;
+#endif
+}
+
 // a value every lane of the row holds in full (computed by the one-lane routines, the same in all lanes) -> limb per lane
 ROW_FN RFp rfp_of(const Fp& x) {
 #if defined(__HIPCC__)
@@ -231,11 +248,12 @@ ROW_FN void r_hash_to_g2_map(J2* out, const u8* msg, size_t msg_len, int j, u32*
     rfp_store(&out->z.c1, q.z.c1);
 }
 
-// the psi subgroup check of a decoded signature on a row (g2_in_subgroup of bls_curve.h): psi(Q) == [x] Q
+// the psi subgroup check of a decoded signature (g2_in_subgroup of bls_curve.h): psi(Q) == [x] Q
+template <class F>
 ROW_FN bool r_g2_in_subgroup(const A2* q) {
     if (q->inf) return true;
-    Aff<RFp2> a{rfp2_load(&q->x), rfp2_load(&q->y), 0u};
-    RJ2 Q, t, ps;
+    Aff<F> a{f_load2((const F*)nullptr, &q->x), f_load2((const F*)nullptr, &q->y), 0u};
+    Jac<F> Q, t, ps;
     jac_from_aff(Q, a);
     jac_mul_xabs_aff(t, a);
     jac_neg(t, t);
@@ -243,31 +261,27 @@ ROW_FN bool r_g2_in_subgroup(const A2* q) {
     return jac_eq(ps, t);
 }
 
-// q0 + q1, cofactor, affine: the row's H(m) to memory (pointers uniform over the row)
+// q0 + q1, cofactor, affine: H(m) to memory (pointers uniform over the row / the row pair)
+template <class F>
 ROW_FN void r_hash_to_g2_finish(A2* out, const J2* q0, const J2* q1, u32* tab) {
-    RJ2 a{rfp2_load(&q0->x), rfp2_load(&q0->y), rfp2_load(&q0->z)};
-    const RJ2 b{rfp2_load(&q1->x), rfp2_load(&q1->y), rfp2_load(&q1->z)};
+    const F* tag = nullptr;
+    Jac<F> a{f_load2(tag, &q0->x), f_load2(tag, &q0->y), f_load2(tag, &q0->z)};
+    const Jac<F> b{f_load2(tag, &q1->x), f_load2(tag, &q1->y), f_load2(tag, &q1->z)};
     jac_add(a, a, b);
     r_g2_clear_cofactor(a, a);
     const bool inf = jac_is_inf(a);
-    RFp2 x, y;
+    F x, y;
     f_set_zero(x);
     f_set_zero(y);
     if (!inf) {
-        const RFp2 zi = rfp2_inv(a.z, tab);
-        const RFp2 zi2 = f_sqr(zi);
+        const F zi = f_inv_tab(a.z, tab);
+        const F zi2 = f_sqr(zi);
         x = f_mul(a.x, zi2);
         y = f_mul(f_mul(a.y, zi2), zi);
     }
-    rfp_store(&out->x.c0, x.c0);
-    rfp_store(&out->x.c1, x.c1);
-    rfp_store(&out->y.c0, y.c0);
-    rfp_store(&out->y.c1, y.c1);
-#if defined(__HIPCC__)
-    if ((threadIdx.x & 15u) == 0) out->inf = inf ? 1u : 0u;
-#else
-    out->inf = inf ? 1u : 0u;
-#endif
+    f_store2(&out->x, x);
+    f_store2(&out->y, y);
+    if (f_first_lane(tag)) out->inf = inf ? 1u : 0u;
 }
 
 }  // namespace ecg

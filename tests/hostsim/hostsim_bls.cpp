@@ -264,7 +264,7 @@ void hs_hash_to_g2_row(const u8* msg, u64 len, u8* xy, int* inf, int which) {
     g_ecg_column_overflows = 0;
     J2 q0, q1;
     std::vector<u32> tab(16 * ROW_REG_DW, 0);
-    if (which) {
+    if (which & 1) {
         r_hash_to_g2_map(&q0, msg, (size_t)len, 0, tab.data());
         r_hash_to_g2_map(&q1, msg, (size_t)len, 1, tab.data());
     } else {
@@ -273,15 +273,16 @@ void hs_hash_to_g2_row(const u8* msg, u64 len, u8* xy, int* inf, int which) {
     }
     A2 h;
     std::memset(&h, 0, sizeof(h));
-    r_hash_to_g2_finish(&h, &q0, &q1, tab.data());
+    if (which & 2) r_hash_to_g2_finish<RP2>(&h, &q0, &q1, tab.data());  // a row PAIR per message (k_h2c_finish_row)
+    else r_hash_to_g2_finish<RFp2>(&h, &q0, &q1, tab.data());
     out_a2(h, xy);
     *inf = g_ecg_column_overflows ? -1 : (int)h.inf;
 }
 // the psi subgroup check of a decoded signature on a row (k_sig_group_row): 1 in G2, 0 not; affine point canonical big-endian
-int hs_g2_in_subgroup_row(const u8* xy) {
+int hs_g2_in_subgroup_row(const u8* xy, int pair) {
     g_ecg_column_overflows = 0;
     const A2 q = in_a2(xy, 0);
-    const int r = r_g2_in_subgroup(&q) ? 1 : 0;
+    const int r = (pair ? r_g2_in_subgroup<RP2>(&q) : r_g2_in_subgroup<RFp2>(&q)) ? 1 : 0;
     return g_ecg_column_overflows ? -1 : r;
 }
 // Fp2 square root / signs on a row against the one-lane routines: out = root (canonical big-endian c0 | c1); returns

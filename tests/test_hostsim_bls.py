@@ -226,11 +226,11 @@ def test_row_field_square_roots_signs_and_the_subgroup_check():
     L.hs_g2_in_subgroup_row.restype = ctypes.c_int
     for k in range(4):
         Q = B.g2_mul(B.G2, r.randrange(1, B.R))
-        assert L.hs_g2_in_subgroup_row(a2(Q)) == 1
+        assert L.hs_g2_in_subgroup_row(a2(Q), 0) == 1 and L.hs_g2_in_subgroup_row(a2(Q), 1) == 1
     from tests import _blscases as C
     for k in range(4):
         Q = C.rand_g2_curve_point(r)  # on E2, outside G2
-        assert L.hs_g2_in_subgroup_row(a2(Q)) == 0
+        assert L.hs_g2_in_subgroup_row(a2(Q), 0) == 0 and L.hs_g2_in_subgroup_row(a2(Q), 1) == 0
 
 
 def _lin_raw(op, a, b=None):
@@ -451,6 +451,9 @@ def test_expand_message_and_hash_to_g2():
         xy5 = ctypes.create_string_buffer(192)  # ... with the two SSWU maps on rows as well (k_h2c_map_row)
         L.hs_hash_to_g2_row(msg, len(msg), xy5, ctypes.byref(inf), 1)
         assert xy5.raw == xy.raw and inf.value == 0
+        xy6 = ctypes.create_string_buffer(192)  # ... and the end on a row PAIR, one Fp2 component per row (bls_rowpair.h)
+        L.hs_hash_to_g2_row(msg, len(msg), xy6, ctypes.byref(inf), 3)
+        assert xy6.raw == xy.raw and inf.value == 0
     # crypto/bls.rs:530-544 test_can_sign through the lane programs: [sk] H(msg) compressed
     xy = ctypes.create_string_buffer(192)
     inf = ctypes.c_int(0)
