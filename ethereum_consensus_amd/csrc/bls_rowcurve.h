@@ -12,27 +12,6 @@ namespace ecg {
 typedef Jac<RFp2> RJ2;
 typedef Jac<RP2> PJ2;
 
-// memory <-> row: limb j of a 13-limb image goes to lane j (the pointer is the same for every lane of the row)
-ROW_FN RFp rfp_load(const Fp* src) {
-#if defined(__HIPCC__)
-    const u32 l = threadIdx.x & 15u;
-    return RFp{l < 13 ? src->l[l] : 0u};
-#else
-    return RFp{row_const_limb(src->l)};
-#endif
-}
-ROW_FN RFp2 rfp2_load(const Fp2* src) { return RFp2{rfp_load(&src->c0), rfp_load(&src->c1)}; }
-ROW_FN void rfp_store(Fp* dst, const RFp& a) {  // exact limbs of the representative in [0, p)
-    const RowK K = row_k();
-    const RFp c = rfp_canon(a, K);
-#if defined(__HIPCC__)
-    const u32 l = threadIdx.x & 15u;
-    if (l < 13) dst->l[l] = c.v;
-#else
-    for (int l = 0; l < 13; l++) dst->l[l] = c.v.v[l];
-#endif
-}
-
 // psi(x, y, z) = (conj(x) PSI_X, conj(y) PSI_Y, conj(z)); F = RFp2 (a point per row) or RP2 (a point per row pair)
 template <class F>
 ROW_FN void r_g2_psi(Jac<F>& r, const Jac<F>& p) {
