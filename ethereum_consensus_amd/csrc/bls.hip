@@ -588,7 +588,12 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     auto run_keys = [&] {
         if (n_pks && !reg) {
             ProfScope ps("bls_pk_validate", s);
-            launch_pk_validate(s, d_pks48, n_pks, pts, st);
+            if (g_row_stages && n_pks <= g_h2c_row_max) {  // (round 5) a few keys: decoding on one lane each, the subgroup check on a row each
+                hipLaunchKernelGGL(k_pk_decode_w1, grid_for(n_pks), dim3(BLS_BLOCK), 0, s, d_pks48, n_pks, pts, st);
+                launch_pk_group_row(s, (const A1*)pts, n_pks, st);
+            } else {
+                launch_pk_validate(s, d_pks48, n_pks, pts, st);
+            }
         }
         if (d_pk_off) {
             ProfScope ps("bls_pk_aggregate", s);

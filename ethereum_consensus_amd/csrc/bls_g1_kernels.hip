@@ -30,4 +30,18 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_G1_OCCUPANCY) ECG_G1_KN(k_pk_va
     st[i] = s;
 }
 
+#if ECG_G1_WAVES == 1
+// the decoding alone (small batches: the subgroup check then runs on rows, bls_row_g2.hip k_pk_group_row): the status
+// key_validate would return before its group check
+__global__ void __launch_bounds__(BLS_BLOCK, ECG_G1_OCCUPANCY) k_pk_decode_w1(const u8* pks48, u32 n, A1* pts, u8* st) {
+    u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    A1 p;
+    int s = g1_decompress(p, pks48 + 48 * (size_t)i);
+    if (!s && p.inf) s = ECGPU_PK_IS_INFINITY;
+    pts[i] = p;
+    st[i] = (u8)s;
+}
+#endif
+
 }  // namespace ecg

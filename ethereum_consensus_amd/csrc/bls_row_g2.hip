@@ -33,6 +33,17 @@ __global__ void __launch_bounds__(64) k_sig_group_row(const A2* pts, const u8* s
     if ((threadIdx.x & 31u) == 0) st_grp[i] = g;
 }
 
+// row t = public key t, already decoded (k_pk_decode): reject infinity, then the endomorphism subgroup check of key_validate
+// (crypto/bls.rs:279-285)
+__global__ void __launch_bounds__(64) k_pk_group_row(const A1* pts, u32 n, u8* st) {
+    const u32 row = threadIdx.x >> 4, i = blockIdx.x * 4 + row;
+    if (i >= n) return;
+    if (st[i] != 0) return;  // (the decoder's verdict stands: bad encoding, not on the curve, x == 0, infinity)
+    if (!r_g1_in_subgroup(&pts[i]) && (threadIdx.x & 15u) == 0) st[i] = ECGPU_POINT_NOT_IN_GROUP;
+}
+void launch_pk_group_row(hipStream_t s, const A1* pts, u32 n, u8* st) {
+    hipLaunchKernelGGL(k_pk_group_row, dim3((n + 3) / 4), dim3(64), 0, s, pts, n, st);
+}
 void launch_h2c_map_row(hipStream_t s, const u8* msgs, const u64* msg_off, u32 n, J2* maps) {
     hipLaunchKernelGGL(k_h2c_map_row, dim3((2 * n + 3) / 4), dim3(64), 0, s, msgs, msg_off, n, maps);
 }

@@ -240,6 +240,19 @@ ROW_FN bool r_g2_in_subgroup(const A2* q) {
     return jac_eq(ps, t);
 }
 
+// the subgroup check of a decoded public key on a row (g1_in_subgroup of bls_curve.h): P + phi(P) == [x^2] P
+ROW_FN bool r_g1_in_subgroup(const A1* p) {
+    if (p->inf) return true;
+    const Aff<R1> a{R1{rfp_load(&p->x).v}, R1{rfp_load(&p->y).v}, 0u};
+    Jac<R1> P, t, lhs;
+    jac_from_aff(P, a);
+    jac_mul_xabs_aff(t, a);
+    jac_mul_xabs(t, t);  // [x^2] P
+    const R1 bx = f_mul(a.x, R1{row_const_limb(blsc::BETA.l)});
+    jac_add_aff(lhs, P, bx, a.y);  // P + phi(P)
+    return jac_eq(lhs, t);
+}
+
 // q0 + q1, cofactor, affine: H(m) to memory (pointers uniform over the row / the row pair)
 template <class F>
 ROW_FN void r_hash_to_g2_finish(A2* out, const J2* q0, const J2* q1, u32* tab) {

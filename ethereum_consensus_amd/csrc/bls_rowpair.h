@@ -102,6 +102,38 @@ ROW_FN bool f_first_lane(const RP2*) {
 #endif
 }
 
+// ---- Fp on a row as the field of the generic G1 routines (a public key per row: its subgroup check is 126 Fp doublings) ----------
+struct R1 {
+    rv32 v;
+};
+ROW_FN R1 f_add(const R1& a, const R1& b) { const RowK K = row_k(); return R1{rfp_add(RFp{a.v}, RFp{b.v}, K).v}; }
+ROW_FN R1 f_sub(const R1& a, const R1& b) { const RowK K = row_k(); return R1{rfp_sub(RFp{a.v}, RFp{b.v}, K).v}; }
+ROW_FN R1 f_dbl(const R1& a) { return f_add(a, a); }
+ROW_FN R1 f_neg(const R1& a) { const RowK K = row_k(); return R1{rfp_neg(RFp{a.v}, K).v}; }
+ROW_FN R1 f_add_lazy(const R1& a, const R1& b) { const RowK K = row_k(); return R1{rfp_add_lazy(RFp{a.v}, RFp{b.v}, K).v}; }
+template <int KP>
+ROW_FN R1 f_sub_lazy(const R1& a, const R1& b) { const RowK K = row_k(); return R1{rfp_sub_lazy<KP>(RFp{a.v}, RFp{b.v}, K).v}; }
+template <int KP>
+ROW_FN R1 f_neg_lazy(const R1& a) { const RowK K = row_k(); return R1{rfp_neg_lazy<KP>(RFp{a.v}, K).v}; }
+ROW_FN R1 f_sub_dbl(const R1& a, const R1& b) { const RowK K = row_k(); return R1{rfp_sub_dbl(RFp{a.v}, RFp{b.v}, K).v}; }
+ROW_FN R1 f_mul(const R1& a, const R1& b) { const RowK K = row_k(); return R1{rfp_mul(RFp{a.v}, RFp{b.v}, K).v}; }
+ROW_FN R1 f_sqr(const R1& a) { return f_mul(a, a); }
+template <int KP>
+ROW_FN R1 f_sqr_lazy(const R1& a) { return f_mul(a, a); }
+template <int KB0, int KB1>
+ROW_FN R1 f_sp2(const R1& a0, const R1& b0, const R1& a1, const R1& b1) {
+    const RowK K = row_k();
+    rv32 bv[2][13];
+    rfp_spread(bv[0], RFp{b0.v});
+    rfp_spread(bv[1], RFp{b1.v});
+    const rv32 av[2] = {a0.v, a1.v};
+    return R1{row_sumprod<2>(av, bv, K.p)};
+}
+ROW_FN bool f_is_zero(const R1& a) { const RowK K = row_k(); return rfp_is_zero(RFp{a.v}, K); }
+ROW_FN bool f_eq(const R1& a, const R1& b) { const RowK K = row_k(); return rfp_eq(RFp{a.v}, RFp{b.v}, K); }
+ROW_FN void f_set_zero(R1& a) { a = R1{rv_splat(0)}; }
+ROW_FN void f_set_one(R1& a) { a = R1{row_const_limb(blsc::ONE.l)}; }
+
 // ... and the same helpers for the one-row form, so that the routines of bls_rowcurve.h are written once
 ROW_FN RFp2 f_conj(const RFp2& a) { return rfp2_conj(a); }
 ROW_FN RFp2 f_const2(const RFp2*, const Fp2& c) { return rfp2_const(c); }

@@ -285,6 +285,13 @@ int hs_g2_in_subgroup_row(const u8* xy, int pair) {
     const int r = (pair ? r_g2_in_subgroup<RP2>(&q) : r_g2_in_subgroup<RFp2>(&q)) ? 1 : 0;
     return g_ecg_column_overflows ? -1 : r;
 }
+// the subgroup check of a decoded public key on a row (k_pk_group_row): 1 in G1, 0 not
+int hs_g1_in_subgroup_row(const u8* xy) {
+    g_ecg_column_overflows = 0;
+    const A1 p = in_a1(xy, 0);
+    const int r = r_g1_in_subgroup(&p) ? 1 : 0;
+    return g_ecg_column_overflows ? -1 : r;
+}
 // Fp2 square root / signs on a row against the one-lane routines: out = root (canonical big-endian c0 | c1); returns
 // is_square | sgn0(a) << 1 | lex_largest(a) << 2
 int hs_rowfield_sqrt(const u8* a96, u8* out96) {

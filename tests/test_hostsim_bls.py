@@ -228,6 +228,9 @@ def test_row_field_square_roots_signs_and_the_subgroup_check():
         Q = B.g2_mul(B.G2, r.randrange(1, B.R))
         assert L.hs_g2_in_subgroup_row(a2(Q), 0) == 1 and L.hs_g2_in_subgroup_row(a2(Q), 1) == 1
     from tests import _blscases as C
+    for k in range(3):
+        assert L.hs_g1_in_subgroup_row(a1(B.g1_mul(B.G1, r.randrange(1, B.R)))) == 1
+        assert L.hs_g1_in_subgroup_row(a1(C.rand_g1_curve_point(r))) == 0  # on E1, outside G1
     for k in range(4):
         Q = C.rand_g2_curve_point(r)  # on E2, outside G2
         assert L.hs_g2_in_subgroup_row(a2(Q), 0) == 0 and L.hs_g2_in_subgroup_row(a2(Q), 1) == 0
