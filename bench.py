@@ -139,6 +139,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the strong_2p20 / epoch / slots sub-records of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aggregates", action="store_true", help="skip the secondary K = 2048 aggregates line")
+    ap.add_argument("--even-shards", action="store_true", help="strong scaling: keep the even split (no speed-weighted re-sharding)")
     ap.add_argument("--verbose", action="store_true",
                     help="print the full record (every note and provenance string) instead of the compact line; the full record is "
                          "always written to gpurun_out/bench_full.json as well")
@@ -522,18 +523,12 @@ def cpu_baseline_bls(sample, budget_s: float = 20.0):
                       "(blst itself is not available offline: ~1.2-1.5 k/s per core published)"}
 
 
-def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
-    """K = 1 tuples.  weak scaling (default): every rank verifies `--tuples` tuples of its own.  strong (`--scaling strong`,
-    north_star's 2^20-signature batch): `--tuples` in all, rank g verifies shard_range(total, g, N) -- ragged shards, one
-    all-gather of the status bytes per step either way."""
-    from ethereum_consensus_amd import shard
-    strong = (args.scaling == "strong") if strong is None else strong
-    total = args.tuples if n_total is None else n_total
-    if strong:
-        lo, hi = shard.shard_range(total, rank, world)
-    else:
-        lo, hi = rank * total, (rank + 1) * total
-    n = hi - lo
+BLS_SHARD_GRANULE = 1024  # weighted shards are cut at multiples of this many tuples
+
+
+def _bls_setup(L, torch, n, lo):
+    """the shard [lo, lo + n) of the K = 1 workload, resident in HBM: keys and signatures made on the device, the fault cycle
+    injected on the host copy (statuses known by construction)"""
     dev = _device(torch)
     sks, msgs = bls_inputs(n, lo)
     d_sk = torch.frombuffer(bytearray(sks or b"\0"), dtype=torch.uint8).to(dev)
@@ -559,19 +554,62 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
     d_msg = torch.frombuffer(msgs or bytearray(1), dtype=torch.uint8).to(dev)
     d_st = torch.full((max(n, 1),), 0xFF, dtype=torch.uint8, device=dev)
     _sync(torch)
-    gathered = {}
+    return d_pk, d_msg, d_sig, d_st, h_pk, msgs, h_sig, want_bytes, stream
 
-    def step():
-        if n:
-            rc = L.ecgpu_fast_aggregate_verify_batch_dev(d_pk.data_ptr(), None, n, d_msg.data_ptr(), d_sig.data_ptr(), n, 0,
-                                                         d_st.data_ptr(), stream)
-            if rc != 0:
-                raise RuntimeError(f"ecgpu_fast_aggregate_verify_batch_dev -> {rc}: {L.ecgpu_last_error()}")
-        if _multi(dist, world):
-            # the path's only collective: every rank learns every shard's verify statuses
-            gathered["st"] = (shard.all_gather_ragged(dist, d_st[:n], total, world, force=FORCE_DIST) if strong
-                              else shard.all_gather_bytes(dist, d_st, world, force=FORCE_DIST))
 
+def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
+    """K = 1 tuples.  weak scaling (default): every rank verifies `--tuples` tuples of its own.  strong (`--scaling strong`,
+    north_star's 2^20-signature batch): `--tuples` in all, rank g verifies shard_range(total, g, N) -- ragged shards, one
+    all-gather of the status bytes per step either way."""
+    from ethereum_consensus_amd import shard
+    strong = (args.scaling == "strong") if strong is None else strong
+    total = args.tuples if n_total is None else n_total
+    weights = None  # strong scaling only: per-rank speeds once measured (speed-weighted shards)
+    balance = {"weights": None}
+    while True:
+        if strong:
+            lo, hi = shard.shard_range(total, rank, world, weights, BLS_SHARD_GRANULE)
+        else:
+            lo, hi = rank * total, (rank + 1) * total
+        n = hi - lo
+        setup = _bls_setup(L, torch, n, lo)
+        d_pk, d_msg, d_sig, d_st, h_pk, msgs, h_sig, want_bytes, stream = setup
+        gathered = {}
+
+        def step():
+            if n:
+                rc = L.ecgpu_fast_aggregate_verify_batch_dev(d_pk.data_ptr(), None, n, d_msg.data_ptr(), d_sig.data_ptr(), n, 0,
+                                                             d_st.data_ptr(), stream)
+                if rc != 0:
+                    raise RuntimeError(f"ecgpu_fast_aggregate_verify_batch_dev -> {rc}: {L.ecgpu_last_error()}")
+            if _multi(dist, world):
+                # the path's only collective: every rank learns every shard's verify statuses
+                gathered["st"] = (shard.all_gather_ragged(dist, d_st[:n], total, world, force=FORCE_DIST, weights=weights,
+                                                          granule=BLS_SHARD_GRANULE) if strong
+                                  else shard.all_gather_bytes(dist, d_st, world, force=FORCE_DIST))
+
+        if not (strong and _multi(dist, world) and weights is None and world > 1 and not getattr(args, "even_shards", False)):
+            break
+        # Speed-weighted shards (SURVEY.md 8e row 1; VERDICT round 4 item 4): one GPU with slow instruction fetch runs this batch
+        # 1.8 x slower (DESIGN.md 3.5) and an even split makes every step wait for it.  Each rank times its own kernels on its
+        # even shard (no collective inside), the speeds are all-gathered, and unless the node is homogeneous the batch is cut
+        # again in proportion.
+        local_step = lambda: L.ecgpu_fast_aggregate_verify_batch_dev(d_pk.data_ptr(), None, n, d_msg.data_ptr(), d_sig.data_ptr(), n, 0,
+                                                                     d_st.data_ptr(), stream) if n else 0
+        local_step()
+        _sync(torch)
+        t_probe = time.perf_counter()
+        for _ in range(2):
+            local_step()
+        _sync(torch)
+        mine = (2 * n) / max(time.perf_counter() - t_probe, 1e-9) * float(os.environ.get("ECGPU_BENCH_SPEED_SCALE", "1"))
+        speeds = shard.gather_speeds(dist, mine, world, device=_device(torch))
+        balance = {"speeds_tuples_per_s": speeds, "weights": None}
+        if shard.balanced_enough(speeds):
+            break
+        weights = speeds
+        balance["weights"] = [s_ / sum(speeds) for s_ in speeds]
+    dev = _device(torch)
     for _ in range(max(args.warmup, 1)):
         step()
     _sync(torch)
@@ -593,6 +631,9 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
     path = int(L.ecgpu_bls_last_pairing_path())
     if path == 3:  # the sum-of-products lane groups ran the pairing check (ECGPU_PAIRING=vm3, or a box with slow instruction fetch)
         pairing_kernel = "k_vm3_pair_a + k_vm3_pair_c"
+        ops["bls_pairing"] = (0, 0, vm3_multiplies_per_tuple())
+    if path == 7:  # the row machine (csrc/bls_row.hip): the lane groups' programs, one Fp operation per 16-lane row
+        pairing_kernel = "k_row_pair_a + k_row_pair_c"
         ops["bls_pairing"] = (0, 0, vm3_multiplies_per_tuple())
     if path == 5:  # Miller loop on two lanes per tuple; final exponentiation on one lane, or (up to half a round of lanes, or when
         # ECGPU_FINALEXP_LANES=2) on the lane pair as well: the same multiplies either way
@@ -647,7 +688,7 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
                              "decompressed + subgroup-checked, every message hashed to G2, per-tuple pairing check",
                 "sharding": ("strong scaling: the batch is fixed, rank g verifies shard_range(total, g, N); ragged all-gather of the status "
                              "bytes every step") if strong else "one independent batch per GPU; all-gather of the status bytes every step"},
-        roofline={"bound": "hbm", "kernel": pairing_kernel, "kernel_build": ("sum-of-products lane groups (vm3)" if path == 3 else "two lanes per tuple (Miller loop) + one lane (final exponentiation)" if path == 5
+        roofline={"bound": "hbm", "kernel": pairing_kernel, "kernel_build": ("sum-of-products lane groups (vm3)" if path == 3 else "row machine" if path == 7 else "two lanes per tuple (Miller loop) + one lane (final exponentiation)" if path == 5
                                    else {1: "sums of products", 2: "compact-code tower"}.get(build, "?")),
                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic or {}).get("bytes_per_launch"), "traffic_detail": traffic,
@@ -662,6 +703,7 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
                                "note": f"the path is integer-multiplier bound, not HBM bound: {mults_per_sig / 1e6:.1f} M multiplies vs 177 B per "
                                        "signature (census of the kernel build that ran)"}},
         check={"statuses_match_construction": ok, "expected_failures": int(want.astype(bool).sum())},
+        extra=({"weights": balance} if strong and _multi(dist, world) else {}),
     )
 
 
@@ -1055,6 +1097,18 @@ def run_block(args, L, torch, n_val=1 << 16):
             if rep:
                 best = dt if best is None or dt < best else best
         scalar[name + "_ms"] = best * 1e3
+    # where a lone call's time goes: the three side stages run side by side on three queues, then the pairing check (HIP events
+    # per stage; the wall time above is host buffers in, status out)
+    L.ecgpu_prof_enable(1)
+    tags = ("bls_pk_validate", "bls_sig", "bls_h2c", "bls_pairing", "bls_row_a", "bls_row_inv", "bls_row_c")
+    before = {t_: _prof(L, t_) for t_ in tags}
+    keys = [key(i) for i in lists[129 + 3]]
+    for _ in range(4):
+        assert bls.verify_signature_status(keys[0], msgs[129 + 3], sig(129 + 3)) == 0
+    scalar["verify_signature_stage_ms"] = {t_: (_prof(L, t_)[0] - before[t_][0]) / max(1, _prof(L, t_)[1] - before[t_][1]) for t_ in tags}
+    L.ecgpu_prof_enable(0)
+    scalar["pairing_path"] = {1: "lane", 3: "lane groups", 5: "two lanes per tuple", 7: "row machine"}.get(int(L.ecgpu_bls_last_pairing_path()), "?")
+    scalar["blst_one_core_estimate_ms"] = 1e3 / BLST_SIGS_PER_CORE
     n_sigs = sum(len(l) for l in lists)
     return {"verifications": len(lists), "signatures": n_sigs, **out, "scalar_call": scalar,
             "note": "flush() of one block's verifications (host buffers in, statuses out); scalar_call: ONE verification per call, "

@@ -4,8 +4,34 @@ GPU over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tes
 from __future__ import annotations
 
 
-def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
-    """Contiguous, balanced [lo, hi) of rank `rank`; the first n_total % world ranks get one extra."""
+def weighted_bounds(n_total: int, weights, granule: int = 1) -> list[int]:
+    """Cut points b[0] = 0 <= b[1] <= ... <= b[world] = n_total of contiguous shards whose sizes are proportional to `weights`
+    (a rank's measured speed: units per second), each cut rounded to a multiple of `granule`.  Deterministic in its
+    arguments: every rank computes the same cuts from the same all-gathered weights.  One slow GPU in a node (a box whose
+    instruction fetch is slow runs the BLS batch 1.8 x slower) otherwise sets the step time for all."""
+    world = len(weights)
+    w = [max(float(x), 0.0) for x in weights]
+    tot = sum(w)
+    if tot <= 0:
+        w, tot = [1.0] * world, float(world)
+    g = max(1, int(granule))
+    b, acc = [0], 0.0
+    for r in range(world - 1):
+        acc += w[r]
+        cut = int(round(n_total * acc / tot / g)) * g
+        b.append(min(max(cut, b[-1]), n_total))
+    b.append(n_total)
+    return b
+
+
+def shard_range(n_total: int, rank: int, world: int, weights=None, granule: int = 1) -> tuple[int, int]:
+    """Contiguous [lo, hi) of rank `rank`.  Without weights: balanced, the first n_total % world ranks get one extra.  With
+    per-rank weights (len == world): proportional to them (weighted_bounds)."""
+    if weights is not None:
+        if len(weights) != world:
+            raise ValueError("one weight per rank")
+        b = weighted_bounds(n_total, weights, granule)
+        return b[rank], b[rank + 1]
     base, rem = divmod(n_total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
@@ -26,20 +52,36 @@ def all_gather_bytes(dist, local, world: int, force: bool = False):
     return out
 
 
-def all_gather_ragged(dist, local, n_total: int, world: int, force: bool = False):
-    """All-gather shards produced by shard_range (sizes differ by at most one): pad, gather, trim."""
+def all_gather_ragged(dist, local, n_total: int, world: int, force: bool = False, weights=None, granule: int = 1):
+    """All-gather shards produced by shard_range (balanced: sizes differ by at most one; weighted: by whatever the weights
+    say): pad to the widest shard, gather, trim."""
     import torch
     if world == 1 and not force:
         return local
-    width = (n_total + world - 1) // world
+    sizes = [hi - lo for lo, hi in (shard_range(n_total, r, world, weights, granule) for r in range(world))]
+    width = max(max(sizes), 1)
     padded = torch.zeros(width, dtype=torch.uint8, device=local.device)
     padded[:local.numel()] = local
     g = all_gather_bytes(dist, padded, world, force)
-    parts = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        parts.append(g[r * width:r * width + (hi - lo)])
-    return torch.cat(parts)
+    return torch.cat([g[r * width:r * width + sizes[r]] for r in range(world)])
+
+
+def gather_speeds(dist, mine: float, world: int, device="cpu"):
+    """every rank's measured speed (units per second), in rank order, on every rank"""
+    import torch
+    if world == 1 or dist is None:
+        return [float(mine)]
+    t = torch.tensor([float(mine)], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
+def balanced_enough(speeds, tolerance: float = 1.15) -> bool:
+    """True when the fastest rank is within `tolerance` of the slowest: an even split is kept (re-sharding costs a second
+    workload generation and, on a homogeneous node, would only follow timer noise)"""
+    pos = [s for s in speeds if s > 0]
+    return not pos or max(pos) <= tolerance * min(pos)
 
 
 def subtree_width(n_total: int, world: int) -> int:

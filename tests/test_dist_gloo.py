@@ -220,7 +220,7 @@ def _bench_worker(rank, world, port, q):
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         bench.DEV = "cpu"
-        args = argparse.Namespace(steps=1, warmup=1, tuples=10, scaling="strong")
+        args = argparse.Namespace(steps=1, warmup=1, tuples=10, scaling="strong", even_shards=True)
         res = {}
         # finish(): the slowest rank's wall time sets the step time; value = all ranks' units over it
         line = bench.finish(dict(dt=0.5 * (rank + 1), units_per_step=100, metric="m", unit="u", dtype="u32", config={}, roofline={},
@@ -266,6 +266,89 @@ def test_bench_n_rank_control_flow_under_gloo(world):
         lo, hi = shard.shard_range(10, r, world)
         assert out["bls"][:3] == (True, hi - lo, "strong")
         assert abs(out["bls"][3] - 10) < 1e-3  # value x time of one step = the whole batch, whatever the rank count
+
+
+# ---- speed-weighted shards of the strong-scaled BLS batch ---------------------------
+class _SlowRankStub(_StubLib):
+    """the stub library with a verify call that takes `ms_per_tuple` of wall time per tuple on top of the oracle's: one rank of
+    the group is made 1.8 x slower, the way a GPU with slow instruction fetch is"""
+
+    def __init__(self, ms_per_tuple):
+        super().__init__()
+        self.ms_per_tuple = ms_per_tuple
+
+    def ecgpu_fast_aggregate_verify_batch_dev(self, d_pk, d_off, n_pks, d_msg, d_sig, n, eth, d_st, stream):
+        import time
+        time.sleep(n * self.ms_per_tuple * 1e-3)
+        return super().ecgpu_fast_aggregate_verify_batch_dev(d_pk, d_off, n_pks, d_msg, d_sig, n, eth, d_st, stream)
+
+
+def _weighted_worker(rank, world, port, q, total, slow_rank):
+    import argparse
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        bench.DEV = "cpu"
+        bench.BLS_SHARD_GRANULE = 4
+        L = _SlowRankStub(40.0 * (1.8 if rank == slow_rank else 1.0))
+        args = argparse.Namespace(steps=2, warmup=1, tuples=total, scaling="strong", even_shards=False)
+        b = bench.run_bls(args, L, torch, dist, rank, world)
+        line = bench.finish(b, args, world, dist, torch)
+        even = argparse.Namespace(steps=2, warmup=1, tuples=total, scaling="strong", even_shards=True)
+        e = bench.finish(bench.run_bls(even, L, torch, dist, rank, world), even, world, dist, torch)
+        dist.barrier()
+        q.put((rank, dict(ok=b["check"]["statuses_match_construction"], n=b["config"]["tuples_this_rank"], weights=line["weights"],
+                          ms=line["ms_per_step"], ms_even=e["ms_per_step"], n_even=e["config"]["tuples_this_rank"] if "config" in e else None)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_speed_weighted_shards_with_one_slow_rank_under_gloo():
+    """world 4, rank 2 verifies 1.8 x slower: the strong-scaled batch is cut in proportion to the measured speeds (all-gathered:
+    every rank computes the same cuts), the ragged gather still puts every shard's statuses where they belong, and a step takes
+    within 10 % of the weighted optimum -- where the even split waits for the slow rank."""
+    world, total, slow = 4, 96, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_weighted_worker, args=(r, world, port, q, total, slow)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    w = res[0]["weights"]
+    assert all(res[r]["ok"] for r in range(world))          # own shard AND the gathered whole equal construction on every rank
+    assert all(res[r]["weights"] == w for r in range(world))  # the same cuts everywhere
+    assert w["weights"] is not None and min(w["weights"]) == w["weights"][slow]
+    sizes = [res[r]["n"] for r in range(world)]
+    assert sum(sizes) == total and sizes[slow] == min(sizes) and sizes[slow] < total // world
+    bounds = shard.weighted_bounds(total, w["speeds_tuples_per_s"], 4)
+    assert sizes == [bounds[r + 1] - bounds[r] for r in range(world)]
+    optimum_ms = total / sum(w["speeds_tuples_per_s"]) * 1e3
+    assert res[0]["ms"] <= 1.10 * optimum_ms + 15.0, (res[0]["ms"], optimum_ms)  # (+ the gather's few milliseconds under gloo)
+    assert res[0]["ms_even"] >= 1.25 * res[0]["ms"]           # the even split waits for the slow rank
+
+
+def test_weighted_bounds_are_monotonic_cover_the_range_and_follow_the_weights():
+    for total, weights, g in ((1 << 20, [1] * 8, 1024), (1 << 20, [1, 1, 1, 0.55, 1, 1, 1, 1], 1024), (10, [3, 1], 1), (7, [0, 0, 0], 1),
+                              (1000, [1, 2, 3, 4], 16), (5, [1, 1, 1, 1, 1, 1, 1, 1], 1), (131072, [1, 1e-9], 65536)):
+        b = shard.weighted_bounds(total, weights, g)
+        assert b[0] == 0 and b[-1] == total and all(x <= y for x, y in zip(b, b[1:])) and len(b) == len(weights) + 1
+        assert all(x % g == 0 for x in b[1:-1])
+        if sum(weights) > 0 and total >= 100 * g:
+            for r, wt in enumerate(weights):
+                assert abs((b[r + 1] - b[r]) - total * wt / sum(weights)) <= g
+        for r in range(len(weights)):
+            assert shard.shard_range(total, r, len(weights), weights, g) == (b[r], b[r + 1])
+    assert shard.balanced_enough([1.0, 1.1, 1.05]) and not shard.balanced_enough([1.0, 1.8, 1.0])
 
 
 # ---- ONE BeaconState over N ranks (bench.py --workload merkle --scaling strong; SURVEY.md 8e row 2) --------------------------
