@@ -664,54 +664,99 @@ pub mod merkle {
         pub vector_len: u64,  // SLOTS_PER_HISTORICAL_ROOT
         pub mixes_len: u64,   // EPOCHS_PER_HISTORICAL_VECTOR
     }
+    /// a tracked region of the serialization: a queued write names the region and a byte offset INSIDE it, and is resolved to an
+    /// absolute offset only in `root()`, after the length changes of the same slot have been applied (advisor, round 4: absolute
+    /// offsets taken before an append land 121 n bytes early once a deposit has grown the registry)
+    #[derive(Clone, Copy, Debug, PartialEq, Eq, Hash)]
+    pub enum Region {
+        BlockRoots, StateRoots, RandaoMixes, Slashings, Validators, Balances, PreviousEpochParticipation, CurrentEpochParticipation,
+        InactivityScores,
+        /// an absolute offset (the small runs and the payload header, which `root()` itself queues after the layout is final)
+        Absolute,
+    }
+    impl StateLayout {
+        fn base(&self, r: Region) -> u64 {
+            match r {
+                Region::BlockRoots => self.block_roots, Region::StateRoots => self.state_roots, Region::RandaoMixes => self.randao_mixes,
+                Region::Slashings => self.slashings, Region::Validators => self.validators, Region::Balances => self.balances,
+                Region::PreviousEpochParticipation => self.previous_epoch_participation,
+                Region::CurrentEpochParticipation => self.current_epoch_participation, Region::InactivityScores => self.inactivity_scores,
+                Region::Absolute => 0,
+            }
+        }
+        /// `bytes` inserted (or, negative, removed) at the END of eth1_data_votes: every variable-size field behind it moves
+        fn shift_after_votes(&mut self, bytes: i64) {
+            let sh = |x: &mut u64| *x = (*x as i64 + bytes) as u64;
+            sh(&mut self.validators);
+            sh(&mut self.balances);
+            sh(&mut self.previous_epoch_participation);
+            sh(&mut self.current_epoch_participation);
+            sh(&mut self.inactivity_scores);
+            sh(&mut self.payload_header.0);
+        }
+    }
     pub struct StateMirror {
         state: ResidentState,
         layout: StateLayout,
-        patches: Vec<(u64, Vec<u8>)>,
+        patches: Vec<(Region, u64, Vec<u8>)>,
         appended_validators: Vec<u8>,  // 121-byte records of add_validator_to_registry since the last root
         appended_balances: Vec<u8>,
+        appended_votes: Vec<u8>,       // 72-byte Eth1Data records of process_eth1_data since the last root
+        votes_reset: bool,             // process_eth1_data_reset emptied the list since the last root
+        n_votes: u64,                  // eth1_data_votes currently on the device
         stale: bool,                   // the next root re-creates the resident state from a full serialization
         fork: i32,
         preset: i32,
     }
     impl StateMirror {
-        /// `layout_of(ssz)` derives the offsets from the offset table of the serialization (the caller knows its fork's table)
-        pub fn new(fork: i32, preset: i32, ssz: &[u8], layout: StateLayout) -> Result<Self, MerkleizationError> {
+        /// `layout_of(ssz)` derives the offsets from the offset table of the serialization (the caller knows its fork's table);
+        /// `n_votes` = eth1_data_votes in `ssz`
+        pub fn new(fork: i32, preset: i32, ssz: &[u8], layout: StateLayout, n_votes: u64) -> Result<Self, MerkleizationError> {
             Ok(Self { state: ResidentState::new(fork, preset, ssz)?, layout, patches: Vec::new(), appended_validators: Vec::new(),
-                      appended_balances: Vec::new(), stale: false, fork, preset })
+                      appended_balances: Vec::new(), appended_votes: Vec::new(), votes_reset: false, n_votes, stale: false, fork, preset })
         }
         pub fn touch_balance(&mut self, index: usize, gwei: u64) {
-            self.patches.push((self.layout.balances + 8 * index as u64, gwei.to_le_bytes().to_vec()));
+            self.patches.push((Region::Balances, 8 * index as u64, gwei.to_le_bytes().to_vec()));
         }
         pub fn touch_inactivity_score(&mut self, index: usize, score: u64) {
-            self.patches.push((self.layout.inactivity_scores + 8 * index as u64, score.to_le_bytes().to_vec()));
+            self.patches.push((Region::InactivityScores, 8 * index as u64, score.to_le_bytes().to_vec()));
         }
         /// `current`: current_epoch_participation, else previous (altair/block_processing.rs process_attestation)
         pub fn touch_participation(&mut self, current: bool, index: usize, flags: u8) {
-            let base = if current { self.layout.current_epoch_participation } else { self.layout.previous_epoch_participation };
-            self.patches.push((base + index as u64, vec![flags]));
+            let r = if current { Region::CurrentEpochParticipation } else { Region::PreviousEpochParticipation };
+            self.patches.push((r, index as u64, vec![flags]));
         }
         /// the whole 121-byte record (slashings, exits, credential changes, effective-balance updates)
         pub fn touch_validator(&mut self, index: usize, record121: &[u8]) {
             debug_assert_eq!(record121.len(), 121);
-            self.patches.push((self.layout.validators + 121 * index as u64, record121.to_vec()));
+            self.patches.push((Region::Validators, 121 * index as u64, record121.to_vec()));
         }
         pub fn touch_block_root(&mut self, slot: u64, root: &Bytes32) {
-            self.patches.push((self.layout.block_roots + 32 * (slot % self.layout.vector_len), root.to_vec()));
+            self.patches.push((Region::BlockRoots, 32 * (slot % self.layout.vector_len), root.to_vec()));
         }
         pub fn touch_state_root(&mut self, slot: u64, root: &Bytes32) {
-            self.patches.push((self.layout.state_roots + 32 * (slot % self.layout.vector_len), root.to_vec()));
+            self.patches.push((Region::StateRoots, 32 * (slot % self.layout.vector_len), root.to_vec()));
         }
         pub fn touch_randao_mix(&mut self, epoch: u64, mix: &Bytes32) {
-            self.patches.push((self.layout.randao_mixes + 32 * (epoch % self.layout.mixes_len), mix.to_vec()));
+            self.patches.push((Region::RandaoMixes, 32 * (epoch % self.layout.mixes_len), mix.to_vec()));
         }
         pub fn touch_slashings(&mut self, index: usize, gwei: u64) {
-            self.patches.push((self.layout.slashings + 8 * index as u64, gwei.to_le_bytes().to_vec()));
+            self.patches.push((Region::Slashings, 8 * index as u64, gwei.to_le_bytes().to_vec()));
         }
         /// add_validator_to_registry (phase0/block_processing.rs:317-349): five lists grow by one element
         pub fn append_validator(&mut self, record121: &[u8], balance: u64) {
             self.appended_validators.extend_from_slice(record121);
             self.appended_balances.extend_from_slice(&balance.to_le_bytes());
+        }
+        /// process_eth1_data (phase0/block_processing.rs:689-700): `state.eth1_data_votes.push(vote)` -- 72 bytes per block
+        pub fn append_eth1_vote(&mut self, vote72: &[u8]) {
+            debug_assert_eq!(vote72.len(), 72);
+            self.appended_votes.extend_from_slice(vote72);
+        }
+        /// process_eth1_data_reset (phase0/epoch_processing.rs): the list is emptied at the start of a voting period
+        pub fn reset_eth1_votes(&mut self) {
+            self.appended_votes.clear();
+            self.votes_reset = true;
         }
         /// anything the hooks do not follow (process_epoch rewrites every balance and rotates the participation lists; a fork
         /// upgrade changes the layout): the next root starts from a full serialization
@@ -720,18 +765,34 @@ pub mod merkle {
             self.patches.clear();
             self.appended_validators.clear();
             self.appended_balances.clear();
+            self.appended_votes.clear();
+            self.votes_reset = false;
         }
         /// The root of the state the hooks have described.  `small(run)` serializes one run of small fixed-size fields
         /// (`layout.small_runs`) and `payload_header()` the header -- together < 1 KB, re-sent every time; `full()` is only
-        /// called when the mirror is stale (once per epoch) and returns (serialization, its layout).
+        /// called when the mirror is stale (once per epoch) and returns (serialization, its layout, its eth1_data_votes count).
         pub fn root(&mut self, small: impl Fn(usize) -> Vec<u8>, payload_header: impl FnOnce() -> Vec<u8>,
-                    full: impl FnOnce() -> (Vec<u8>, StateLayout)) -> Result<Bytes32, MerkleizationError> {
+                    full: impl FnOnce() -> (Vec<u8>, StateLayout, u64)) -> Result<Bytes32, MerkleizationError> {
             if self.stale {
-                let (ssz, layout) = full();
+                let (ssz, layout, n_votes) = full();
                 self.state = ResidentState::new(self.fork, self.preset, &ssz)?;
                 self.layout = layout;
+                self.n_votes = n_votes;
                 self.stale = false;
                 return self.state.root();
+            }
+            // 1. length changes first, each followed by the layout shift it causes; queued writes are resolved afterwards
+            if self.votes_reset {
+                self.state.truncate(sys::ECGPU_STATE_ETH1_DATA_VOTES, 0)?;
+                self.layout.shift_after_votes(-(72 * self.n_votes as i64));
+                self.n_votes = 0;
+                self.votes_reset = false;
+            }
+            if !self.appended_votes.is_empty() {
+                self.state.append(sys::ECGPU_STATE_ETH1_DATA_VOTES, &self.appended_votes)?;
+                self.layout.shift_after_votes(self.appended_votes.len() as i64);
+                self.n_votes += (self.appended_votes.len() / 72) as u64;
+                self.appended_votes.clear();
             }
             if !self.appended_validators.is_empty() {
                 let n = (self.appended_validators.len() / 121) as u64;
@@ -752,25 +813,31 @@ pub mod merkle {
                 self.appended_validators.clear();
                 self.appended_balances.clear();
             }
+            // 2. the small runs and the payload header: a length that does not match the layout means the mirror has lost track
+            //    (never overwrite neighbouring bytes): start over from a full serialization
             for (k, (off, len)) in self.layout.small_runs.clone().into_iter().enumerate() {
                 let bytes = small(k);
-                debug_assert_eq!(bytes.len() as u64, len);
-                self.patches.push((off, bytes));
+                if bytes.len() as u64 != len {
+                    self.invalidate();
+                    return self.root(small, || Vec::new(), full);
+                }
+                self.patches.push((Region::Absolute, off, bytes));
             }
             let hdr = payload_header();
             if hdr.len() as u64 == self.layout.payload_header.1 {
-                self.patches.push((self.layout.payload_header.0, hdr));
+                self.patches.push((Region::Absolute, self.layout.payload_header.0, hdr));
             } else {
                 self.invalidate();  // extra_data changed length: rare enough for a full upload
                 return self.root(small, || Vec::new(), full);
             }
-            // later writes win: a byte range touched twice keeps its last value (patches of one call must not overlap)
-            self.patches.reverse();
+            // 3. resolve against the FINAL layout; later writes win: a byte range touched twice keeps its last value (patches of
+            //    one call must not overlap)
+            let mut abs: Vec<(u64, Vec<u8>)> = self.patches.drain(..).map(|(r, o, d)| (self.layout.base(r) + o, d)).collect();
+            abs.reverse();
             let mut seen = std::collections::HashSet::new();
-            self.patches.retain(|(o, d)| seen.insert((*o, d.len())));
-            let refs: Vec<(u64, &[u8])> = self.patches.iter().map(|(o, d)| (*o, d.as_slice())).collect();
+            abs.retain(|(o, d)| seen.insert((*o, d.len())));
+            let refs: Vec<(u64, &[u8])> = abs.iter().map(|(o, d)| (*o, d.as_slice())).collect();
             self.state.patch(&refs)?;
-            self.patches.clear();
             self.state.root()
         }
     }
