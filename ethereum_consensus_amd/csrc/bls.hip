@@ -565,7 +565,11 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     // (up to half a round of lanes: 32 768 tuples 19.3 -> 17.8 ms, 20 000 tuples 18.9 -> 16.3 with the stages side by side,
     // profiles/r04f4_*; round 3 stopped at 16 384.  ECGPU_FORK_MAX overrides.)
     static const u32 fork_max = [] { const char* e = getenv("ECGPU_FORK_MAX"); return e ? (u32)strtoul(e, nullptr, 10) : 32768u; }();
-    const bool fork = (n <= fork_max && (fork_small || (d_pk_off && (reg || key_heavy)))) || overlap_sides;
+    // (advisor, round 4: a host that verifies from MANY threads would hold four streams per thread -- more live streams than
+    // hardware queues, where the side stages queue behind each other again: small batches fork only while few threads do)
+    static const int fork_threads_max = [] { const char* e = getenv("ECGPU_FORK_THREADS_MAX"); return e ? atoi(e) : 4; }();
+    const bool few_threads = ax.ready || AuxStreams::live_sets() < fork_threads_max;
+    const bool fork = (n <= fork_max && ((fork_small && few_threads) || (d_pk_off && (reg || key_heavy)))) || overlap_sides;
     hipStream_t s2 = s, s3 = s;  // message stage / signature stage
     if (fork) {
         int rc = ax.init();
@@ -577,7 +581,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         // (st[1] and st[2] share ONE hardware queue -- HISTORY.md 3.4 -- so a signature stage on st[1] ran after the message
         // stage, not beside it; since round 4 it has st[AUX_SIG], a high-priority stream with a queue of its own:
         // a block's 145 verifications 7.9 -> 6.8 ms, profiles/r04x_*)
-        if (key_heavy || overlap_sides || fork_small) {
+        if (key_heavy || overlap_sides || (fork_small && few_threads)) {
             // the two stages are independent of each other as well: a stream each (a lone aggregate is all latency:
             // 3.6 ms + 9.7 ms one after the other, 9.7 ms side by side)
             s3 = ax.st[AUX_SIG];

@@ -54,6 +54,7 @@ struct AuxStreams {
     bool ready = false;
     int device = -1;
     int init();     // takes a set from the device's pool of sets that exited threads gave back, or creates one
+    static int live_sets();  // stream sets currently held by host threads of this process (all devices)
     void give_back();  // (thread exit, after a device-wide synchronisation) back to the pool: streams are never destroyed --
                        // short-lived host threads would otherwise create and destroy hardware queues at every exit
 };
@@ -84,7 +85,9 @@ struct ThreadCtx {
     PinnedBuf staging;      // host-pinned staging for small H2D/D2H payloads
     UploadRing uploads;
     u64 last_hash64 = 0;
-    u8* small_scratch = nullptr;  // 2 KB of device memory outside the arenas (a block that must outlive an arena reset)
+    // 4 KB of device memory outside the arenas PER STREAM (a block that must outlive an arena reset; advisor, round 4: one
+    // buffer per thread was shared by asynchronous calls of that thread on different streams)
+    std::map<hipStream_t, u8*> small_scratch;
     hipStream_t stream_or_own(ecgpu_stream_t s);
     Arena& arena(hipStream_t s) { return arenas[s]; }
     void release();  // synchronize and free every stream, event, arena and pinned buffer (thread exit)

@@ -98,14 +98,14 @@ void ThreadCtx::release() {
     // The arenas are keyed by the stream they were used on, and some of those streams are the CALLER's: they may have been
     // destroyed long ago, so their handles are not touched here.  One device-wide synchronisation covers every stream that
     // could still be reading an arena (this runs once per thread, at its exit).
-    bool any = own_stream != nullptr || aux.ready || small_scratch != nullptr;
+    bool any = own_stream != nullptr || aux.ready || !small_scratch.empty();
     for (auto& kv : arenas) any = any || kv.second.base != nullptr;
     if (any) (void)hipDeviceSynchronize();
     for (auto& kv : arenas)
         if (kv.second.base) (void)hipFree(kv.second.base);
     arenas.clear();
-    if (small_scratch) (void)hipFree(small_scratch);
-    small_scratch = nullptr;
+    for (auto& kv : small_scratch) (void)hipFree(kv.second);
+    small_scratch.clear();
     if (staging.p) (void)hipHostFree(staging.p);
     staging = PinnedBuf();
     uploads.release();
@@ -233,8 +233,12 @@ hipStream_t ThreadCtx::stream_or_own(ecgpu_stream_t s) {
 static std::mutex& g_aux_pool_mu = *new std::mutex();
 static std::vector<AuxStreams>* const g_aux_pool = new std::vector<AuxStreams>[MAX_DEVICES];
 
+static std::atomic<int> g_live_aux_sets{0};
+int AuxStreams::live_sets() { return g_live_aux_sets.load(); }
+
 void AuxStreams::give_back() {
     if (!ready) return;
+    g_live_aux_sets.fetch_sub(1);
     {
         std::lock_guard<std::mutex> lk(g_aux_pool_mu);
         g_aux_pool[device].push_back(*this);
@@ -251,6 +255,7 @@ int AuxStreams::init() {
         if (!pool.empty()) {
             *this = pool.back();
             pool.pop_back();
+            g_live_aux_sets.fetch_add(1);
             return ECGPU_SUCCESS;
         }
     }
@@ -287,6 +292,7 @@ int AuxStreams::init() {
         return rc;
     }
     ready = true;
+    g_live_aux_sets.fetch_add(1);
     return ECGPU_SUCCESS;
 }
 

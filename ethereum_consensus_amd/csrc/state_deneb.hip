@@ -147,8 +147,9 @@ static int state_shard_subroots_device(hipStream_t s, ThreadCtx* c, const u8* d_
         const u64 lo_b = std::min<u64>(lo * rec, b.bytes), hi_b = std::min<u64>(hi * rec, b.bytes);  // a packed list's last chunk may be partial
         return BigField{b.kind, b.src + lo_b, hi_b - lo_b, hi - lo, ceil_log2_u64(W), false, 0, out_chunk};
     };
-    if (!c->small_scratch) ECG_HIP_CHECK(hipMalloc((void**)&c->small_scratch, 4096));
-    u8* d_sc = c->small_scratch;  // <= 2 KB field-root block + the 32-byte root of a container nobody reads
+    u8*& sc_slot = c->small_scratch[s];  // one per stream: two phase-A calls of a thread on two streams must not share it
+    if (!sc_slot) ECG_HIP_CHECK(hipMalloc((void**)&sc_slot, 4096));
+    u8* d_sc = sc_slot;  // <= 2 KB field-root block + the 32-byte root of a container nobody reads
     if (d_keep) {
         // the whole state plan, the five lists cut down to this rank's subtrees (their field slots then hold SUB-roots, the
         // container job a root nobody reads)
