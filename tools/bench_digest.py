@@ -18,7 +18,7 @@ for key in ("aggregates_k2048", "merkle", "epoch", "slots", "strong_2p20", "half
             print("      phases", {k: round(v, 3) for k, v in e["phases"].items() if k.endswith("_ms") or k.endswith("rank")})
 if "block" in d:
     print("  block", round(d["block"]["reference_semantics"]["block_verify_ms"], 2), round(d["block"]["validated_key_registry"]["block_verify_ms"], 2),
-          {k: round(v, 2) for k, v in d["block"].get("scalar_call", {}).items()})
+          {k: round(v, 2) for k, v in d["block"].get("scalar_call", {}).items() if isinstance(v, (int, float))})
 if "msm" in d:
     print("  msm", {k: (round(v["ms"], 2), round(v["points_per_s"])) for k, v in d["msm"].items() if k.startswith("g1_")}, d["msm"]["check"])
 if "box_selfcheck" in d:
