@@ -942,11 +942,24 @@ def run_slots(args, L, torch, dist, rank, world, n_sync=512):
         for _ in range(2048):
             patches[bal_off + 8 * r.randrange(n)] = r.randbytes(8)
             patches[part_off + r.randrange(n)] = bytes([r.randrange(8)])
-        work.append(dict(k=len(part), d_idx=torch.tensor(part, dtype=torch.int32, device=dev),
+        plist = sorted(patches.items())
+        # marshalled once: what a Rust caller hands over is three arrays, not 4 096 Python tuples per slot
+        c_offs = (ctypes.c_uint64 * len(plist))(*[o for o, _ in plist])
+        doff = [0]
+        for _, b_ in plist:
+            doff.append(doff[-1] + len(b_))
+        c_doff = (ctypes.c_uint64 * len(doff))(*doff)
+        blob = ssz._buf(b"".join(b_ for _, b_ in plist))
+        work.append(dict(c_patch=(c_offs, c_doff, blob, len(plist)), k=len(part), d_idx=torch.tensor(part, dtype=torch.int32, device=dev),
                          d_off=torch.tensor([0, len(part)], dtype=torch.int32, device=dev),
                          d_msg=torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev),
-                         d_sig=torch.frombuffer(bytearray(sig), dtype=torch.uint8).to(dev), patches=sorted(patches.items()),
+                         d_sig=torch.frombuffer(bytearray(sig), dtype=torch.uint8).to(dev), patches=plist,
                          want=5 if slot == 5 else 0))
+    def apply_patches(w_):
+        o_, d_, b_, n_ = w_["c_patch"]
+        if L.ecgpu_resident_state_patch(st.handle, o_, d_, b_, n_) != 0:
+            raise RuntimeError(f"resident patch: {L.ecgpu_last_error()}")
+
     d_res = torch.zeros(33, dtype=torch.uint8, device=dev)  # status byte + state root of the slot
     s_bls, s_mk = torch.cuda.Stream(), torch.cuda.Stream()
     statuses = []
@@ -957,7 +970,7 @@ def run_slots(args, L, torch, dist, rank, world, n_sync=512):
         # (host work: ~1 ms of Python per 4 096 patches) and the root run underneath its 6.7 ms dependent chain
         rc1 = L.ecgpu_fast_aggregate_verify_indexed_batch_dev(reg.handle, w["d_idx"].data_ptr(), w["d_off"].data_ptr(), w["k"], w["d_msg"].data_ptr(),
                                                               w["d_sig"].data_ptr(), 1, 1, d_res.data_ptr(), s_bls.cuda_stream)
-        st.patch(w["patches"])
+        apply_patches(w)
         rc2 = L.ecgpu_resident_state_root_dev(st.handle, d_res.data_ptr() + 1, s_mk.cuda_stream)
         if rc1 or rc2:
             raise RuntimeError(f"slot step -> {rc1}, {rc2}: {L.ecgpu_last_error()}")
@@ -991,7 +1004,7 @@ def run_slots(args, L, torch, dist, rank, world, n_sync=512):
         t1 = time.perf_counter()
         for _ in range(8):
             if name == "state_root_ms":
-                st.patch(w["patches"])
+                apply_patches(w)
             fn()
             torch.cuda.synchronize()
         lat[name] = (time.perf_counter() - t1) / 8 * 1e3
@@ -1004,7 +1017,7 @@ def run_slots(args, L, torch, dist, rank, world, n_sync=512):
     for k in range(8):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        st.patch(work[k % n_distinct]["patches"])
+        apply_patches(work[k % n_distinct])
         t2 = time.perf_counter()
         if L.ecgpu_resident_state_root(st.handle, rb) != 0:
             raise RuntimeError(f"resident root: {L.ecgpu_last_error()}")
