@@ -17,8 +17,9 @@
 // CLIMB (at root time, ONE WORKGROUP PER ACTIVE REGION): counters for the region's 2^T - 1 interior nodes live in LDS.  Pass 1:
 // every dirty entry walks up adding 1 to each ancestor's counter and stops at the first ancestor already marked -- afterwards a
 // dirty node's counter holds the number of its dirty children.  Pass 2: every dirty entry recomputes its level-0 node and walks
-// up: subtract 1 from the parent's counter; whoever takes it from 2 to 1 stops (the sibling's subtree is still on its way and
-// will carry on), whoever takes it to 0 loads the sibling, hashes and continues.  Nobody waits, and exactly the nodes on dirty
+// up: where the parent has one dirty child it just hashes with the (clean, prefetched) sibling; where it has two it subtracts 1
+// from the parent's counter: whoever takes it from 2 to 1 stops (the sibling's subtree is still on its way and will carry
+// on), whoever takes it to 0 loads the sibling's fresh node, hashes and continues.  Nobody waits, and exactly the nodes on dirty
 // paths are re-hashed: 4 096 dirty balances of 2^20 cost ~ 4 096 x 6 + 4 096 hash64 instead of 2^18.
 // A region is one workgroup on purpose: tickets and node hand-over stay inside a CU (LDS atomics, workgroup-scope fences).  The
 // first version of this file climbed with one thread per dirty entry anywhere on the chip and device-scope tickets: every level
@@ -134,8 +135,25 @@ ECG_HD void tree_region_count(const TreeGeom& g, u32* lcnt, u32 le) {
         if (tree_atomic_add(&lcnt[tree_local_off(g.T, k) + i], 1u) != 0) return;  // counted from here on up already
     }
 }
-// CLIMB pass 2, per dirty entry: returns the hash64 it performed
-ECG_HD u32 tree_region_climb(const TreeGeom& g, u32* lcnt, u64 region, u32 le, const ZeroTable* zt) {
+// Between the passes (behind the barrier that ends pass 1, in front of the one that starts pass 2), per dirty entry: which of its
+// ancestors have TWO dirty children (bit k - 1 for level k) -- read while the counters are still what pass 1 left, because pass 2
+// takes them down (a counter seen at 1 later on may be a 2 whose other child has already passed).  (Loading the clean siblings
+// of the whole path here as well, so that their latency runs underneath the hashes, was tried: thirteen nodes indexed by a
+// runtime level live in the private segment, and the climb got slower -- profiles/r05u_resident_probe.txt.)
+struct TreePath {
+    u32 both;
+};
+ECG_HD void tree_region_path(const TreeGeom& g, const u32* lcnt, u64 region, u32 le, const ZeroTable* zt, TreePath& P) {
+    const u64 e = (region << g.T) + le;
+    (void)e;
+    (void)zt;
+    P.both = 0;
+    for (u32 k = 1; k <= g.T; k++)
+        if (lcnt[tree_local_off(g.T, k) + (le >> k)] == 2) P.both |= 1u << (k - 1);
+}
+// CLIMB pass 2, per dirty entry: returns the hash64 it performed.  Below the level where a region's paths meet an ancestor
+// has ONE dirty child: nobody to wait for, nothing to hand over -- no ticket, no fences.
+ECG_HD u32 tree_region_climb(const TreeGeom& g, u32* lcnt, u64 region, u32 le, const ZeroTable* zt, const TreePath& P) {
     const u64 e = (region << g.T) + le;
     tree_atomic_and(&g.flag0[e >> 5], ~(1u << (e & 31)));
     u32 hashes = tree_leaf_hashes(g.kind);
@@ -146,10 +164,14 @@ ECG_HD u32 tree_region_climb(const TreeGeom& g, u32* lcnt, u64 region, u32 le, c
     for (u32 k = 1; k <= g.T; k++) {
         const u64 p = i >> 1;
         li >>= 1;
-        tree_fence();  // release (workgroup): the node stored above is visible to the region's other waves before the ticket is given up
-        const u32 before = tree_atomic_sub(&lcnt[tree_local_off(g.T, k) + li], 1u);
-        if (before != 1) return hashes;  // 2: the sibling's subtree is still on its way and carries on from here
-        tree_fence();  // acquire: the sibling's node
+        if ((P.both >> (k - 1)) & 1) {  // both children dirty: the last to arrive carries on, with the other's fresh node
+            tree_fence();  // release (workgroup): the node stored so far is visible to the region's other lanes before the ticket is given up
+            const u32 before = tree_atomic_sub(&lcnt[tree_local_off(g.T, k) + li], 1u);
+            if (before != 1) return hashes;  // 2: the sibling's subtree is still on its way and carries on from here
+            tree_fence();  // acquire: the sibling's node
+        } else {
+            lcnt[tree_local_off(g.T, k) + li] = 0;  // (nobody else touches a counter of 1; left tidy: the host simulator checks that every ticket was taken)
+        }
         const Node sib = tree_node(g, k - 1, i ^ 1, zt);
         // ONE call for the wave: operands selected per lane.  (`odd ? hash64(sib, x) : hash64(x, sib)` is two calls under
         // complementary masks -- a wave holding a left and a right child ran every level twice: profiles/r05g_*)

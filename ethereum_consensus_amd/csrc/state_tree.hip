@@ -45,7 +45,21 @@ __global__ void __launch_bounds__(CLIMB_BLOCK) k_tree_climb(TreeTable tab, const
     if (threadIdx.x == 0) g.rcount[region] = 0;  // the list is consumed
     if (trace && threadIdx.x == 0 && blockIdx.x < 2048) g_tree_trace[3 * blockIdx.x + 1] = wall_clock64();
     u32 h = 0;
-    for (u32 j = threadIdx.x; j < n; j += CLIMB_BLOCK) h += tree_region_climb(g, lcnt, region, list[j], zt);
+    if (n <= CLIMB_BLOCK) {  // the usual shape: every dirty entry of the region has a lane of its own
+        TreePath P;
+        if (threadIdx.x < n) tree_region_path(g, lcnt, region, list[threadIdx.x], zt, P);
+        __syncthreads();  // every lane has read the counters pass 1 left before any ticket is taken
+        if (threadIdx.x < n) h = tree_region_climb(g, lcnt, region, list[threadIdx.x], zt, P);
+    } else {  // a crowded region, entries in rounds of 64: a later round's counters have been taken down by the earlier ones, so its
+              // entries treat every ancestor as shared (ticket at every level; an ancestor nobody else reaches was counted 1, and
+              // whoever takes a counter from 1 to 0 carries on -- the rule of the two-children case covers it)
+        for (u32 j = threadIdx.x; j < n; j += CLIMB_BLOCK) {
+            TreePath P;
+            tree_region_path(g, lcnt, region, list[j], zt, P);
+            P.both = 0xffffffffu;
+            h += tree_region_climb(g, lcnt, region, list[j], zt, P);
+        }
+    }
     if (h) atomicAdd(hashes, (unsigned long long)h);
     if (trace && blockIdx.x < 2048) {
         __syncthreads();

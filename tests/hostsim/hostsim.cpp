@@ -235,7 +235,13 @@ u64 hs_tree_update(int kind, const u8* before, u64 bytes_before, u64 n0_before, 
             x = x * 6364136223846793005ull + 1442695040888963407ull;
             std::swap(list[i - 1], list[(x >> 33) % i]);
         }
-        for (u32 j = 0; j < n; j++) hashes += tree_region_climb(g, lcnt.data(), region, list[j], zt());
+        // k_tree_climb: every lane reads its path (counters as pass 1 left them, siblings as they are NOW) before any lane climbs --
+        // a climb that trusted a stale sibling, or a counter another lane has taken down, shows up here
+        std::vector<TreePath> paths(n);
+        for (u32 j = 0; j < n; j++) tree_region_path(g, lcnt.data(), region, list[j], zt(), paths[j]);
+        if (n > 64)
+            for (u32 j = 0; j < n; j++) paths[j].both = 0xffffffffu;  // (the kernel's crowded-region rule: a ticket at every level)
+        for (u32 j = 0; j < n; j++) hashes += tree_region_climb(g, lcnt.data(), region, list[j], zt(), paths[j]);
         for (u32 c : lcnt) bad += c != 0;
     }
     for (u32 f : flag) bad += f != 0;
