@@ -88,39 +88,61 @@ struct NodeLeaves {
 //   htr(pubkey 48 B) | withdrawal_credentials | effective_balance | slashed |
 //   activation_eligibility_epoch | activation_epoch | exit_epoch | withdrawable_epoch
 // = 1 + 7 hash64 per validator.
+// The validator's root from its record, read through `word(i)` = little-endian dword i of the record (i < 31; the last three
+// bytes of dword 30 belong to the next record and are not used).  Words are asked for right before the hash64 that consumes
+// them, and `word.after(node)` is told each intermediate result: a source that fetches on demand (the LDS-staged registry
+// pass) ties its next fetches to that result, so that no copy of the record sits in registers across the calls.
+template <class Words>
+ECG_HD Node validator_root_from_words(Words& word) {
+    Node a, b;
+#pragma unroll
+    for (int i = 0; i < 8; i++) a.w[i] = ecg_bswap32(word(i));          // pubkey[0..32)
+#pragma unroll
+    for (int i = 0; i < 4; i++) { b.w[i] = ecg_bswap32(word(8 + i)); b.w[4 + i] = 0; }  // pubkey[32..48) || 0^16
+    a = hash64(a, b);
+    word.after(a);
+#pragma unroll
+    for (int i = 0; i < 8; i++) b.w[i] = ecg_bswap32(word(12 + i));   // withdrawal_credentials
+    Node left = hash64(a, b);
+    word.after(left);
+    node_zero(a);
+    node_zero(b);
+    a.w[0] = ecg_bswap32(word(20));                                   // effective_balance u64 LE
+    a.w[1] = ecg_bswap32(word(21));
+    b.w[0] = ecg_bswap32(word(22) & 0xffu);                           // slashed: byte 88
+    left = hash64(left, hash64(a, b));
+    word.after(left);
+    // four u64 epochs at bytes 89,97,105,113: one byte past a dword boundary
+    Node right;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        node_zero(a);
+        node_zero(b);
+        const u32 w0 = word(22 + 4 * k), w1 = word(23 + 4 * k), w2 = word(24 + 4 * k), w3 = word(25 + 4 * k), w4 = word(26 + 4 * k);
+        a.w[0] = ecg_bswap32(funnel_bytes(w0, w1, 1));
+        a.w[1] = ecg_bswap32(funnel_bytes(w1, w2, 1));
+        b.w[0] = ecg_bswap32(funnel_bytes(w2, w3, 1));
+        b.w[1] = ecg_bswap32(funnel_bytes(w3, w4, 1));
+        const Node h = hash64(a, b);
+        word.after(h);
+        right = k == 0 ? h : hash64(right, h);
+    }
+    return hash64(left, right);
+}
+
+struct WordArray31 {
+    u32 d[31];
+    ECG_HD u32 operator()(int i) const { return d[i]; }
+    ECG_HD void after(const Node&) {}
+};
+
 struct ValidatorLeaves {
     const u8* base;  // n * 121 bytes
     u64 total_bytes;
     ECG_HD Node operator()(u64 idx) const {
-        u32 d[31];
-        load_bytes_le<31>(d, base, idx * 121, total_bytes);  // 124 bytes, the last 3 are the next record
-        Node l[8];
-        Node a, b;
-#pragma unroll
-        for (int i = 0; i < 8; i++) a.w[i] = ecg_bswap32(d[i]);          // pubkey[0..32)
-#pragma unroll
-        for (int i = 0; i < 4; i++) { b.w[i] = ecg_bswap32(d[8 + i]); b.w[4 + i] = 0; }  // pubkey[32..48) || 0^16
-        l[0] = hash64(a, b);
-#pragma unroll
-        for (int i = 0; i < 8; i++) l[1].w[i] = ecg_bswap32(d[12 + i]);   // withdrawal_credentials
-#pragma unroll
-        for (int k = 2; k < 8; k++) node_zero(l[k]);
-        l[2].w[0] = ecg_bswap32(d[20]);                                   // effective_balance u64 LE
-        l[2].w[1] = ecg_bswap32(d[21]);
-        l[3].w[0] = ecg_bswap32(d[22] & 0xffu);                           // slashed: byte 88
-        // four u64 epochs at bytes 89,97,105,113: one byte past a dword boundary
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            u32 lo = funnel_bytes(d[22 + 2 * k], d[23 + 2 * k], 1);
-            u32 hi = funnel_bytes(d[23 + 2 * k], d[24 + 2 * k], 1);
-            l[4 + k].w[0] = ecg_bswap32(lo);
-            l[4 + k].w[1] = ecg_bswap32(hi);
-        }
-        Node h01 = hash64(l[0], l[1]);
-        Node h23 = hash64(l[2], l[3]);
-        Node h45 = hash64(l[4], l[5]);
-        Node h67 = hash64(l[6], l[7]);
-        return hash64(hash64(h01, h23), hash64(h45, h67));
+        WordArray31 w;
+        load_bytes_le<31>(w.d, base, idx * 121, total_bytes);  // 124 bytes, the last 3 are the next record
+        return validator_root_from_words(w);
     }
 };
 

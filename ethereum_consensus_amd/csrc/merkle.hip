@@ -1,5 +1,6 @@
 // gfx950 SHA-256 Merkle kernels + host driver + C ABI entry points (see include/ecgpu.h).
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "merkle_driver.h"
@@ -46,6 +47,94 @@ constexpr int PASS_BLOCK = 256;  // 4 waves; one lane = one output node
 template <int D, class Leaf>
 __global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass(Leaf leaf, u64 n_in, u64 n_out, u8* out,
                                                             const ZeroTable* zt, int level0, u64 gid0) {
+    u64 gid = gid0 + (u64)blockIdx.x * PASS_BLOCK + threadIdx.x;
+    if (gid >= n_out) return;
+    lane_pass<D, Leaf>(leaf, gid, n_in, out, zt, level0);
+}
+
+// The registry's leaf pass (D = 2: a lane = four validators = one level-2 node).  In the generic pass a lane reads its own 484
+// contiguous bytes, 124 at a time with three root computations in between: neighbouring lanes share every cache line, the
+// line's other users come tens of microseconds later, and by then it has left the L1 and the XCD's L2 -- the pass fetched
+// 1.39 x the records (PMC, round 4).  Here a WAVE takes its 256 records in four steps of 64 x 121 = 7 744 contiguous bytes:
+// 16-byte lane loads into LDS (fully coalesced, every line fetched once and consumed at once), lane i hashes record 64 k + i
+// out of LDS, and the 256 roots are transposed through the same LDS so that lane j ends up with records 4 j .. 4 j + 3.
+constexpr u32 VAL_STEP_BYTES = 64 * 121;               // = 484 x 16
+constexpr u32 VAL_STAGE_VECS = VAL_STEP_BYTES / 16 + 1;  // + the vector the step's misalignment spills into
+
+// a record in the stage, read a dword pair at a time where the words are used
+struct StagedRecord {
+    const u32* stage;  // the wave's stage (LDS)
+    u32 at;            // the aligned dword that holds the record's first byte
+    u32 sh;            // ... and that byte's position in it
+    __device__ __forceinline__ u32 operator()(int i) const {
+        // (dword 30 is asked for its first byte only: the dword after it, which may lie past the stage, is never needed)
+        return i < 30 ? funnel_bytes(stage[at + i], stage[at + i + 1], sh) : funnel_bytes(stage[at + 30], 0u, sh);
+    }
+    __device__ __forceinline__ void after(const Node& n) {
+        // the next fetches "depend" on the hash just computed: they stay behind the call (hash64 is pure, and without this the
+        // compiler reads the whole record up front and carries 31 words across seven calls)
+        asm volatile("" : "+v"(at) : "v"(n.w[0]));
+    }
+};
+
+template <>
+__global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass<2, ValidatorLeaves>(ValidatorLeaves leaf, u64 n_in, u64 n_out, u8* out,
+                                                                                const ZeroTable* zt, int level0, u64 gid0) {
+    __shared__ uint4 stage[PASS_BLOCK / 64][VAL_STAGE_VECS];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 out0 = gid0 + (u64)blockIdx.x * PASS_BLOCK + wave * 64;  // the wave's first output node
+    const u64 v0 = out0 << 2;
+    if (out0 + 64 > n_out || v0 + 256 > n_in) return;  // (launch_pass sends whole waves only; the ragged rest goes to k_merkle_pass_rest)
+    const u8* src = leaf.base + v0 * 121;
+    const u32 adj = (u32)((u64)src & 15);  // the same in every step: a step is a multiple of 16 bytes
+    const uint4* vsrc = reinterpret_cast<const uint4*>(src - adj);
+    uint4* st = stage[wave];
+    Node r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint4* g = vsrc + (VAL_STEP_BYTES / 16) * k;
+        const uint4 v0_ = g[lane], v1_ = g[lane + 64], v2_ = g[lane + 128], v3_ = g[lane + 192], v4_ = g[lane + 256], v5_ = g[lane + 320],
+                    v6_ = g[lane + 384];
+        // vectors 448 .. 484: the last one exists only where the step is misaligned (then it holds bytes of the step: mapped memory)
+        uint4 v7_ = uint4{0, 0, 0, 0};
+        if (lane + 448 < VAL_STAGE_VECS - 1 || (lane + 448 == VAL_STAGE_VECS - 1 && adj)) v7_ = g[lane + 448];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the previous step's reads of the stage are done)
+        __builtin_amdgcn_wave_barrier();
+        st[lane] = v0_, st[lane + 64] = v1_, st[lane + 128] = v2_, st[lane + 192] = v3_, st[lane + 256] = v4_, st[lane + 320] = v5_,
+        st[lane + 384] = v6_;
+        if (lane + 448 < VAL_STAGE_VECS) st[lane + 448] = v7_;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u32 o = adj + 121 * lane;
+        StagedRecord rec{reinterpret_cast<const u32*>(st), o >> 2, o & 3};
+        r[k] = validator_root_from_words(rec);
+    }
+    // roots: lane i holds records 64 k + i; lane j wants 4 j .. 4 j + 3.  Word-major through the stage, four words at a time.
+    u32* tw = reinterpret_cast<u32*>(st);
+    Node c[4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) tw[256 * w + 64 * k + lane] = r[k].w[4 * h + w];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint4 x = reinterpret_cast<const uint4*>(tw + 256 * w)[lane];
+            c[0].w[4 * h + w] = x.x, c[1].w[4 * h + w] = x.y, c[2].w[4 * h + w] = x.z, c[3].w[4 * h + w] = x.w;
+        }
+    }
+    node_store(hash64(hash64(c[0], c[1]), hash64(c[2], c[3])), out + (out0 + lane) * 32);
+}
+
+// the generic pass under a second name: the waves that the registry's staged pass does not take (its ragged end)
+template <int D, class Leaf>
+__global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass_rest(Leaf leaf, u64 n_in, u64 n_out, u8* out, const ZeroTable* zt, int level0,
+                                                                 u64 gid0) {
     u64 gid = gid0 + (u64)blockIdx.x * PASS_BLOCK + threadIdx.x;
     if (gid >= n_out) return;
     lane_pass<D, Leaf>(leaf, gid, n_in, out, zt, level0);
@@ -344,6 +433,21 @@ static int launch_pass(hipStream_t s, int D, const Leaf& leaf, u64 n_in, u64 n_o
     dim3 grid((unsigned)((gid1 - gid0 + PASS_BLOCK - 1) / PASS_BLOCK)), block(PASS_BLOCK);
     const ZeroTable* zt = device_zero_table();
     ProfScope ps(tag, s);
+    if constexpr (std::is_same<Leaf, ValidatorLeaves>::value) {
+        if (D == 2 && gid0 % 64 == 0) {
+            // whole waves (64 nodes = 256 records, all present) to the LDS-staged pass, the ragged end to the generic one
+            const u64 whole = n_in / 4 < gid1 ? n_in / 4 : gid1;
+            const u64 mid = whole > gid0 ? gid0 + (whole - gid0) / 64 * 64 : gid0;
+            if (mid > gid0)
+                hipLaunchKernelGGL((k_merkle_pass<2, Leaf>), dim3((unsigned)((mid - gid0 + PASS_BLOCK - 1) / PASS_BLOCK)), block, 0, s, leaf, n_in,
+                                   mid, out, zt, level0, gid0);
+            if (gid1 > mid)
+                hipLaunchKernelGGL((k_merkle_pass_rest<2, Leaf>), dim3((unsigned)((gid1 - mid + PASS_BLOCK - 1) / PASS_BLOCK)), block, 0, s, leaf,
+                                   n_in, n_out, out, zt, level0, mid);
+            ECG_HIP_CHECK(hipGetLastError());
+            return ECGPU_SUCCESS;
+        }
+    }
     switch (D) {
         case 0: hipLaunchKernelGGL((k_merkle_pass<0, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;
         case 1: hipLaunchKernelGGL((k_merkle_pass<1, Leaf>), grid, block, 0, s, leaf, n_in, n_out, out, zt, level0, gid0); break;

@@ -406,7 +406,7 @@ int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes
 int ecgpu_resident_state_create_fork(int fork, int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (!ssz || !out || preset < 0 || preset > 1 || fork < FORK_ALTAIR || fork > FORK_DENEB ||
+    if (!ssz || !out || preset < 0 || preset > 1 || fork < FORK_ALTAIR || fork > FORK_LAST ||
         n_bytes < layout_for(STATE_PRESETS[preset], fork).size)
         return ECGPU_ERR_BAD_ARG;  // phase0 states hold lists of variable-size elements: host entry only
     StatePlan plan;
@@ -441,13 +441,15 @@ struct VarField {
     u64 word;
     u32 elem;
 };
-static int var_fields(const ecgpu_resident_state* st, VarField out[9]) {
+constexpr int N_VAR_FIELDS = 12;  // (9 .. 11: electra's three lists of pending operations, electra/beacon_state.rs:133-137)
+static int var_fields(const ecgpu_resident_state* st, VarField out[N_VAR_FIELDS]) {
     const FixedLayout L = layout_for(STATE_PRESETS[st->preset], st->fork);
-    const VarField f[9] = {{L.historical_roots_off, 32}, {L.eth1_data_votes_off, 72}, {L.validators_off, 121}, {L.balances_off, 8},
-                           {L.prev_participation_off, 1}, {L.cur_participation_off, 1}, {L.inactivity_scores_off, 8},
-                           {L.payload_header_off, 0}, {L.historical_summaries_off, 64}};
-    for (int i = 0; i < 9; i++) out[i] = f[i];
-    return 9;
+    const VarField f[N_VAR_FIELDS] = {{L.historical_roots_off, 32}, {L.eth1_data_votes_off, 72}, {L.validators_off, 121}, {L.balances_off, 8},
+                                      {L.prev_participation_off, 1}, {L.cur_participation_off, 1}, {L.inactivity_scores_off, 8},
+                                      {L.payload_header_off, 0}, {L.historical_summaries_off, 64}, {L.pending_balance_deposits_off, 16},
+                                      {L.pending_partial_withdrawals_off, 24}, {L.pending_consolidations_off, 16}};
+    for (int i = 0; i < N_VAR_FIELDS; i++) out[i] = f[i];
+    return N_VAR_FIELDS;
 }
 static void wr32(u8* p, u32 v) {
     p[0] = (u8)v, p[1] = (u8)(v >> 8), p[2] = (u8)(v >> 16), p[3] = (u8)(v >> 24);
@@ -480,15 +482,15 @@ static int splice(ecgpu_resident_state* st, hipStream_t s, Arena& ar, u64 pos, u
 }
 // change the byte length of variable field `fi` to new_len (append `data` when it grows, drop the tail when it shrinks)
 static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 add_len, u64 new_len_or_keep, bool truncate) {
-    VarField vf[9];
+    VarField vf[N_VAR_FIELDS];
     var_fields(st, vf);
-    if (fi < 0 || fi >= 9 || vf[fi].word == NO_FIELD || vf[fi].elem == 0) {
+    if (fi < 0 || fi >= N_VAR_FIELDS || vf[fi].word == NO_FIELD || vf[fi].elem == 0) {
         set_last_error("not a variable-length list of this fork");
         return ECGPU_ERR_BAD_ARG;
     }
     const u64 start = rd32(st->h_fixed.data() + vf[fi].word);
     u64 end = st->n_bytes;
-    for (int k = fi + 1; k < 9; k++)
+    for (int k = fi + 1; k < N_VAR_FIELDS; k++)
         if (vf[k].word != NO_FIELD) {
             end = rd32(st->h_fixed.data() + vf[k].word);
             break;
@@ -503,14 +505,25 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
         pos = end, remove = 0, insert = add_len;
     }
     if (remove == 0 && insert == 0) return ECGPU_SUCCESS;
+    const int64_t delta = (int64_t)insert - (int64_t)remove;
+    {  // the resized state must still be a valid state of this fork (a list past its limit is not): checked on a copy of the
+       // fixed part BEFORE anything moves, so a refused call leaves the resident state as it was
+        std::vector<u8> probe(st->h_fixed);
+        for (int k = fi + 1; k < N_VAR_FIELDS; k++)
+            if (vf[k].word != NO_FIELD) wr32(probe.data() + vf[k].word, (u32)((int64_t)rd32(probe.data() + vf[k].word) + delta));
+        StatePlan would_be;
+        if (!build_state_plan(st->fork, probe.data(), (u64)((int64_t)st->n_bytes + delta), st->preset, would_be, nullptr, nullptr)) {
+            set_last_error(would_be.error);
+            return ECGPU_ERR_BAD_ARG;
+        }
+    }
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
     Arena& ar = c->arena(s);
     int rc = splice(st, s, ar, pos, remove, data, insert);
     if (rc) return rc;
     // later fields start `insert - remove` bytes later: their offset words change on the host mirror and on the device
-    const int64_t delta = (int64_t)insert - (int64_t)remove;
-    for (int k = fi + 1; k < 9; k++)
+    for (int k = fi + 1; k < N_VAR_FIELDS; k++)
         if (vf[k].word != NO_FIELD) {
             const u32 v = (u32)((int64_t)rd32(st->h_fixed.data() + vf[k].word) + delta);
             wr32(st->h_fixed.data() + vf[k].word, v);
@@ -523,7 +536,7 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
         set_last_error(plan.error);
         return ECGPU_ERR_BAD_ARG;
     }
-    static const u32 field_chunk[9] = {7, 9, 11, 12, 15, 16, 21, 0, 27};  // var_fields order -> field-root chunk of the list
+    static const u32 field_chunk[N_VAR_FIELDS] = {7, 9, 11, 12, 15, 16, 21, 0, 27, 34, 35, 36};  // var_fields order -> field-root chunk of the list
     u32 slot = TREE_MAX_FIELDS;
     for (u32 k = 0; k < plan.bigs.size() && k < TREE_MAX_FIELDS; k++)
         if (plan.bigs[k].out_chunk == field_chunk[fi] && plan.bigs[k].mix) slot = k;
@@ -606,8 +619,9 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     }
     // the variable-size lists keep their lengths: a patch must not rewrite the offset words of the fixed part
     const FixedLayout L = layout_for(STATE_PRESETS[st->preset], st->fork);
-    u64 off_words[10] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off, L.prev_participation_off,
-                         L.cur_participation_off, L.inactivity_scores_off, L.payload_header_off, L.historical_summaries_off, NO_FIELD};
+    u64 off_words[13] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off, L.prev_participation_off,
+                         L.cur_participation_off, L.inactivity_scores_off, L.payload_header_off, L.historical_summaries_off, NO_FIELD,
+                         L.pending_balance_deposits_off, L.pending_partial_withdrawals_off, L.pending_consolidations_off};
     // ... and the one offset word INSIDE the payload header (extra_data): the reference's deserializer rejects any other value
     if (L.payload_header_off != NO_FIELD) off_words[9] = rd32(st->h_fixed.data() + L.payload_header_off) + PAYLOAD_EXTRA_DATA_OFFSET_WORD;
     for (u32 i = 0; i < n; i++)

@@ -126,7 +126,7 @@ def hash_tree_root_beacon_state(fork, ssz: bytes, preset: int = MAINNET) -> byte
 
 
 class ResidentBeaconStateDeneb:
-    """A BeaconState (deneb unless `fork` says altair / bellatrix / capella) kept in HBM: uploaded once, then patched in place with the bytes a block changed and
+    """A BeaconState (deneb unless `fork` says altair / bellatrix / capella / electra) kept in HBM: uploaded once, then patched in place with the bytes a block changed and
     re-Merkleized on the device (the reference re-hashes the host-resident state every slot,
     phase0/slot_processing.rs:67)."""
 
@@ -170,6 +170,7 @@ class ResidentBeaconStateDeneb:
 
     VALIDATORS, BALANCES, PREVIOUS_EPOCH_PARTICIPATION, CURRENT_EPOCH_PARTICIPATION, INACTIVITY_SCORES = 2, 3, 4, 5, 6
     HISTORICAL_ROOTS, ETH1_DATA_VOTES, HISTORICAL_SUMMARIES = 0, 1, 8
+    PENDING_BALANCE_DEPOSITS, PENDING_PARTIAL_WITHDRAWALS, PENDING_CONSOLIDATIONS = 9, 10, 11  # electra
 
     def append(self, field: int, data: bytes) -> None:
         """whole elements appended to a variable-length list of the state (a new validator = five appends)"""

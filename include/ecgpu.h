@@ -123,7 +123,7 @@ uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);
 #define ECGPU_FORK_DENEB 4
 /* electra as this revision of the reference defines it (electra/beacon_state.rs:73-145: 37 fields, three lists of pending
  * operations; electra/execution_payload.rs:54-84: a 19-field payload header): the host-pointer entry, the _dev entries and
- * the sharded form; resident states stop at deneb. */
+ * the sharded form and, since round 5, resident states. */
 #define ECGPU_FORK_ELECTRA 5
 int ecgpu_htr_beacon_state(int fork, const uint8_t* ssz, uint64_t n_bytes, int preset, uint8_t root[32]);
 int ecgpu_htr_beacon_state_dev(int fork, const uint8_t* d_ssz, uint64_t n_bytes, const uint8_t* h_fixed, int preset,
@@ -189,6 +189,9 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
 #define ECGPU_STATE_CURRENT_EPOCH_PARTICIPATION 5
 #define ECGPU_STATE_INACTIVITY_SCORES 6
 #define ECGPU_STATE_HISTORICAL_SUMMARIES 8
+#define ECGPU_STATE_PENDING_BALANCE_DEPOSITS 9      /* electra: 16-byte records */
+#define ECGPU_STATE_PENDING_PARTIAL_WITHDRAWALS 10  /* electra: 24-byte records */
+#define ECGPU_STATE_PENDING_CONSOLIDATIONS 11       /* electra: 16-byte records */
 int ecgpu_resident_state_append(ecgpu_resident_state_t* st, int field, const uint8_t* data, uint64_t n_bytes);
 int ecgpu_resident_state_truncate(ecgpu_resident_state_t* st, int field, uint64_t new_n_bytes);
 uint64_t ecgpu_resident_state_size(const ecgpu_resident_state_t* st);

@@ -92,6 +92,31 @@ def test_validator_list(gpu, n):
         assert gpu.hash_tree_root_validators(enc) == ossz.SSZList(ossz.Validator, 1 << 40).htr(vs)
 
 
+def test_staged_registry_pass_at_every_alignment_and_with_ragged_ends(gpu):
+    """The registry pass of 2^20 .. 2^21 validators (csrc/merkle.hip k_merkle_pass<2, ValidatorLeaves>: 16-byte lane loads into
+    LDS, whole waves of 256 records; the ragged end goes to the generic pass): the same records at all 16 byte alignments of the
+    device pointer, and lengths that end inside a wave, inside a lane's four records, and on a wave boundary."""
+    import torch
+    from ethereum_consensus_amd import _lib, synthetic as S
+    L = _lib.load()
+    n_max = (1 << 20) + 256 + 3
+    data = S.validators(n_max, seed=11).tobytes()
+    t = torch.frombuffer(bytearray(bytes(32) + data + bytes(32)), dtype=torch.uint8).cuda()
+    shifted = torch.empty(32 + len(data) + 64, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    lens = [1 << 20, (1 << 20) + 1, (1 << 20) + 255, (1 << 20) + 256, n_max]
+    want = {n: cref.htr_validators(data[:121 * n])[0] for n in lens}
+    for mis in range(16):
+        shifted[mis:mis + len(data)] = t[32:32 + len(data)]
+        torch.cuda.synchronize()  # (torch's default stream is the null handle here: the library would run on a stream of its own)
+        for n in (lens if mis in (0, 5) else lens[:1] + lens[-1:]):
+            rc = L.ecgpu_htr_validators_dev(shifted.data_ptr() + mis, n, 1 << 40, out.data_ptr(), st)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert bytes(out.cpu().numpy()) == want[n], (mis, n)
+
+
 def test_device_resident_unaligned_slices(gpu):
     """_dev entry points on byte-unaligned slices of a device buffer (what the state driver does)."""
     import torch
@@ -763,9 +788,11 @@ def test_resident_state_lists_change_length(gpu):
 
 # ---- the resident state's trees re-hash dirty paths only (csrc/state_tree.h) --------------------------
 VAR_INDEX = {"historical_roots": 0, "eth1_data_votes": 1, "validators": 2, "balances": 3, "previous_epoch_participation": 4,
-             "current_epoch_participation": 5, "inactivity_scores": 6, "historical_summaries": 8}
+             "current_epoch_participation": 5, "inactivity_scores": 6, "historical_summaries": 8, "pending_balance_deposits": 9,
+             "pending_partial_withdrawals": 10, "pending_consolidations": 11}
 ELEM = {"historical_roots": 32, "eth1_data_votes": 72, "validators": 121, "balances": 8, "previous_epoch_participation": 1,
-        "current_epoch_participation": 1, "inactivity_scores": 8, "historical_summaries": 64}
+        "current_epoch_participation": 1, "inactivity_scores": 8, "historical_summaries": 64, "pending_balance_deposits": 16,
+        "pending_partial_withdrawals": 24, "pending_consolidations": 16}
 
 
 def _random_step(r, st, m, fork):
@@ -812,13 +839,15 @@ def _random_step(r, st, m, fork):
             m.var["current_epoch_participation"] += b"\x00"
             m.var["inactivity_scores"] += bytes(8)
     elif op == "append":  # an eth1 vote per block, a summary / root per period
-        name = r.choice([n for n in ("eth1_data_votes", "historical_roots", "historical_summaries") if n in m.var])
+        name = r.choice([n for n in ("eth1_data_votes", "historical_roots", "historical_summaries", "pending_balance_deposits",
+                                     "pending_partial_withdrawals", "pending_consolidations") if n in m.var])
         data = r.randbytes(ELEM[name] * r.choice([1, 1, 3]))
-        if len(m.var[name]) + len(data) <= ELEM[name] * (32 if name == "eth1_data_votes" else 1 << 20):  # (minimal preset: 32 votes)
+        if len(m.var[name]) + len(data) <= ELEM[name] * min(getattr(m, "limits", {}).get(name, 1 << 20), 32 if name == "eth1_data_votes" else 1 << 20):
             st.append(VAR_INDEX[name], data)
             m.var[name] += data
     elif op == "truncate":  # the eth1_data_votes reset; a list cut to a shorter length
-        name = r.choice([n for n in ("eth1_data_votes", "historical_roots", "balances") if n in m.var])
+        name = r.choice([n for n in ("eth1_data_votes", "historical_roots", "balances", "pending_balance_deposits", "pending_consolidations")
+                         if n in m.var])
         if name == "balances":
             return op  # (balances never shrink on their own: only together with the registry -- not modelled)
         keep = ELEM[name] * r.randrange(0, len(m.var[name]) // ELEM[name] + 1)
@@ -841,9 +870,10 @@ def _random_step(r, st, m, fork):
 
 @pytest.mark.parametrize("fork,preset,n_val,steps", [("altair", "minimal", 700, 170), ("bellatrix", "minimal", 1100, 170),
                                                       ("capella", "mainnet", 2500, 170), ("deneb", "minimal", 37, 170),
-                                                      ("deneb", "mainnet", 5000, 170), ("deneb", "minimal", 2040, 170)])
+                                                      ("deneb", "mainnet", 5000, 170), ("deneb", "minimal", 2040, 170),
+                                                      ("electra", "minimal", 900, 170)])
 def test_resident_state_randomised_patch_append_truncate_sequences(gpu, fork, preset, n_val, steps):
-    """1 020 randomised steps over every resident fork: after EVERY step the resident root (dirty paths climbed, rebuilt fields,
+    """1 190 randomised steps over every resident fork (altair ... electra): after EVERY step the resident root (dirty paths climbed, rebuilt fields,
     finishing jobs over the cached levels) equals ecgpu_htr_beacon_state of the re-serialized state, computed from scratch."""
     from ethereum_consensus_amd import synthetic
     from tests._statemodel import EncodingModel
@@ -857,6 +887,7 @@ def test_resident_state_randomised_patch_append_truncate_sequences(gpu, fork, pr
     pid = ssz.MINIMAL if preset == "minimal" else ssz.MAINNET
     st = ssz.ResidentBeaconStateDeneb(enc, pid, fork=fork)
     m = EncodingModel(t, enc)
+    m.limits = {n: ty.limit for n, ty in t.fields if hasattr(ty, "limit")}  # (an append past a list's limit is an error, tested elsewhere)
     assert m.encoding() == enc
     assert st.hash_tree_root() == t.htr(v)
     seen = set()
@@ -871,6 +902,32 @@ def test_resident_state_randomised_patch_append_truncate_sequences(gpu, fork, pr
     cur = m.encoding()
     assert st.hash_tree_root() == ssz.hash_tree_root_beacon_state(fork, cur, pid)
     assert {"patch", "add_validator", "rewrite", "rotate", "fixed"} <= seen
+    st.close()
+
+
+def test_resident_electra_state_refuses_an_append_past_a_list_limit_and_stays_as_it_was(gpu):
+    """electra/beacon_state.rs:73-145 (minimal preset: PENDING_PARTIAL_WITHDRAWALS_LIMIT = 64): the 65th record is refused
+    before anything moves; the root and the size afterwards are those before the call, and the next legal append works."""
+    from ethereum_consensus_amd import synthetic
+    ssz = gpu
+    r = random.Random(77)
+    f = synthetic.state_fields(300, "minimal", seed=3)
+    f["_preset"] = "minimal"
+    t, v = _fork_state_value("electra", f, r)
+    v["pending_partial_withdrawals"] = [{"index": i, "amount": 5, "withdrawable_epoch": 9} for i in range(63)]
+    enc = t.serialize(v)
+    st = ssz.ResidentBeaconStateDeneb(enc, ssz.MINIMAL, fork="electra")
+    root0 = st.hash_tree_root()
+    assert root0 == t.htr(v)
+    with pytest.raises(Exception):
+        st.append(ssz.ResidentBeaconStateDeneb.PENDING_PARTIAL_WITHDRAWALS, bytes(48))  # 63 + 2 > 64
+    assert len(st) == len(enc) and st.hash_tree_root() == root0
+    st.append(ssz.ResidentBeaconStateDeneb.PENDING_PARTIAL_WITHDRAWALS, (7).to_bytes(8, "little") * 3)
+    v["pending_partial_withdrawals"].append({"index": 7, "amount": 7, "withdrawable_epoch": 7})
+    assert st.hash_tree_root() == t.htr(v)
+    st.truncate(ssz.ResidentBeaconStateDeneb.PENDING_PARTIAL_WITHDRAWALS, 24)  # the queue processed down to one record
+    v["pending_partial_withdrawals"] = v["pending_partial_withdrawals"][:1]
+    assert st.hash_tree_root() == t.htr(v)
     st.close()
 
 
