@@ -109,6 +109,9 @@ inline MerkleSchedule schedule_merkleize(LeafKind kind, u64 n0, u32 depth, bool 
     // per root against 1.09: profiles/r03j_merkle_prepass_kernel_stats.txt.  Not kept.)
     while (n > 0 && ((first && kind == LEAF_VALIDATORS) || n > TILE_MAX_IN)) {
         int D = choose_pass_height(n, background);
+        // (round 5) the registry's leaf pass is the LDS-staged one (merkle.hip k_merkle_pass<2, ValidatorLeaves>: four records per
+        // lane) however long the registry: taller lanes would hold 8 or 16 roots across the calls
+        if (first && kind == LEAF_VALIDATORS && D > 2) D = 2;
         if ((u32)D > depth - level) D = (int)(depth - level);
         if (!first && D == 0) break;
         push_pass(D);

@@ -117,6 +117,16 @@ def test_staged_registry_pass_at_every_alignment_and_with_ragged_ends(gpu):
             assert bytes(out.cpu().numpy()) == want[n], (mis, n)
 
 
+def test_staged_registry_pass_beyond_two_million_validators(gpu):
+    """2^21 + 77 validators (mainnet's registry is about to pass 2^21): the leaf pass stays the staged one, four records per lane"""
+    from ethereum_consensus_amd import synthetic as S
+    n = (1 << 21) + 77
+    enc = S.validators(n, seed=21).tobytes()
+    want, h = cref.htr_validators(enc)
+    assert gpu.hash_tree_root_validators(enc) == want
+    assert gpu.last_hash64_count() == h
+
+
 def test_device_resident_unaligned_slices(gpu):
     """_dev entry points on byte-unaligned slices of a device buffer (what the state driver does)."""
     import torch
