@@ -20,7 +20,8 @@ if "block" in d:
     print("  block", round(d["block"]["reference_semantics"]["block_verify_ms"], 2), round(d["block"]["validated_key_registry"]["block_verify_ms"], 2),
           {k: round(v, 2) for k, v in d["block"].get("scalar_call", {}).items() if isinstance(v, (int, float))})
 if "msm" in d:
-    print("  msm", {k: (round(v["ms"], 2), round(v["points_per_s"])) for k, v in d["msm"].items() if k.startswith("g1_")}, d["msm"]["check"])
+    print("  msm", {k: (round(v["ms"], 2), round(v["points_per_s"])) for k, v in d["msm"].items() if k.startswith("g1_") and isinstance(v, dict) and "ms" in v},
+          d["msm"].get("check"))
 if "box_selfcheck" in d:
     print("  box slowdown", round(d["box_selfcheck"]["large_code_slowdown"], 2), d["box_selfcheck"]["pairing_kernels"])
 if "merkle" in d and d["merkle"].get("h2d_inclusive"):
