@@ -75,6 +75,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_resident_state_patch": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, u8p, c_u32]),
         "ecgpu_resident_state_append": (c_int, [ctypes.c_void_p, c_int, u8p, c_u64]),
         "ecgpu_resident_state_truncate": (c_int, [ctypes.c_void_p, c_int, c_u64]),
+        "ecgpu_resident_state_replace": (c_int, [ctypes.c_void_p, c_int, u8p, c_u64]),
         "ecgpu_resident_state_size": (c_u64, [ctypes.c_void_p]),
         "ecgpu_resident_state_root": (c_int, [ctypes.c_void_p, u8p]),
         "ecgpu_resident_state_root_dev": (c_int, [ctypes.c_void_p, u8p, ctypes.c_void_p]),

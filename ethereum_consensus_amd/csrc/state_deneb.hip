@@ -393,11 +393,18 @@ struct ecgpu_resident_state {
     hipStream_t patch_stream = nullptr;
     hipEvent_t rooted = nullptr;   // recorded behind the last root: a patch on another stream waits for it before it overwrites bytes
     hipStream_t root_stream = nullptr;
+    // phase0: the roots of previous / current_epoch_attestations (lists of variable-size elements: rooted through the generic
+    // planner when the state is created and whenever ecgpu_resident_state_replace hands a list over -- on the host side of
+    // the call, where its bytes are; the state root takes the two nodes as they are)
+    u8 att_roots[64] = {};
+    const u8* ext_roots() const { return fork == ecg::FORK_PHASE0 ? att_roots : nullptr; }
 };
 
 using namespace ecg;
 
 extern "C" {
+
+static int pending_attestations_root(const u8* ssz, u64 n_bytes, int preset, u8 root[32]);
 
 int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out) {
     return ecgpu_resident_state_create_fork(ECGPU_FORK_DENEB, preset, ssz, n_bytes, out);
@@ -406,16 +413,28 @@ int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes
 int ecgpu_resident_state_create_fork(int fork, int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (!ssz || !out || preset < 0 || preset > 1 || fork < FORK_ALTAIR || fork > FORK_LAST ||
+    if (!ssz || !out || preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_LAST ||
         n_bytes < layout_for(STATE_PRESETS[preset], fork).size)
-        return ECGPU_ERR_BAD_ARG;  // phase0 states hold lists of variable-size elements: host entry only
+        return ECGPU_ERR_BAD_ARG;
+    u8 att[64] = {};
+    if (fork == FORK_PHASE0) {  // (round 5) the two PendingAttestation lists: rooted here, from the caller's bytes
+        const FixedLayout L = layout_for(STATE_PRESETS[preset], fork);
+        const u64 a = rd32(ssz + L.prev_attestations_off), b = rd32(ssz + L.cur_attestations_off);
+        if (a > b || b > n_bytes || a < L.size) {
+            set_last_error("SSZ offsets not monotonic");
+            return ECGPU_ERR_BAD_ARG;
+        }
+        if ((rc = pending_attestations_root(ssz + a, b - a, preset, att))) return rc;
+        if ((rc = pending_attestations_root(ssz + b, n_bytes - b, preset, att + 32))) return rc;
+    }
     StatePlan plan;
-    if (!build_state_plan(fork, ssz, n_bytes, preset, plan, nullptr,
+    if (!build_state_plan(fork, ssz, n_bytes, preset, plan, fork == FORK_PHASE0 ? att : nullptr,
                           fork >= FORK_BELLATRIX ? ssz + rd32(ssz + layout_for(STATE_PRESETS[preset], fork).payload_header_off) : nullptr)) {
         set_last_error(plan.error);
         return ECGPU_ERR_BAD_ARG;
     }
     ecgpu_resident_state* st = new ecgpu_resident_state();
+    std::memcpy(st->att_roots, att, 64);
     st->preset = preset;
     st->fork = fork;
     st->n_bytes = n_bytes;
@@ -444,8 +463,11 @@ struct VarField {
 constexpr int N_VAR_FIELDS = 12;  // (9 .. 11: electra's three lists of pending operations, electra/beacon_state.rs:133-137)
 static int var_fields(const ecgpu_resident_state* st, VarField out[N_VAR_FIELDS]) {
     const FixedLayout L = layout_for(STATE_PRESETS[st->preset], st->fork);
+    // (slots 4 and 5 of a phase0 state: the PendingAttestation lists, element size 0 = variable -- ecgpu_resident_state_replace only)
+    const bool p0 = st->fork == FORK_PHASE0;
     const VarField f[N_VAR_FIELDS] = {{L.historical_roots_off, 32}, {L.eth1_data_votes_off, 72}, {L.validators_off, 121}, {L.balances_off, 8},
-                                      {L.prev_participation_off, 1}, {L.cur_participation_off, 1}, {L.inactivity_scores_off, 8},
+                                      {p0 ? L.prev_attestations_off : L.prev_participation_off, p0 ? 0u : 1u},
+                                      {p0 ? L.cur_attestations_off : L.cur_participation_off, p0 ? 0u : 1u}, {L.inactivity_scores_off, 8},
                                       {L.payload_header_off, 0}, {L.historical_summaries_off, 64}, {L.pending_balance_deposits_off, 16},
                                       {L.pending_partial_withdrawals_off, 24}, {L.pending_consolidations_off, 16}};
     for (int i = 0; i < N_VAR_FIELDS; i++) out[i] = f[i];
@@ -481,12 +503,20 @@ static int splice(ecgpu_resident_state* st, hipStream_t s, Arena& ar, u64 pos, u
     return ECGPU_SUCCESS;
 }
 // change the byte length of variable field `fi` to new_len (append `data` when it grows, drop the tail when it shrinks)
-static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 add_len, u64 new_len_or_keep, bool truncate) {
+enum ResizeMode { RESIZE_APPEND, RESIZE_TRUNCATE, RESIZE_REPLACE };
+static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 add_len, u64 new_len_or_keep, ResizeMode mode) {
+    const bool truncate = mode == RESIZE_TRUNCATE, replace = mode == RESIZE_REPLACE;
     VarField vf[N_VAR_FIELDS];
     var_fields(st, vf);
-    if (fi < 0 || fi >= N_VAR_FIELDS || vf[fi].word == NO_FIELD || vf[fi].elem == 0) {
-        set_last_error("not a variable-length list of this fork");
+    const bool attestations = st->fork == FORK_PHASE0 && (fi == 4 || fi == 5);
+    if (fi < 0 || fi >= N_VAR_FIELDS || vf[fi].word == NO_FIELD || (vf[fi].elem == 0 && !(replace && attestations))) {
+        set_last_error(attestations ? "a list of variable-size elements changes through ecgpu_resident_state_replace" : "not a variable-length list of this fork");
         return ECGPU_ERR_BAD_ARG;
+    }
+    u8 new_att_root[32];
+    if (attestations) {  // the list's root, from the caller's bytes (which also validates the encoding), before anything moves
+        int rc_att = pending_attestations_root(data ? data : (const u8*)"", add_len, st->preset, new_att_root);
+        if (rc_att) return rc_att;
     }
     const u64 start = rd32(st->h_fixed.data() + vf[fi].word);
     u64 end = st->n_bytes;
@@ -500,6 +530,9 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
     if (truncate) {
         if (new_len_or_keep > cur || new_len_or_keep % vf[fi].elem) return ECGPU_ERR_BAD_ARG;
         pos = start + new_len_or_keep, remove = cur - new_len_or_keep, insert = 0;
+    } else if (replace) {
+        if ((vf[fi].elem && add_len % vf[fi].elem) || (!data && add_len)) return ECGPU_ERR_BAD_ARG;
+        pos = start, remove = cur, insert = add_len;
     } else {
         if (add_len % vf[fi].elem || (!data && add_len)) return ECGPU_ERR_BAD_ARG;
         pos = end, remove = 0, insert = add_len;
@@ -512,7 +545,11 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
         for (int k = fi + 1; k < N_VAR_FIELDS; k++)
             if (vf[k].word != NO_FIELD) wr32(probe.data() + vf[k].word, (u32)((int64_t)rd32(probe.data() + vf[k].word) + delta));
         StatePlan would_be;
-        if (!build_state_plan(st->fork, probe.data(), (u64)((int64_t)st->n_bytes + delta), st->preset, would_be, nullptr, nullptr)) {
+        u8 ext_probe[64];
+        std::memcpy(ext_probe, st->att_roots, 64);
+        if (attestations) std::memcpy(ext_probe + 32 * (fi - 4), new_att_root, 32);
+        if (!build_state_plan(st->fork, probe.data(), (u64)((int64_t)st->n_bytes + delta), st->preset, would_be,
+                              st->fork == FORK_PHASE0 ? ext_probe : nullptr, nullptr)) {
             set_last_error(would_be.error);
             return ECGPU_ERR_BAD_ARG;
         }
@@ -531,8 +568,9 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
         }
     // the trees follow: every field's offset may have moved; the resized field's new entries are marked dirty (a field whose
     // height changed, or that shrank, is rebuilt at the next root)
+    if (attestations) std::memcpy(st->att_roots + 32 * (fi - 4), new_att_root, 32);
     StatePlan plan;
-    if (!build_state_plan(st->fork, st->h_fixed.data(), st->n_bytes, st->preset, plan, nullptr, nullptr)) {
+    if (!build_state_plan(st->fork, st->h_fixed.data(), st->n_bytes, st->preset, plan, st->ext_roots(), nullptr)) {
         set_last_error(plan.error);
         return ECGPU_ERR_BAD_ARG;
     }
@@ -547,7 +585,7 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
     if (rc) return rc;
     if (was_live && st->trees.f[slot].live && !st->trees.f[slot].all_dirty && st->trees.f[slot].g.H == old_H) {
         FieldTree& t = st->trees.f[slot];
-        if (truncate) {
+        if (truncate || replace) {
             t.all_dirty = true;
         } else {
             const u64 rec = leaf_record_bytes((LeafKind)t.g.kind);
@@ -573,14 +611,21 @@ int ecgpu_resident_state_append(ecgpu_resident_state_t* st, int field, const uin
     int rc = ensure_init();
     if (rc) return rc;
     if (!st) return ECGPU_ERR_BAD_ARG;
-    return resize_field(st, field, data, n_bytes, 0, false);
+    return resize_field(st, field, data, n_bytes, 0, RESIZE_APPEND);
+}
+
+int ecgpu_resident_state_replace(ecgpu_resident_state_t* st, int field, const uint8_t* data, uint64_t n_bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!st) return ECGPU_ERR_BAD_ARG;
+    return resize_field(st, field, data, n_bytes, 0, RESIZE_REPLACE);
 }
 
 int ecgpu_resident_state_truncate(ecgpu_resident_state_t* st, int field, uint64_t new_n_bytes) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!st) return ECGPU_ERR_BAD_ARG;
-    return resize_field(st, field, nullptr, 0, new_n_bytes, true);
+    return resize_field(st, field, nullptr, 0, new_n_bytes, RESIZE_TRUNCATE);
 }
 
 uint64_t ecgpu_resident_state_size(const ecgpu_resident_state_t* st) { return st ? st->n_bytes : 0; }
@@ -619,9 +664,20 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     }
     // the variable-size lists keep their lengths: a patch must not rewrite the offset words of the fixed part
     const FixedLayout L = layout_for(STATE_PRESETS[st->preset], st->fork);
-    u64 off_words[13] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off, L.prev_participation_off,
+    u64 off_words[15] = {L.historical_roots_off, L.eth1_data_votes_off, L.validators_off, L.balances_off, L.prev_participation_off,
                          L.cur_participation_off, L.inactivity_scores_off, L.payload_header_off, L.historical_summaries_off, NO_FIELD,
-                         L.pending_balance_deposits_off, L.pending_partial_withdrawals_off, L.pending_consolidations_off};
+                         L.pending_balance_deposits_off, L.pending_partial_withdrawals_off, L.pending_consolidations_off,
+                         L.prev_attestations_off, L.cur_attestations_off};
+    if (st->fork == FORK_PHASE0) {
+        // the PendingAttestation lists are rooted where they are handed over (ecgpu_resident_state_replace): bytes patched
+        // underneath would leave the two roots stale
+        const u64 att0 = rd32(st->h_fixed.data() + L.prev_attestations_off);
+        for (u32 i = 0; i < n; i++)
+            if (descs[i].len && descs[i].dst_off + descs[i].len > att0) {
+                set_last_error("a patch may not reach into the PendingAttestation lists: ecgpu_resident_state_replace");
+                return ECGPU_ERR_BAD_ARG;
+            }
+    }
     // ... and the one offset word INSIDE the payload header (extra_data): the reference's deserializer rejects any other value
     if (L.payload_header_off != NO_FIELD) off_words[9] = rd32(st->h_fixed.data() + L.payload_header_off) + PAYLOAD_EXTRA_DATA_OFFSET_WORD;
     for (u32 i = 0; i < n; i++)
@@ -710,7 +766,7 @@ int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, e
     u64 rebuilt = 0;
     rc = st->trees.update(s, st->d_ssz, &rebuilt);
     if (rc) return rc;
-    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, &st->trees, st->fork);
+    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, &st->trees, st->fork, st->ext_roots());
     c->last_hash64 += rebuilt;  // (the climbs' share is on the device: the host-pointer entry below adds it)
     if (rc) return rc;
     if (!st->rooted) ECG_HIP_CHECK(hipEventCreateWithFlags(&st->rooted, hipEventDisableTiming));
@@ -730,7 +786,7 @@ int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
     u64 rebuilt = 0;
     rc = st->trees.update(s, st->d_ssz, &rebuilt);
     if (rc) return rc;
-    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, &st->trees, st->fork);
+    rc = state_root_device(s, c, st->d_ssz, st->n_bytes, st->h_fixed.data(), st->preset, d_root, &st->trees, st->fork, st->ext_roots());
     if (rc) return rc;
     // root and the climbs' hash counter come back in one copy
     ECG_HIP_CHECK(hipMemcpyAsync(d_root + 32, st->trees.d_hashes(), 8, hipMemcpyDeviceToDevice, s));
@@ -749,8 +805,6 @@ uint64_t ecgpu_beacon_state_fixed_size(int fork, int preset) {
     if (preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_LAST) return 0;
     return layout_for(STATE_PRESETS[preset], fork).size;
 }
-
-static int pending_attestations_root(const u8* ssz, u64 n_bytes, int preset, u8 root[32]);
 
 // phase0 through the device entry ("missing" 4): the two PendingAttestation lists hold variable-size elements
 // whose offset tables are part of the encoding, and the plan of such a list is built from those tables -- on the host.  They

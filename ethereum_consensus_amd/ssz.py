@@ -126,7 +126,7 @@ def hash_tree_root_beacon_state(fork, ssz: bytes, preset: int = MAINNET) -> byte
 
 
 class ResidentBeaconStateDeneb:
-    """A BeaconState (deneb unless `fork` says altair / bellatrix / capella / electra) kept in HBM: uploaded once, then patched in place with the bytes a block changed and
+    """A BeaconState (deneb unless `fork` says phase0 / altair / bellatrix / capella / electra) kept in HBM: uploaded once, then patched in place with the bytes a block changed and
     re-Merkleized on the device (the reference re-hashes the host-resident state every slot,
     phase0/slot_processing.rs:67)."""
 
@@ -134,7 +134,8 @@ class ResidentBeaconStateDeneb:
         self._h = None
         self._L = _lib.load()
         h = ctypes.c_void_p()
-        rc = self._L.ecgpu_resident_state_create_fork(FORKS[fork] if isinstance(fork, str) else int(fork), preset, _buf(encoding),
+        self._fork = FORKS[fork] if isinstance(fork, str) else int(fork)
+        rc = self._L.ecgpu_resident_state_create_fork(self._fork, preset, _buf(encoding),
                                                       len(encoding), ctypes.byref(h))
         if rc == -3:
             raise MerkleizationError((self._L.ecgpu_last_error() or b"bad state").decode())
@@ -179,6 +180,16 @@ class ResidentBeaconStateDeneb:
             raise MerkleizationError((self._L.ecgpu_last_error() or b"bad append").decode())
         _lib.check(rc, "ecgpu_resident_state_append")
 
+    PREVIOUS_EPOCH_ATTESTATIONS, CURRENT_EPOCH_ATTESTATIONS = 4, 5  # phase0 (in place of the participation lists): replace() only
+
+    def replace(self, field: int, data: bytes) -> None:
+        """a variable-length list exchanged for a new serialization of it (phase0: the two PendingAttestation lists change
+        this way -- process_attestation, phase0/block_processing.rs:160-189, and the rotation at the epoch boundary)"""
+        rc = self._L.ecgpu_resident_state_replace(self._h, field, _buf(data), len(data))
+        if rc == -3:
+            raise MerkleizationError((self._L.ecgpu_last_error() or b"bad replace").decode())
+        _lib.check(rc, "ecgpu_resident_state_replace")
+
     def truncate(self, field: int, new_n_bytes: int) -> None:
         rc = self._L.ecgpu_resident_state_truncate(self._h, field, new_n_bytes)
         if rc == -3:
@@ -186,9 +197,11 @@ class ResidentBeaconStateDeneb:
         _lib.check(rc, "ecgpu_resident_state_truncate")
 
     def add_validator(self, validator121: bytes, balance: int) -> None:
-        """add_validator_to_registry (phase0/block_processing.rs:317-349, altair form: + participation flags, inactivity score)"""
+        """add_validator_to_registry (phase0/block_processing.rs:317-349; altair and later: + participation flags, inactivity score)"""
         self.append(self.VALIDATORS, validator121)
         self.append(self.BALANCES, int(balance).to_bytes(8, "little"))
+        if self._fork == 0:
+            return
         self.append(self.PREVIOUS_EPOCH_PARTICIPATION, b"\x00")
         self.append(self.CURRENT_EPOCH_PARTICIPATION, b"\x00")
         self.append(self.INACTIVITY_SCORES, bytes(8))

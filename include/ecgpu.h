@@ -115,7 +115,9 @@ uint64_t ecgpu_beacon_state_deneb_fixed_size(int preset);
  * deneb/beacon_state.rs:13-64 (28).  The host-pointer entry takes any fork.  phase0 states hold two lists of variable-size
  * elements (PendingAttestation) whose offset tables live in the encoding itself: ecgpu_htr_beacon_state_dev(phase0) copies those
  * two lists -- the tail of the encoding, KBs to ~1 MB -- back to the host once (ONE synchronisation of the stream; every other
- * fork is fully asynchronous) and plans them there; the checked / sharded forms and resident states start at altair. */
+ * fork is fully asynchronous) and plans them there; the checked / sharded forms start at altair.  A RESIDENT phase0 state
+ * (round 5) never copies them back: the two lists are rooted where the host hands them over (at creation, and in
+ * ecgpu_resident_state_replace), and the state root takes the two nodes as they are. */
 #define ECGPU_FORK_PHASE0 0
 #define ECGPU_FORK_ALTAIR 1
 #define ECGPU_FORK_BELLATRIX 2
@@ -192,8 +194,18 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
 #define ECGPU_STATE_PENDING_BALANCE_DEPOSITS 9      /* electra: 16-byte records */
 #define ECGPU_STATE_PENDING_PARTIAL_WITHDRAWALS 10  /* electra: 24-byte records */
 #define ECGPU_STATE_PENDING_CONSOLIDATIONS 11       /* electra: 16-byte records */
+#define ECGPU_STATE_PREVIOUS_EPOCH_ATTESTATIONS 4   /* phase0 (in place of the participation lists): ecgpu_resident_state_replace only */
+#define ECGPU_STATE_CURRENT_EPOCH_ATTESTATIONS 5
 int ecgpu_resident_state_append(ecgpu_resident_state_t* st, int field, const uint8_t* data, uint64_t n_bytes);
 int ecgpu_resident_state_truncate(ecgpu_resident_state_t* st, int field, uint64_t new_n_bytes);
+/* `replace` exchanges a variable-length list for a new serialization of it, whatever the two lengths.  It is how the two
+ * lists of variable-size elements of a phase0 state change (phase0/beacon_state.rs:80-81: process_attestation pushes a
+ * PendingAttestation onto current_epoch_attestations, phase0/block_processing.rs:160-189; the epoch boundary moves current to
+ * previous and empties it, phase0/epoch_processing.rs process_participation_record_updates): their offset tables are part of
+ * the encoding, so there is no in-place append.  The list is rooted from `data` inside the call (a malformed serialization is
+ * refused with ECGPU_ERR_BAD_ARG before anything moves); patches may not reach into these two lists.  Lists of fixed-size
+ * elements can be replaced too (their cached tree is rebuilt at the next root). */
+int ecgpu_resident_state_replace(ecgpu_resident_state_t* st, int field, const uint8_t* data, uint64_t n_bytes);
 uint64_t ecgpu_resident_state_size(const ecgpu_resident_state_t* st);
 int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]);
 /* asynchronous form: root written to device memory on `stream` */

@@ -626,6 +626,15 @@ pub mod merkle {
                 rc => backend_fault(rc),
             }
         }
+        /// a variable-length list exchanged for a new serialization of it (phase0: the two PendingAttestation lists,
+        /// `sys::ECGPU_STATE_{PREVIOUS,CURRENT}_EPOCH_ATTESTATIONS`, change this way and no other)
+        pub fn replace(&mut self, field: i32, serialization: &[u8]) -> Result<(), MerkleizationError> {
+            match unsafe { sys::ecgpu_resident_state_replace(self.raw, field, serialization.as_ptr(), serialization.len() as u64) } {
+                0 => Ok(()),
+                -3 => Err(MerkleizationError::InvalidEncoding),
+                rc => backend_fault(rc),
+            }
+        }
         /// size of the serialization now
         pub fn size(&self) -> u64 {
             unsafe { sys::ecgpu_resident_state_size(self.raw) }

@@ -14,6 +14,7 @@ pub const ECGPU_FORK_ALTAIR: c_int = 1;
 pub const ECGPU_FORK_BELLATRIX: c_int = 2;
 pub const ECGPU_FORK_CAPELLA: c_int = 3;
 pub const ECGPU_FORK_DENEB: c_int = 4;
+pub const ECGPU_FORK_ELECTRA: c_int = 5;
 // variable-length fields of a resident state (ecgpu_resident_state_append / _truncate)
 pub const ECGPU_STATE_HISTORICAL_ROOTS: c_int = 0;
 pub const ECGPU_STATE_ETH1_DATA_VOTES: c_int = 1;
@@ -23,6 +24,11 @@ pub const ECGPU_STATE_PREVIOUS_EPOCH_PARTICIPATION: c_int = 4;
 pub const ECGPU_STATE_CURRENT_EPOCH_PARTICIPATION: c_int = 5;
 pub const ECGPU_STATE_INACTIVITY_SCORES: c_int = 6;
 pub const ECGPU_STATE_HISTORICAL_SUMMARIES: c_int = 8;
+pub const ECGPU_STATE_PENDING_BALANCE_DEPOSITS: c_int = 9; // electra
+pub const ECGPU_STATE_PENDING_PARTIAL_WITHDRAWALS: c_int = 10;
+pub const ECGPU_STATE_PENDING_CONSOLIDATIONS: c_int = 11;
+pub const ECGPU_STATE_PREVIOUS_EPOCH_ATTESTATIONS: c_int = 4; // phase0, in place of the participation lists: replace only
+pub const ECGPU_STATE_CURRENT_EPOCH_ATTESTATIONS: c_int = 5;
 
 #[repr(C)]
 pub struct ecgpu_registry_t {
@@ -92,6 +98,7 @@ extern "C" {
     pub fn ecgpu_beacon_state_fixed_size(fork: c_int, preset: c_int) -> u64;
     pub fn ecgpu_resident_state_append(st: *mut ecgpu_resident_state_t, field: c_int, data: *const u8, n_bytes: u64) -> c_int;
     pub fn ecgpu_resident_state_truncate(st: *mut ecgpu_resident_state_t, field: c_int, new_n_bytes: u64) -> c_int;
+    pub fn ecgpu_resident_state_replace(st: *mut ecgpu_resident_state_t, field: c_int, data: *const u8, n_bytes: u64) -> c_int;
     pub fn ecgpu_resident_state_size(st: *const ecgpu_resident_state_t) -> u64;
     pub fn ecgpu_ssz_generalized_index(types: *const ecgpu_ssz_type, n_types: u32, fields: *const u32, n_field_refs: u32,
                                        root_type: u32, path: *const u64, path_len: u32, gindex: *mut u64) -> c_int;

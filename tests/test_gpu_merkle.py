@@ -805,11 +805,39 @@ ELEM = {"historical_roots": 32, "eth1_data_votes": 72, "validators": 121, "balan
         "pending_partial_withdrawals": 24, "pending_consolidations": 16}
 
 
+def ssz_resident():
+    from ethereum_consensus_amd import ssz
+    return ssz.ResidentBeaconStateDeneb
+
+
 def _random_step(r, st, m, fork):
     """one randomly chosen mutation applied to the resident state `st` and to the host model `m`; returns its name"""
     from ethereum_consensus_amd import synthetic
     lists = [n for n in m.names if n in VAR_INDEX]
     op = r.choice(["patch"] * 6 + ["add_validator", "add_validator", "append", "truncate", "rewrite", "rotate", "fixed", "nothing"])
+    if fork == "phase0" and op == "rotate":
+        op = r.choice(["attest", "attest", "rotate_attestations"])
+    if op == "attest":  # process_attestation: a PendingAttestation pushed onto current_epoch_attestations (the list re-serialized)
+        from oracle import ssz as O
+        t = O.SSZList(O.PendingAttestation(), 4096 if m.preset == "mainnet" else 1024)
+        cur = m.att["current_epoch_attestations"]
+        for _ in range(r.choice([1, 1, 4])):
+            cur.append({"aggregation_bits": [r.random() < 0.5 for _ in range(r.choice([0, 1, 8, 9, 64, 333]))],
+                        "data": {"slot": r.randrange(1 << 40), "index": r.randrange(64), "beacon_block_root": r.randbytes(32),
+                                 "source": {"epoch": r.randrange(1 << 30), "root": r.randbytes(32)},
+                                 "target": {"epoch": r.randrange(1 << 30), "root": r.randbytes(32)}},
+                        "inclusion_delay": r.randrange(1, 33), "proposer_index": r.randrange(1 << 20)})
+        enc = t.serialize(cur)
+        st.replace(ssz_resident().CURRENT_EPOCH_ATTESTATIONS, enc)
+        m.var["current_epoch_attestations"] = bytearray(enc)
+        return op
+    if op == "rotate_attestations":  # process_participation_record_updates: previous = current, current = []
+        st.replace(ssz_resident().PREVIOUS_EPOCH_ATTESTATIONS, bytes(m.var["current_epoch_attestations"]))
+        st.replace(ssz_resident().CURRENT_EPOCH_ATTESTATIONS, b"")
+        m.var["previous_epoch_attestations"] = bytearray(m.var["current_epoch_attestations"])
+        m.var["current_epoch_attestations"] = bytearray()
+        m.att["previous_epoch_attestations"], m.att["current_epoch_attestations"] = m.att["current_epoch_attestations"], []
+        return op
     if op == "patch":  # a block's worth of small writes: balances, flags, scores, records, roots
         patches, used = [], set()
         for _ in range(r.choice([1, 3, 40, 400])):
@@ -845,6 +873,8 @@ def _random_step(r, st, m, fork):
             st.add_validator(rec, bal)
             m.var["validators"] += rec
             m.var["balances"] += bal.to_bytes(8, "little")
+            if fork == "phase0":
+                continue
             m.var["previous_epoch_participation"] += b"\x00"
             m.var["current_epoch_participation"] += b"\x00"
             m.var["inactivity_scores"] += bytes(8)
@@ -864,7 +894,7 @@ def _random_step(r, st, m, fork):
         st.truncate(VAR_INDEX[name], keep)
         del m.var[name][keep:]
     elif op == "rewrite":  # an epoch's rewards: every balance changes in one patch (the tree is rebuilt, not climbed)
-        name = r.choice(["balances", "inactivity_scores"])
+        name = r.choice(["balances", "inactivity_scores"] if fork != "phase0" else ["balances"])
         data = r.randbytes(len(m.var[name]))
         if data:
             st.patch([(m.start(name), data)])
@@ -878,12 +908,13 @@ def _random_step(r, st, m, fork):
     return op
 
 
-@pytest.mark.parametrize("fork,preset,n_val,steps", [("altair", "minimal", 700, 170), ("bellatrix", "minimal", 1100, 170),
+@pytest.mark.parametrize("fork,preset,n_val,steps", [("phase0", "minimal", 600, 170), ("phase0", "mainnet", 3000, 120),
+                                                      ("altair", "minimal", 700, 170), ("bellatrix", "minimal", 1100, 170),
                                                       ("capella", "mainnet", 2500, 170), ("deneb", "minimal", 37, 170),
                                                       ("deneb", "mainnet", 5000, 170), ("deneb", "minimal", 2040, 170),
                                                       ("electra", "minimal", 900, 170)])
 def test_resident_state_randomised_patch_append_truncate_sequences(gpu, fork, preset, n_val, steps):
-    """1 190 randomised steps over every resident fork (altair ... electra): after EVERY step the resident root (dirty paths climbed, rebuilt fields,
+    """1 480 randomised steps over every resident fork (phase0 ... electra; phase0 with attestations pushed and rotated): after EVERY step the resident root (dirty paths climbed, rebuilt fields,
     finishing jobs over the cached levels) equals ecgpu_htr_beacon_state of the re-serialized state, computed from scratch."""
     from ethereum_consensus_amd import synthetic
     from tests._statemodel import EncodingModel
@@ -898,6 +929,8 @@ def test_resident_state_randomised_patch_append_truncate_sequences(gpu, fork, pr
     st = ssz.ResidentBeaconStateDeneb(enc, pid, fork=fork)
     m = EncodingModel(t, enc)
     m.limits = {n: ty.limit for n, ty in t.fields if hasattr(ty, "limit")}  # (an append past a list's limit is an error, tested elsewhere)
+    m.preset = preset
+    m.att = {k: list(v[k]) for k in ("previous_epoch_attestations", "current_epoch_attestations") if k in v}
     assert m.encoding() == enc
     assert st.hash_tree_root() == t.htr(v)
     seen = set()
@@ -911,7 +944,46 @@ def test_resident_state_randomised_patch_append_truncate_sequences(gpu, fork, pr
         assert st.hash_tree_root() == ssz.hash_tree_root_beacon_state(fork, cur, pid), (k, op)
     cur = m.encoding()
     assert st.hash_tree_root() == ssz.hash_tree_root_beacon_state(fork, cur, pid)
-    assert {"patch", "add_validator", "rewrite", "rotate", "fixed"} <= seen
+    assert {"patch", "add_validator", "rewrite", "fixed"} <= seen and ({"rotate"} <= seen or {"attest", "rotate_attestations"} <= seen)
+    st.close()
+
+
+def test_resident_phase0_state_attestation_lists_change_by_replacement_only(gpu):
+    """phase0/beacon_state.rs:80-81: the two lists of variable-size PendingAttestation.  A patch reaching into them, an append,
+    and a malformed replacement are refused and leave the state as it was; a replacement is rooted inside the call."""
+    from ethereum_consensus_amd import synthetic
+    from oracle import ssz as O
+    ssz = gpu
+    R = ssz.ResidentBeaconStateDeneb
+    r = random.Random(5)
+    f = synthetic.state_fields(200, "minimal", seed=8)
+    f["_preset"] = "minimal"
+    t, v = _fork_state_value("phase0", f, r)
+    enc = t.serialize(v)
+    st = R(enc, ssz.MINIMAL, fork="phase0")
+    root0 = st.hash_tree_root()
+    assert root0 == t.htr(v)
+    with pytest.raises(Exception):
+        st.patch([(len(enc) - 4, b"\x01\x02\x03\x04")])
+    with pytest.raises(Exception):
+        st.append(R.CURRENT_EPOCH_ATTESTATIONS, bytes(148))
+    lt = O.SSZList(O.PendingAttestation(), 1024)
+    good = lt.serialize(v["current_epoch_attestations"] + v["current_epoch_attestations"][:1])
+    with pytest.raises(Exception):
+        st.replace(R.CURRENT_EPOCH_ATTESTATIONS, good[:-3] if len(good) > 8 else b"\x07")  # a truncated serialization
+    assert len(st) == len(enc) and st.hash_tree_root() == root0
+    st.replace(R.CURRENT_EPOCH_ATTESTATIONS, good)
+    v["current_epoch_attestations"] = v["current_epoch_attestations"] + v["current_epoch_attestations"][:1]
+    assert st.hash_tree_root() == t.htr(v)
+    st.replace(R.PREVIOUS_EPOCH_ATTESTATIONS, good)
+    st.replace(R.CURRENT_EPOCH_ATTESTATIONS, b"")
+    v["previous_epoch_attestations"], v["current_epoch_attestations"] = v["current_epoch_attestations"], []
+    assert st.hash_tree_root() == t.htr(v) and len(st) == len(t.serialize(v))
+    st.replace(R.BALANCES, bytes(8 * 200))  # lists of fixed-size elements replaced whole: same length, another length
+    v["balances"] = [0] * 200
+    st.replace(R.HISTORICAL_ROOTS, bytes(range(96)))
+    v["historical_roots"] = [bytes(range(32 * i, 32 * i + 32)) for i in range(3)]
+    assert st.hash_tree_root() == t.htr(v)
     st.close()
 
 
