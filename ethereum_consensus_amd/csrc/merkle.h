@@ -146,6 +146,37 @@ struct ValidatorLeaves {
     }
 };
 
+// ---- the registry's leaf pass staged through LDS (merkle.hip k_merkle_pass<2, ValidatorLeaves>; the host simulator runs the
+// same addressing, tests/hostsim hs_staged_validator_wave) -------------------------------------------------------------------
+constexpr u32 VAL_STEP_BYTES = 64 * 121;                 // a wave's step: 64 records = 484 x 16 bytes
+constexpr u32 VAL_STAGE_VECS = VAL_STEP_BYTES / 16 + 1;  // + the vector the step's misalignment spills into
+// a record in the stage, read a dword pair at a time where the words are used
+struct StagedRecord {
+    const u32* stage;  // the wave's stage
+    u32 at;            // the aligned dword that holds the record's first byte
+    u32 sh;            // ... and that byte's position in it
+    ECG_HD u32 operator()(int i) const {
+        // (dword 30 is asked for its first byte only: the dword after it, which may lie past the stage, is never needed)
+        return i < 30 ? funnel_bytes(stage[at + i], stage[at + i + 1], sh) : funnel_bytes(stage[at + 30], 0u, sh);
+    }
+    ECG_HD void after(const Node& n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the next fetches "depend" on the hash just computed: they stay behind the call (hash64 is pure, and without this the
+        // compiler reads the whole record up front and carries 31 words across seven calls)
+        asm volatile("" : "+v"(at) : "v"(n.w[0]));
+#else
+        (void)n;
+#endif
+    }
+};
+// record `lane` of a step whose first record starts `adj` bytes into the stage
+ECG_HD StagedRecord staged_record(const u32* stage, u32 adj, u32 lane) {
+    const u32 o = adj + 121 * lane;
+    return StagedRecord{stage, o >> 2, o & 3};
+}
+// the transposition of a wave's 256 record roots through the stage, four words at a time: word w of record v
+ECG_HD u32 staged_root_dword(u32 w, u32 v) { return 256 * w + v; }
+
 // hash_tree_root(ByteVector<48>) for packed 48-byte records (BlsPublicKey vectors of
 // SyncCommittee, /root/reference/ethereum-consensus/src/altair/sync.rs:17-22)
 struct Bytes48Leaves {

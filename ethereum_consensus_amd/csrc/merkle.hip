@@ -58,25 +58,6 @@ __global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass(Leaf leaf, u64 n_in,
 // 1.39 x the records (PMC, round 4).  Here a WAVE takes its 256 records in four steps of 64 x 121 = 7 744 contiguous bytes:
 // 16-byte lane loads into LDS (fully coalesced, every line fetched once and consumed at once), lane i hashes record 64 k + i
 // out of LDS, and the 256 roots are transposed through the same LDS so that lane j ends up with records 4 j .. 4 j + 3.
-constexpr u32 VAL_STEP_BYTES = 64 * 121;               // = 484 x 16
-constexpr u32 VAL_STAGE_VECS = VAL_STEP_BYTES / 16 + 1;  // + the vector the step's misalignment spills into
-
-// a record in the stage, read a dword pair at a time where the words are used
-struct StagedRecord {
-    const u32* stage;  // the wave's stage (LDS)
-    u32 at;            // the aligned dword that holds the record's first byte
-    u32 sh;            // ... and that byte's position in it
-    __device__ __forceinline__ u32 operator()(int i) const {
-        // (dword 30 is asked for its first byte only: the dword after it, which may lie past the stage, is never needed)
-        return i < 30 ? funnel_bytes(stage[at + i], stage[at + i + 1], sh) : funnel_bytes(stage[at + 30], 0u, sh);
-    }
-    __device__ __forceinline__ void after(const Node& n) {
-        // the next fetches "depend" on the hash just computed: they stay behind the call (hash64 is pure, and without this the
-        // compiler reads the whole record up front and carries 31 words across seven calls)
-        asm volatile("" : "+v"(at) : "v"(n.w[0]));
-    }
-};
-
 template <>
 __global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass<2, ValidatorLeaves>(ValidatorLeaves leaf, u64 n_in, u64 n_out, u8* out,
                                                                                 const ZeroTable* zt, int level0, u64 gid0) {
@@ -105,8 +86,7 @@ __global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass<2, ValidatorLeaves>(
         if (lane + 448 < VAL_STAGE_VECS) st[lane + 448] = v7_;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const u32 o = adj + 121 * lane;
-        StagedRecord rec{reinterpret_cast<const u32*>(st), o >> 2, o & 3};
+        StagedRecord rec = staged_record(reinterpret_cast<const u32*>(st), adj, lane);
         r[k] = validator_root_from_words(rec);
     }
     // roots: lane i holds records 64 k + i; lane j wants 4 j .. 4 j + 3.  Word-major through the stage, four words at a time.
@@ -119,12 +99,12 @@ __global__ void __launch_bounds__(PASS_BLOCK) k_merkle_pass<2, ValidatorLeaves>(
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int w = 0; w < 4; w++) tw[256 * w + 64 * k + lane] = r[k].w[4 * h + w];
+            for (int w = 0; w < 4; w++) tw[staged_root_dword(w, 64 * k + lane)] = r[k].w[4 * h + w];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const uint4 x = reinterpret_cast<const uint4*>(tw + 256 * w)[lane];
+            const uint4 x = *reinterpret_cast<const uint4*>(tw + staged_root_dword(w, 4 * lane));
             c[0].w[4 * h + w] = x.x, c[1].w[4 * h + w] = x.y, c[2].w[4 * h + w] = x.z, c[3].w[4 * h + w] = x.w;
         }
     }

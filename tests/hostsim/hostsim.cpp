@@ -95,6 +95,43 @@ u64 hs_pass(int kind, int D, const u8* in, u64 in_bytes, u64 n_in, u8* out, int 
     return n_out;
 }
 
+// One wave of the registry's staged leaf pass (merkle.hip k_merkle_pass<2, ValidatorLeaves>) with the kernel's addressing: the
+// wave's 256 records start at `in + first_byte` (any alignment), each of the four steps copies the 485 aligned 16-byte vectors
+// that cover its 64 records into a 7 760-byte stage -- vector 484 only where the step is misaligned, as the kernel loads it --,
+// lane i hashes record 64 k + i through StagedRecord, the 256 roots go through the stage word-major in two halves, lane j
+// stores the node over records 4 j .. 4 j + 3.  out: 64 nodes.  `in` must be readable 15 bytes before first_byte.
+void hs_staged_validator_wave(const u8* in, u64 first_byte, u8* out) {
+    const u8* src = in + first_byte;
+    const u32 adj = (u32)((u64)src & 15);
+    const u8* vsrc = src - adj;
+    std::vector<u32> stage(4 * VAL_STAGE_VECS, 0xdeadbeefu);
+    Node r[4][64];
+    for (int k = 0; k < 4; k++) {
+        const u8* g = vsrc + (u64)VAL_STEP_BYTES * k;
+        for (u32 lane = 0; lane < 64; lane++)
+            for (int i = 0; i < 8; i++) {
+                const u32 j = lane + 64 * i;
+                if (j >= VAL_STAGE_VECS) continue;
+                if (j < VAL_STAGE_VECS - 1 || adj) std::memcpy(&stage[4 * j], g + 16ull * j, 16);
+                else std::memset(&stage[4 * j], 0, 16);
+            }
+        for (u32 lane = 0; lane < 64; lane++) {
+            StagedRecord rec = staged_record(stage.data(), adj, lane);
+            r[k][lane] = validator_root_from_words(rec);
+        }
+    }
+    Node c[4][64];
+    for (int h = 0; h < 2; h++) {
+        for (int k = 0; k < 4; k++)
+            for (u32 lane = 0; lane < 64; lane++)
+                for (int w = 0; w < 4; w++) stage[staged_root_dword(w, 64 * k + lane)] = r[k][lane].w[4 * h + w];
+        for (u32 lane = 0; lane < 64; lane++)
+            for (int w = 0; w < 4; w++)
+                for (int q = 0; q < 4; q++) c[q][lane].w[4 * h + w] = stage[staged_root_dword(w, 4 * lane) + q];
+    }
+    for (u32 lane = 0; lane < 64; lane++) node_store(hash64(hash64(c[0][lane], c[1][lane]), hash64(c[2][lane], c[3][lane])), out + 32 * lane);
+}
+
 // the tile stage exactly as k_tree_tiles runs it (merkle.h TileDesc): per tile 256 lanes x Subtree<2>, then up to
 // 8 levels pairwise with the virtual-pair shortcut; one node per tile at level min(top, level0 + 10)
 u64 hs_tiles(int kind, const u8* in, u64 in_bytes, u64 n0, u32 level0, u32 top, u8* out) {

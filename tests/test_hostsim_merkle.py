@@ -86,6 +86,29 @@ def test_validator_list_root(n, ds, misalign):
     assert got == want
 
 
+@pytest.mark.parametrize("misalign", range(16))
+def test_staged_registry_wave_addressing(misalign):
+    """The registry's leaf pass staged through LDS (csrc/merkle.hip k_merkle_pass<2, ValidatorLeaves>), on the host with the kernel's
+    own addressing (merkle.h StagedRecord / staged_record / staged_root_dword): a wave's 256 records at every byte alignment --
+    16-byte vectors into the stage, the spill vector only where the step is misaligned, words fetched through the funnel, the
+    roots transposed word-major -- give the 64 nodes of the generic lane program, and never read what lies behind the records."""
+    import ctypes
+    import random
+    from ethereum_consensus_amd import synthetic as S
+    L = hs.lib()
+    L.hs_staged_validator_wave.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    data = S.validators(256 + 3, seed=100 + misalign).tobytes()
+    lead = random.Random(misalign).randbytes(16 + 121 * 2)  # (records in front of the wave: the aligned head reads into them)
+    raw, addr = hs.unaligned_buffer(lead + data[:121 * 256], (misalign - len(lead)) % 16)
+    out = ctypes.create_string_buffer(32 * 64)
+    L.hs_staged_validator_wave(addr, len(lead), out)
+    assert (addr + len(lead)) % 16 == misalign
+    want = ctypes.create_string_buffer(32 * 64)
+    raw2, addr2 = hs.unaligned_buffer(data[:121 * 256], 0)
+    L.hs_pass(2, 2, addr2, 121 * 256, 256, want, 0)
+    assert out.raw == want.raw
+
+
 def test_bytes48_pair64_eth1data_leaves():
     r = random.Random(5)
     pks = [r.randbytes(48) for _ in range(33)]
