@@ -490,6 +490,14 @@ static const int g_row_stages = [] {  // ECGPU_ROW_STAGES=0: the SSWU maps and t
     const char* e = getenv("ECGPU_ROW_STAGES");
     return e ? atoi(e) : 1;
 }();
+static const u32 g_h2c_quad_max = [] {  // ECGPU_H2C_QUAD_MAX: up to this many messages the end of the message stage takes a WAVE per message
+    const char* e = getenv("ECGPU_H2C_QUAD_MAX");  // (0: always a row pair per message)
+    return e ? (u32)strtoul(e, nullptr, 10) : 512u;
+}();
+static const int g_row_decode = [] {  // ECGPU_ROW_DECODE=0: keys and signatures of a small batch are decoded on one lane each (their square roots
+    const char* e = getenv("ECGPU_ROW_DECODE");  // included), only the subgroup checks run on rows: the first form of round 5
+    return e ? atoi(e) : 1;
+}();
 static const u32 g_h2c_row_max = [] {
     const char* e = getenv("ECGPU_H2C_ROW_MAX");
     return e ? (u32)strtoul(e, nullptr, 10) : 1024u;  // (4 096 messages on rows: 3.2 ms against the lane pair's 2.9, profiles/r05l_probe.txt)
@@ -592,9 +600,13 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     auto run_keys = [&] {
         if (n_pks && !reg) {
             ProfScope ps("bls_pk_validate", s);
-            if (g_row_stages && n_pks <= g_h2c_row_max) {  // (round 5) a few keys: decoding on one lane each, the subgroup check on a row each
-                hipLaunchKernelGGL(k_pk_decode_w1, grid_for(n_pks), dim3(BLS_BLOCK), 0, s, d_pks48, n_pks, pts, st);
-                launch_pk_group_row(s, (const A1*)pts, n_pks, st);
+            if (g_row_stages && n_pks <= g_h2c_row_max) {  // (round 5) a few keys: a row each
+                if (g_row_decode) {  // ... square root included
+                    launch_pk_row(s, d_pks48, n_pks, pts, st);
+                } else {             // ... the decoding on one lane (ECGPU_ROW_DECODE=0)
+                    hipLaunchKernelGGL(k_pk_decode_w1, grid_for(n_pks), dim3(BLS_BLOCK), 0, s, d_pks48, n_pks, pts, st);
+                    launch_pk_group_row(s, (const A1*)pts, n_pks, st);
+                }
             } else {
                 launch_pk_validate(s, d_pks48, n_pks, pts, st);
             }
@@ -614,6 +626,10 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     auto run_sig = [&] {
         ProfScope ps("bls_sig", s3);
         if (rows) {
+            if (g_row_decode) {
+                launch_sig_row(s3, d_sigs96, n, sigpts, st_dec, st_grp);
+                return;
+            }
             hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_decode_calls : k_sig_decode, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts, st_dec);
             launch_sig_group_row(s3, (const A2*)sigpts, (const u8*)st_dec, n, st_grp);
             return;
@@ -631,7 +647,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             // one lane -- on a lane PAIR (bls_g2_pair2.h): half the Fp2 components, 0.57 of the instructions, per lane
             // (round 5) ... or on a ROW of 16 lanes, limb per lane (bls_rowcurve.h: 0.57 of the instructions per lane became
             // ~0.2; for up to ECGPU_H2C_ROW_MAX messages)
-            if (g_h2c_finish_lanes == 16 && n <= g_h2c_row_max)
+            if (g_h2c_finish_lanes == 16 && n <= g_h2c_quad_max)
+                launch_h2c_finish_quad(s2, (const J2*)h2c_maps, n, hpts);  // (round 5, last) a wave per message while waves are free
+            else if (g_h2c_finish_lanes == 16 && n <= g_h2c_row_max)
                 launch_h2c_finish_row(s2, (const J2*)h2c_maps, n, hpts);
             else if (g_h2c_finish_lanes == 1)
                 hipLaunchKernelGGL(calls ? k_h2c_finish_calls : k_h2c_finish, grid_for(n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);

@@ -38,9 +38,12 @@ __global__ void k_h2c_calls(const u8* msgs, const u64* msg_off, u32 n, A2* hpts)
 
 // bls_row_g2.hip: side stages of a small batch with one point per 16-lane row
 void launch_h2c_finish_row(hipStream_t s, const J2* maps, u32 n, A2* hpts);
+void launch_h2c_finish_quad(hipStream_t s, const J2* maps, u32 n, A2* hpts);  // one message per wave, doublings over both row pairs
 void launch_h2c_map_row(hipStream_t s, const u8* msgs, const u64* msg_off, u32 n, J2* maps);
 void launch_sig_group_row(hipStream_t s, const A2* pts, const u8* st_dec, u32 n, u8* st_grp);
 void launch_pk_group_row(hipStream_t s, const A1* pts, u32 n, u8* st);
+void launch_sig_row(hipStream_t s, const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);  // decoding + group check on a row pair
+void launch_pk_row(hipStream_t s, const u8* pks48, u32 n, A1* pts, u8* st);                    // key_validate on a row
 __global__ void k_pk_decode_w1(const u8* pks48, u32 n, A1* pts, u8* st);  // bls_g1_kernels.hip: decoding + infinity alone
 __global__ void k_sig_decode(const u8* sigs96, u32 n, A2* pts, u8* st_dec);  // bls_g2_kernels.hip: Signature::try_from alone
 __global__ void k_sig_decode_calls(const u8* sigs96, u32 n, A2* pts, u8* st_dec);

@@ -58,6 +58,10 @@ ROW_FN rv32 rv_from_next(rv32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (i
 ROW_FN rv32 rv_from_prev(rv32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); }  // row_shr:1
 // the same lane of the other row of the pair (rows 2m, 2m + 1 of a wave)
 ROW_FN rv32 rv_partner(rv32 x) { return (u32)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u) ^ 16u) << 2), (int)x); }
+// the two row PAIRS of a wave (lanes 0 .. 31, 32 .. 63: bls_rowcurve.h jac_dbl_quad): which one the lane is in, and the same lane
+// of the other one
+ROW_FN rv32 rv_quad_hi() { return (threadIdx.x >> 5) & 1u; }
+ROW_FN rv32 rv_other_pair(rv32 x) { return (u32)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u) ^ 32u) << 2), (int)x); }
 // lane I of the lane's own row
 template <int I>
 ROW_FN rv32 rv_bcast(rv32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + I, 0xf, 0xf, true); }  // row_newbcast:I
@@ -107,14 +111,17 @@ ROW_FN void rv_lds_write(u32* lds, rv32 dw, rv32 v, rv32 pred) {
     if (pred) lds[dw] = v;
 }
 #else
-constexpr int ROW_SIM = 32;  // host: the 32 lanes of one row pair in lock step
+#ifndef ECG_ROW_SIM
+#define ECG_ROW_SIM 32  // host: the 32 lanes of one row pair in lock step (tests/hostsim/hostsim_quad.cpp: 64, the two pairs of a wave)
+#endif
+constexpr int ROW_SIM = ECG_ROW_SIM;
 struct rv32 {
     u32 v[ROW_SIM];
 };
 struct rv64 {
     u64 v[ROW_SIM];
 };
-#define ROW_FN inline
+#define ROW_FN static inline  // (static: the simulator has translation units with different lane-vector widths)
 #define ROW_EACH for (int l_ = 0; l_ < ROW_SIM; l_++)
 ROW_FN rv32 rv_splat(u32 x) { rv32 r; ROW_EACH r.v[l_] = x; return r; }
 ROW_FN rv32 rv_lane() { rv32 r; ROW_EACH r.v[l_] = l_ & 15; return r; }
@@ -149,6 +156,8 @@ ROW_FN rv32 rv_bcast0(rv32 x) { rv32 r; ROW_EACH r.v[l_] = x.v[l_ & ~15]; return
 ROW_FN rv32 rv_from_next(rv32 x) { rv32 r; ROW_EACH r.v[l_] = (l_ & 15) == 15 ? 0u : x.v[l_ + 1]; return r; }
 ROW_FN rv32 rv_from_prev(rv32 x) { rv32 r; ROW_EACH r.v[l_] = (l_ & 15) == 0 ? 0u : x.v[l_ - 1]; return r; }
 ROW_FN rv32 rv_partner(rv32 x) { rv32 r; ROW_EACH r.v[l_] = x.v[l_ ^ 16]; return r; }
+ROW_FN rv32 rv_quad_hi() { rv32 r; ROW_EACH r.v[l_] = (l_ >> 5) & 1; return r; }
+ROW_FN rv32 rv_other_pair(rv32 x) { rv32 r; ROW_EACH r.v[l_] = x.v[(l_ ^ 32) % ROW_SIM]; return r; }
 template <int I>
 ROW_FN rv32 rv_bcast(rv32 x) { rv32 r; ROW_EACH r.v[l_] = x.v[(l_ & ~15) + I]; return r; }
 ROW_FN rv32 rv_or(rv32 a, rv32 b) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] | b.v[l_]; return r; }
@@ -171,9 +180,13 @@ ROW_FN rv32 rv_row_any(rv32 x) {
 ROW_FN bool rv_test(rv32 c) { return c.v[0] != 0; }
 ROW_FN rv32 rv_pair_row() { rv32 r; ROW_EACH r.v[l_] = (l_ >> 4) & 1; return r; }
 ROW_FN rv32 rv_pair_any(rv32 x) {
-    u32 any = 0;
-    ROW_EACH any |= x.v[l_];
-    return rv_splat(any ? 1u : 0u);
+    rv32 r;
+    for (int pair = 0; pair < ROW_SIM; pair += 32) {
+        u32 any = 0;
+        for (int q = 0; q < 32; q++) any |= x.v[pair + q];
+        for (int q = 0; q < 32; q++) r.v[pair + q] = any ? 1u : 0u;
+    }
+    return r;
 }
 ROW_FN rv32 rv_carry_exact(rv32 v) {
     rv32 r;

@@ -42,6 +42,73 @@ ECG_HD_NOINLINE void r_g2_clear_cofactor(Jac<F>& r, const Jac<F>& p_in) {
     jac_add(t3, t3, n);
     r = t3;
 }
+// ---- a G2 doubling over BOTH row pairs of a wave (round 5, last): one message per wave ---------------------------------------
+// A doubling on a row pair is six products one after the other (jac_dbl_inl of bls_curve.h: A = X^2, B = Y^2, D = 4 X B, E^2,
+// Y3 as a sum of two products, Z3 = 2 Y Z), but its dependency depth is three.  With the point held in BOTH pairs of the wave
+// (lanes 0 .. 31 and 32 .. 63, the same values) every step runs ONE instruction sequence on operands selected per pair:
+//     step 1   pair 0: A = X^2                          pair 1: B = Y^2
+//     step 2   pair 0: E^2, E = 3A                      pair 1: D = (4X) B
+//     step 3   pair 0: Y3 = E (D - X3) + (8p - 4B)(2B)  pair 1: Z3 = (2Y) Z + 0 * 0
+// with four lane exchanges between the pairs (D and B over to pair 0; X3, Y3 | Z3 back to both): 8 product-iterations instead of
+// 14, ~1 100 instructions instead of ~1 700 -- for the 126 doublings of the cofactor clearing of a LONE message, whose second row
+// pair would otherwise sit idle.  Bounds as in jac_dbl_inl (the unused halves compute in-range garbage: every operand of a
+// product is < 8p in both pairs).  inf -> inf (Z3 = 0); y == 0 -> inf.  r may alias p.
+ROW_FN RP2 rq_sel(const RP2& pair0, const RP2& pair1) { return RP2{rv_sel(rv_quad_hi(), pair1.v, pair0.v)}; }
+ROW_FN RP2 rq_other(const RP2& a) { return RP2{rv_other_pair(a.v)}; }
+ROW_FN void jac_dbl_quad(PJ2& r, const PJ2& p) {
+    const RP2 AB = f_sqr(rq_sel(p.x, p.y));                            // A | B
+    const RP2 T3 = f_add_lazy(f_add_lazy(AB, AB), AB);                  // E = 3A < 6p | (3B)
+    const RP2 X2 = f_add_lazy(p.x, p.x), X4 = f_add_lazy(X2, X2);       // 4X < 8p
+    const RP2 ED = f_mul(rq_sel(T3, X4), rq_sel(T3, AB));               // E^2 | D
+    const RP2 D0 = rq_other(ED), B0 = rq_other(AB);                     // D | (E^2),  B | (A)
+    const RP2 X3 = f_sub_dbl(ED, D0);                                   // E^2 - 2D in [0, 2p) | (in-range garbage)
+    const RP2 B2 = f_add_lazy(B0, B0), B4 = f_add_lazy(B2, B2);         // < 4p, < 8p
+    const RP2 n4B = f_neg_lazy<8>(B4);
+    RP2 zero;
+    f_set_zero(zero);
+    const RP2 YZ = f_sp2<4, 4>(rq_sel(T3, f_add_lazy(p.y, p.y)), rq_sel(f_sub_lazy<2>(D0, X3), p.z), rq_sel(n4B, zero), rq_sel(B2, zero));  // Y3 | Z3
+    const RP2 ZY = rq_other(YZ), X3o = rq_other(X3);
+    r.x = rq_sel(X3, X3o);
+    r.y = rq_sel(YZ, ZY);
+    r.z = rq_sel(ZY, YZ);
+}
+// [|x|] P with the doublings over both pairs (the additions run on both pairs redundantly)
+ECG_HD_NOINLINE void jac_mul_xabs_quad(PJ2& r, const PJ2& p_in) {
+    const PJ2 base = p_in;
+    PJ2 acc = base;
+    for (int b = 62; b >= 0; b--) {
+        jac_dbl_quad(acc, acc);
+        if ((blsc::X_ABS >> b) & 1) {
+            PJ2 t = acc;
+            jac_add(t, t, base);
+            acc = t;
+        }
+    }
+    r = acc;
+}
+// r_g2_clear_cofactor with its two multiplications by |x| on both pairs
+ECG_HD_NOINLINE void r_g2_clear_cofactor_quad(PJ2& r, const PJ2& p_in) {
+    const PJ2 p = p_in;
+    PJ2 t1, t2, t3, n;
+    jac_mul_xabs_quad(t1, p);
+    jac_neg(t1, t1);  // [x] P
+    r_g2_psi(t2, p);  // psi(P)
+    jac_dbl_quad(t3, p);
+    r_g2_psi(t3, t3);
+    r_g2_psi(t3, t3);  // psi^2(2P)
+    jac_neg(n, t2);
+    jac_add(t3, t3, n);   // psi^2(2P) - psi(P)
+    jac_add(t2, t1, t2);  // [x] P + psi(P)
+    jac_mul_xabs_quad(t2, t2);
+    jac_neg(t2, t2);  // [x^2] P + [x] psi(P)
+    jac_add(t3, t3, t2);
+    jac_neg(n, t1);
+    jac_add(t3, t3, n);
+    jac_neg(n, p);
+    jac_add(t3, t3, n);
+    r = t3;
+}
+
 // 1 / (a0 + a1 i) = (a0 - a1 i) / (a0^2 + a1^2); the Fp inverse as n^(p - 2) = (n^((p - 3) / 4))^4 n (tab: 16 register images of LDS)
 ROW_FN RFp2 rfp2_inv(const RFp2& a, u32* tab) {
     const RowK K = row_k();
@@ -240,6 +307,121 @@ ROW_FN bool r_g2_in_subgroup(const A2* q) {
     return jac_eq(ps, t);
 }
 
+// psi(Q) == [x] Q for an affine point already in row-pair registers
+ROW_FN bool r_g2_in_subgroup_regs(const Aff<RP2>& a) {
+    Jac<RP2> Q, t, ps;
+    jac_from_aff(Q, a);
+    jac_mul_xabs_aff(t, a);
+    jac_neg(t, t);
+    r_g2_psi(ps, Q);
+    return jac_eq(ps, t);
+}
+
+// Signature::try_from + the group check of verify for ONE signature on a row pair (crypto/bls.rs:330-336, 71; g2_decompress_inl
+// and g2_in_subgroup of bls_curve.h, step by step): the flag bytes, the range check and the conversion of x to Montgomery
+// form by the one-lane routines in every lane (a lone wave pays nothing for the redundancy), x^3 + 4(1 + i) and its square root
+// -- two Fp exponentiations -- on the row (each row of the pair holds both components and computes the same thing), the ZCash
+// sign, then the psi check with one component per row.  *sd: the decoding's status; *sg: ECGPU_POINT_NOT_IN_GROUP or 0; the
+// affine point goes to memory exactly as the one-lane decoder leaves it (zero coordinates unless the decoding succeeded).
+ROW_FN void r_sig_decode_and_group(A2* out, u8* sd, u8* sg, const u8* b, u32* tab) {
+    const RowK K = row_k();
+    const RP2* tag = nullptr;
+    const bool first = f_first_lane(tag);
+    RFp2 x, y;
+    f_set_zero(x);
+    f_set_zero(y);
+    u32 inf = 0;
+    int st = ECGPU_SUCCESS;
+    const u32 b0 = b[0];
+    if (!(b0 & 0x80)) {
+        st = ECGPU_BAD_ENCODING;
+    } else if (b0 & 0x40) {
+        if ((b0 & 0x3f) == 0 && bytes_all_zero(b, 1, 96)) inf = 1;
+        else st = ECGPU_BAD_ENCODING;
+    } else {
+        const Fp r1 = raw_from_be48(b, true), r0 = raw_from_be48(b + 48, false);
+        if (raw_geq(r1, blsc::P) || raw_geq(r0, blsc::P)) {
+            st = ECGPU_BAD_ENCODING;
+        } else {
+            const RFp2 xr = rfp2_of(Fp2{fp_from_raw(r0), fp_from_raw(r1)});
+            const RFp2 g = f_add(f_mul(f_sqr(xr), xr), rfp2_const(blsc::B2));
+            RFp2 yr;
+            f_set_zero(yr);
+            if (!rfp2_sqrt(g, yr, tab, K)) {
+                st = ECGPU_POINT_NOT_ON_CURVE;
+            } else {
+                if (rfp2_lex_largest(yr, K) != ((b0 & 0x20) != 0)) yr = f_neg(yr);
+                if (f_is_zero(xr)) st = ECGPU_POINT_NOT_IN_GROUP;
+                else x = xr, y = yr;
+            }
+        }
+    }
+    // every lane of the pair holds both components: row 0 of the pair stores (the row-pair store of f_store2 takes one component per row)
+    const RP2 xp{rv_sel(rv_pair_row(), x.c1.v, x.c0.v)}, yp{rv_sel(rv_pair_row(), y.c1.v, y.c0.v)};
+    f_store2(&out->x, xp);
+    f_store2(&out->y, yp);
+    u8 g8 = 0;
+    if (st == ECGPU_SUCCESS && !inf && !r_g2_in_subgroup_regs(Aff<RP2>{xp, yp, 0u})) g8 = ECGPU_POINT_NOT_IN_GROUP;
+    if (first) {
+        out->inf = inf;
+        *sd = (u8)st;
+        *sg = g8;
+    }
+}
+
+// PublicKey::try_from = blst key_validate for ONE key on a row (crypto/bls.rs:279-285; g1_decompress_inl + the infinity rule +
+// g1_in_subgroup): the square root -- one Fp exponentiation -- and the endomorphism check on the row
+ROW_FN void r_pk_validate(A1* out, u8* st_out, const u8* b, u32* tab) {
+    const RowK K = row_k();
+    RFp x = rfp_zero(), y = rfp_zero();
+    u32 inf = 0;
+    int st = ECGPU_SUCCESS;
+    const u32 b0 = b[0];
+    if (!(b0 & 0x80)) {
+        st = ECGPU_BAD_ENCODING;
+    } else if (b0 & 0x40) {
+        if ((b0 & 0x3f) == 0 && bytes_all_zero(b, 1, 48)) inf = 1, st = ECGPU_PK_IS_INFINITY;
+        else st = ECGPU_BAD_ENCODING;
+    } else {
+        const Fp raw = raw_from_be48(b, true);
+        if (raw_geq(raw, blsc::P)) {
+            st = ECGPU_BAD_ENCODING;
+        } else {
+            const RFp xr = rfp_of(fp_from_raw(raw));
+            const RFp g = rfp_add(rfp_mul(rfp_sqr(xr, K), xr, K), rfp_const(blsc::B1), K);
+            RFp yr;
+            if (!rfp_sqrt(g, yr, tab, K)) {
+                st = ECGPU_POINT_NOT_ON_CURVE;
+            } else {
+                if (rfp_lex_largest(yr, K) != ((b0 & 0x20) != 0)) yr = rfp_neg(yr, K);
+                if (rfp_is_zero(xr, K)) st = ECGPU_POINT_NOT_IN_GROUP;
+                else x = xr, y = yr;
+            }
+        }
+    }
+    rfp_store(&out->x, x);
+    rfp_store(&out->y, y);
+    if (st == ECGPU_SUCCESS) {
+        const Aff<R1> a{R1{x.v}, R1{y.v}, 0u};
+        Jac<R1> P, t, lhs;
+        jac_from_aff(P, a);
+        jac_mul_xabs_aff(t, a);
+        jac_mul_xabs(t, t);  // [x^2] P
+        const R1 bx = f_mul(a.x, R1{row_const_limb(blsc::BETA.l)});
+        jac_add_aff(lhs, P, bx, a.y);  // P + phi(P)
+        if (!jac_eq(lhs, t)) st = ECGPU_POINT_NOT_IN_GROUP;
+    }
+#if defined(__HIPCC__)
+    if ((threadIdx.x & 15u) == 0) {
+        out->inf = inf;
+        *st_out = (u8)st;
+    }
+#else
+    out->inf = inf;
+    *st_out = (u8)st;
+#endif
+}
+
 // the subgroup check of a decoded public key on a row (g1_in_subgroup of bls_curve.h): P + phi(P) == [x^2] P
 ROW_FN bool r_g1_in_subgroup(const A1* p) {
     if (p->inf) return true;
@@ -272,6 +454,28 @@ ROW_FN void r_hash_to_g2_finish(A2* out, const J2* q0, const J2* q1, u32* tab) {
         y = f_mul(f_mul(a.y, zi2), zi);
     }
     f_store2(&out->x, x);
+    f_store2(&out->y, y);
+    if (f_first_lane(tag)) out->inf = inf ? 1u : 0u;
+}
+
+// ... the same with one message per WAVE: both row pairs hold the point, the doublings run over both (jac_dbl_quad)
+ROW_FN void r_hash_to_g2_finish_quad(A2* out, const J2* q0, const J2* q1, u32* tab) {
+    const RP2* tag = nullptr;
+    PJ2 a{f_load2(tag, &q0->x), f_load2(tag, &q0->y), f_load2(tag, &q0->z)};
+    const PJ2 b{f_load2(tag, &q1->x), f_load2(tag, &q1->y), f_load2(tag, &q1->z)};
+    jac_add(a, a, b);
+    r_g2_clear_cofactor_quad(a, a);
+    const bool inf = jac_is_inf(a);
+    RP2 x, y;
+    f_set_zero(x);
+    f_set_zero(y);
+    if (!inf) {
+        const RP2 zi = f_inv_tab(a.z, tab);
+        const RP2 zi2 = f_sqr(zi);
+        x = f_mul(a.x, zi2);
+        y = f_mul(f_mul(a.y, zi2), zi);
+    }
+    f_store2(&out->x, x);  // (both pairs store the same limbs)
     f_store2(&out->y, y);
     if (f_first_lane(tag)) out->inf = inf ? 1u : 0u;
 }

@@ -285,6 +285,30 @@ int hs_g2_in_subgroup_row(const u8* xy, int pair) {
     const int r = (pair ? r_g2_in_subgroup<RP2>(&q) : r_g2_in_subgroup<RFp2>(&q)) ? 1 : 0;
     return g_ecg_column_overflows ? -1 : r;
 }
+// Signature::try_from + the group check on a row pair (k_sig_row): returns st_dec | st_grp << 8, the point as the kernel stores it
+int hs_sig_row(const u8* b96, u8* xy, int* inf) {
+    g_ecg_column_overflows = 0;
+    std::vector<u32> tab(16 * ROW_REG_DW, 0);
+    A2 p;
+    p.x = fp2_zero(), p.y = fp2_zero(), p.inf = 7;
+    u8 sd = 0xee, sg = 0xee;
+    r_sig_decode_and_group(&p, &sd, &sg, b96, tab.data());
+    out_a2(p, xy);
+    *inf = (int)p.inf;
+    return g_ecg_column_overflows ? -1 : (int)sd | ((int)sg << 8);
+}
+// key_validate on a row (k_pk_row): returns the status, the point as the kernel stores it
+int hs_pk_row(const u8* b48, u8* xy, int* inf) {
+    g_ecg_column_overflows = 0;
+    std::vector<u32> tab(16 * ROW_REG_DW, 0);
+    A1 p;
+    p.x = fp_zero(), p.y = fp_zero(), p.inf = 7;
+    u8 st = 0xee;
+    r_pk_validate(&p, &st, b48, tab.data());
+    out_a1(p, xy);
+    *inf = (int)p.inf;
+    return g_ecg_column_overflows ? -1 : (int)st;
+}
 // the subgroup check of a decoded public key on a row (k_pk_group_row): 1 in G1, 0 not
 int hs_g1_in_subgroup_row(const u8* xy) {
     g_ecg_column_overflows = 0;

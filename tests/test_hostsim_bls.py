@@ -236,6 +236,69 @@ def test_row_field_square_roots_signs_and_the_subgroup_check():
         assert L.hs_g2_in_subgroup_row(a2(Q), 0) == 0 and L.hs_g2_in_subgroup_row(a2(Q), 1) == 0
 
 
+def test_row_decoders_of_signatures_and_keys_against_the_oracle():
+    """bls_rowcurve.h r_sig_decode_and_group / r_pk_validate (k_sig_row / k_pk_row: the side stages of a small batch with their
+    square roots on rows): status, point and group verdict for valid encodings, points outside the subgroups and every
+    malformed class of tests/_blscases.py -- equal to the oracle's Signature::try_from + group check and key_validate."""
+    r = random.Random(77)
+    L = lib()
+    sigs = [B.g2_compress(B.g2_mul(B.G2, r.randrange(1, B.R))) for _ in range(3)] + [B.g2_compress(C.rand_g2_curve_point(r)) for _ in range(2)]
+    sigs += [B.INFINITY_SIGNATURE] + C.malformed_g2(r)
+    for c in sigs:
+        xy = ctypes.create_string_buffer(192)
+        inf = ctypes.c_int(0)
+        rc = L.hs_sig_row(c, xy, ctypes.byref(inf))
+        assert rc >= 0
+        wst, wpt = B.g2_decompress(c)
+        assert rc & 0xff == wst, c.hex()
+        if wst == 0 and wpt is not None:
+            assert inf.value == 0 and un2(xy.raw) == wpt
+            assert rc >> 8 == (0 if B.g2_in_subgroup(wpt) else 3), c.hex()
+        else:
+            assert xy.raw == bytes(192) and rc >> 8 == 0 and inf.value == int(wst == 0)
+    keys = [B.sk_to_pk(r.randrange(1, B.R)) for _ in range(3)] + [B.g1_compress(C.rand_g1_curve_point(r)) for _ in range(2)]
+    keys += [B.INFINITY_PUBLIC_KEY] + C.malformed_g1(r)
+    for c in keys:
+        xy = ctypes.create_string_buffer(96)
+        inf = ctypes.c_int(0)
+        st = L.hs_pk_row(c, xy, ctypes.byref(inf))
+        wst, wpt = B.key_validate(c)
+        assert st == wst, c.hex()
+        dst, dpt = B.g1_decompress(c)
+        if dst == 0 and dpt is not None:
+            assert un1(xy.raw) == dpt and inf.value == 0
+        else:
+            assert xy.raw == bytes(96) and inf.value == int(dst == 0)
+
+
+def test_g2_doubling_over_both_row_pairs_of_a_wave():
+    """bls_rowcurve.h jac_dbl_quad (k_h2c_finish_quad: one message per wave, the 126 doublings of the cofactor clearing with their six
+    products scheduled three deep over the wave's two row pairs) on 64 host lanes: a doubling equals the generic one in both
+    pairs -- random points, lazy-free edge coordinates, y = 0, the point at infinity -- and the end of the message stage equals
+    the oracle's hash_to_curve."""
+    r = random.Random(401)
+    L = lib()
+    L.hs_g2_dbl_quad.restype = ctypes.c_int
+
+    def jac(pt, z):  # (x z^2, y z^3, z)
+        z2 = B.f2_sqr(z)
+        return B.f2_mul(pt[0], z2), B.f2_mul(pt[1], B.f2_mul(z2, z)), z
+
+    pts = [jac(C.rand_g2_curve_point(r), (r.randrange(P), r.randrange(P))) for _ in range(6)]
+    pts += [jac(B.g2_mul(B.G2, r.randrange(1, B.R)), (1, 0))]
+    pts += [((r.randrange(P), r.randrange(P)), (0, 0), (r.randrange(1, P), 5)), ((1, 0), (1, 0), (0, 0)), ((0, 0), (2, 3), (7, 0))]
+    for X, Y, Z in pts:
+        blob = b"".join(b48(c % P) for c in (X[0], X[1], Y[0], Y[1], Z[0], Z[1]))
+        out, ref = ctypes.create_string_buffer(288), ctypes.create_string_buffer(288)
+        assert L.hs_g2_dbl_quad(blob, out, ref) == 0
+        assert out.raw == ref.raw
+    for m in (b"", b"abc", bytes(32), r.randbytes(32), r.randbytes(77)):
+        xy = ctypes.create_string_buffer(192)
+        inf = ctypes.c_int(9)
+        L.hs_hash_to_g2_quad(m, len(m), xy, ctypes.byref(inf))
+        assert inf.value == 0 and un2(xy.raw) == B.hash_to_g2(m)
+
+
 def _lin_raw(op, a, b=None):
     arr = ctypes.c_uint32 * 13
     out = arr()
