@@ -25,7 +25,10 @@ __device__ __forceinline__ void row_run(const Vm3Desc& d, const RowFile& F, u32 
         const u32 n = hu & 255, nder = (hu >> 8) & 255;
         const u32 w[8] = {w01.x, w01.y, w01.z, w01.w, w23.x, w23.y, w23.z, w23.w};
         const RowResult res = row_round_compute(F, n, nder, w, p_limb);
-        __syncthreads();  // every row of the tuple has read its operands: results may overwrite registers read in this round
+        // every row of the tuple has read its operands: results may overwrite registers read in this round.  (A register allocation
+        // without reuse inside a round would make this barrier unnecessary; a build without it runs part A in 0.499 ms against
+        // 0.503 -- profiles/r05g_*: the barriers are not what a round costs)
+        __syncthreads();
         row_round_store(F, n, nder, w, res);
         __syncthreads();  // ... and are visible to the next round
         w01 = n01;

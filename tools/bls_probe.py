@@ -49,7 +49,7 @@ def run(n):
         line = f"  verify iter {it}: {1e3*dt:.1f} ms  -> {n/dt:.0f} sigs/s, bad={bad}"
         for tag in ("bls_pk_validate", "bls_sig", "bls_h2c", "bls_pairing", "bls_vm3_a", "bls_vm3_inv", "bls_vm3_c", "bls_row_a", "bls_row_inv", "bls_row_c"):
             ms, cnt = _lib.prof_read(tag)
-            line += f" | {tag} {ms:.1f}"
+            line += f" | {tag} {ms:.3f}" if tag.startswith("bls_row") or n <= 1024 else f" | {tag} {ms:.1f}"
         print(line, flush=True)
         L.ecgpu_prof_enable(0)
 
