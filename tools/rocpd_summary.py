@@ -16,6 +16,26 @@ def main(db, out=None):
     for r in rows:
         lines.append(f"{r[0][:100]:100s} {r[1]:6d} {r[2]:12.1f} {r[3]:10.2f} {r[4]:10.2f} {r[5]:10.2f} {100 * r[2] / tot:6.2f} "
                      f"{r[6]:5d} {r[7]:5d} {r[8]:8d} {r[9]:6d}")
+    # per launch size (one row that averages a 65 536-tuple and a 2^20-tuple launch explains neither): kernels that
+    # were launched with more than one grid get a row per grid, largest share first
+    try:
+        cols = [c[1] for c in con.execute("pragma table_info(kernels)").fetchall()]
+        gx = next((c for c in cols if c.lower() in ("grid_x", "grid_size_x", "gridx")), None) or next((c for c in cols if "grid" in c.lower() and c.lower().endswith("x")), None)
+        if gx:
+            per = con.execute(f"select name, {gx}, count(*), avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, sum(end-start)/1e3 "
+                              f"from kernels group by name, {gx} order by 7 desc").fetchall()
+            multi = {}
+            for r in per:
+                multi.setdefault(r[0], []).append(r)
+            lines += ["", f"# per launch size ({gx} = work-items of the launch in x): kernels launched with more than one grid",
+                      f"{'kernel':70s} {gx:>12s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}"]
+            for name, rs in sorted(multi.items(), key=lambda kv: -sum(x[6] for x in kv[1])):
+                if len(rs) < 2:
+                    continue
+                for r in sorted(rs, key=lambda x: -x[1])[:8]:
+                    lines.append(f"{name[:70]:70s} {r[1]:12d} {r[2]:6d} {r[3]:10.2f} {r[4]:10.2f} {r[5]:10.2f}")
+    except sqlite3.Error as e:  # (an older schema: the aggregate table stands alone)
+        lines += ["", f"# per-launch-size table unavailable: {e}"]
     text = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(text)
