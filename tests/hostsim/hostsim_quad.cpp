@@ -65,4 +65,33 @@ int hs_g2_dbl_quad(const u8* in288, u8* out288, u8* ref288) {
     return g_ecg_column_overflows ? -1 : differ;
 }
 
+// one addition over both pairs against the generic one: two Jacobian points in (288 B each), out / ref 288 B; returns 0, 1 if the
+// pairs differ, -1 on an accumulator overflow
+int hs_g2_add_quad(const u8* p288, const u8* q288, u8* out288, u8* ref288) {
+    g_ecg_column_overflows = 0;
+    J2 pj, qj;
+    Fp* pc[6] = {&pj.x.c0, &pj.x.c1, &pj.y.c0, &pj.y.c1, &pj.z.c0, &pj.z.c1};
+    Fp* qc[6] = {&qj.x.c0, &qj.x.c1, &qj.y.c0, &qj.y.c1, &qj.z.c0, &qj.z.c1};
+    for (int k = 0; k < 6; k++) *pc[k] = q_in_fp(p288 + 48 * k), *qc[k] = q_in_fp(q288 + 48 * k);
+    const RP2* tag = nullptr;
+    const PJ2 a{f_load2(tag, &pj.x), f_load2(tag, &pj.y), f_load2(tag, &pj.z)}, b{f_load2(tag, &qj.x), f_load2(tag, &qj.y), f_load2(tag, &qj.z)};
+    PJ2 d, e;
+    jac_add_quad(d, a, b);
+    jac_add_inl(e, a, b);
+    J2 o, w;
+    f_store2(&o.x, d.x), f_store2(&o.y, d.y), f_store2(&o.z, d.z);
+    f_store2(&w.x, e.x), f_store2(&w.y, e.y), f_store2(&w.z, e.z);
+    Fp* oc[6] = {&o.x.c0, &o.x.c1, &o.y.c0, &o.y.c1, &o.z.c0, &o.z.c1};
+    Fp* wc[6] = {&w.x.c0, &w.x.c1, &w.y.c0, &w.y.c1, &w.z.c0, &w.z.c1};
+    for (int k = 0; k < 6; k++) q_out_fp(*oc[k], out288 + 48 * k), q_out_fp(*wc[k], ref288 + 48 * k);
+    const RowK K = row_k();
+    int differ = 0;
+    const RP2* coords[3] = {&d.x, &d.y, &d.z};
+    for (int k = 0; k < 3; k++) {
+        const RFp cn = rfp_canon(RFp{coords[k]->v}, K);
+        for (int l = 0; l < 32; l++) differ |= cn.v.v[l] != cn.v.v[32 + l];
+    }
+    return g_ecg_column_overflows ? -1 : differ;
+}
+
 }  // extern "C"

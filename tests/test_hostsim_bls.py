@@ -292,6 +292,20 @@ def test_g2_doubling_over_both_row_pairs_of_a_wave():
         out, ref = ctypes.create_string_buffer(288), ctypes.create_string_buffer(288)
         assert L.hs_g2_dbl_quad(blob, out, ref) == 0
         assert out.raw == ref.raw
+    # additions over both pairs: generic pairs, P + P (-> the doubling), P + (-P) (-> infinity), infinity on either side, the
+    # same point in two Jacobian representations
+    L.hs_g2_add_quad.restype = ctypes.c_int
+    blob = lambda J: b"".join(b48(c % P) for c in (J[0][0], J[0][1], J[1][0], J[1][1], J[2][0], J[2][1]))
+    A, Bq = C.rand_g2_curve_point(r), C.rand_g2_curve_point(r)
+    rz = lambda: (r.randrange(1, P), r.randrange(P))
+    inf_pt = ((1, 0), (1, 0), (0, 0))
+    pairs = [(jac(A, rz()), jac(Bq, rz())), (jac(A, rz()), jac(A, rz())), (jac(A, (1, 0)), jac(A, (1, 0))), (jac(A, rz()), jac(B.g2_neg(A), rz())),
+             (inf_pt, jac(Bq, rz())), (jac(A, rz()), inf_pt), (inf_pt, inf_pt)]
+    pairs += [(jac(C.rand_g2_curve_point(r), rz()), jac(C.rand_g2_curve_point(r), rz())) for _ in range(4)]
+    for J1, J2 in pairs:
+        out, ref = ctypes.create_string_buffer(288), ctypes.create_string_buffer(288)
+        assert L.hs_g2_add_quad(blob(J1), blob(J2), out, ref) == 0
+        assert out.raw == ref.raw
     for m in (b"", b"abc", bytes(32), r.randbytes(32), r.randbytes(77)):
         xy = ctypes.create_string_buffer(192)
         inf = ctypes.c_int(9)
