@@ -73,10 +73,6 @@ ROW_FN rv32 rv_in_vgpr(rv32 x) {
     asm volatile("" : "+v"(x));
     return x;
 }
-ROW_FN rv64 rv_pin64(rv64 x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
 ROW_FN rv32 rv_eq(rv32 a, rv32 b) { return a == b ? 1u : 0u; }
 ROW_FN rv32 rv_sar(rv32 a, u32 n) { return (u32)((int32_t)a >> n); }
 // 1 in every lane of the row if x != 0 in any of its lanes (the rows of a wave decide independently)
@@ -164,7 +160,6 @@ ROW_FN rv32 rv_or(rv32 a, rv32 b) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] | b.v[l_]
 ROW_FN rv32 rv_xor(rv32 a, rv32 b) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] ^ b.v[l_]; return r; }
 ROW_FN rv32 rv_shl(rv32 a, u32 n) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] << n; return r; }
 ROW_FN rv32 rv_in_vgpr(rv32 x) { return x; }
-ROW_FN rv64 rv_pin64(rv64 x) { return x; }
 ROW_FN rv32 rv_eq(rv32 a, rv32 b) { rv32 r; ROW_EACH r.v[l_] = a.v[l_] == b.v[l_] ? 1u : 0u; return r; }
 ROW_FN rv32 rv_sar(rv32 a, u32 n) { rv32 r; ROW_EACH r.v[l_] = (u32)((int32_t)a.v[l_] >> n); return r; }
 ROW_FN rv32 rv_row_any(rv32 x) {
@@ -213,40 +208,24 @@ ROW_FN void rv_lds_write(u32* lds, rv32 dw, rv32 v, rv32 pred) {
 // sum_{k < N} A_k * B_k / R mod p (one Montgomery reduction, result < 2p for sum of bound products < R / p): a[k] = limb
 // `lane` of A_k, b[k][i] = limb i of B_k (the same in every lane of the row), p_limb = limb `lane` of p (0 beyond limb 12).
 // Operand limbs <= 2^30; the accumulator of a lane never exceeds 2^35 + 8 * 2^60.
-#ifndef ECG_ROW_SUMPROD
-#define ECG_ROW_SUMPROD 1  // 0: round 5's first form (A/B builds, tools/build_variant.sh); 2: accumulator pinned after every step
-#endif
 template <int N>
 ROW_FN rv32 row_sumprod(const rv32 (&a)[N], const rv32 (&b)[N][13], rv32 p_limb) {
-#if ECG_ROW_SUMPROD == 0
-    const rv32 mask = rv_splat(FP_MASK), n0 = rv_splat(blsc::N0);
-#else
     const rv32 mask = rv_in_vgpr(rv_splat(FP_MASK)), n0 = rv_splat(blsc::N0);  // (a DPP instruction takes no literal operand)
-#endif
     rv64 acc = rv_zero64();
 #pragma unroll
     for (int i = 0; i < FP_N; i++) {
-#if ECG_ROW_SUMPROD == 0
 #pragma unroll
         for (int k = 0; k < N; k++) acc = rv_mad64(a[k], b[k][i], acc);
-        const rv32 m = rv_and(rv_mul_lo(rv_bcast0(rv_lo(acc)), n0), mask);  // the quotient digit: lane 0's column becomes 0 mod 2^30
-        acc = rv_mad64(m, p_limb, acc);
-        // the window moves one limb down: lane j keeps its carry (column i + j + 1) and takes the low 30 bits of lane j + 1
-        const rv64 hi = rv_shr64(acc, 30);
-        acc = rv_add64(hi, rv_from_next(rv_and(rv_lo(acc), mask)));
-#else
-#pragma unroll
-        for (int k = 0; k < N; k++) acc = ECG_ROW_SUMPROD == 2 ? rv_pin64(rv_mad64(a[k], b[k][i], acc)) : rv_mad64(a[k], b[k][i], acc);
         // the quotient digit: lane 0's column becomes 0 mod 2^30.  (Every lane multiplies its own column, lane 0's product is
         // the one broadcast -- in this order the broadcast and the shift below are DPP operands of the two v_and_b32, not
-        // v_mov_b32_dpp of their own in front of a VOP3 instruction: 2 of the 12 + N instructions of an iteration)
+        // v_mov_b32_dpp of their own in front of a VOP3 instruction: 2 of the 12 + N instructions of an iteration.  The first
+        // form of round 5 -- bcast(lo) * n0 & mask, from_next(lo & mask) -- and a form with the accumulator pinned after every
+        // step were measured beside this one: profiles/r05w_*.)
         const rv32 m = rv_and(rv_bcast0(rv_mul_lo(rv_lo(acc), n0)), mask);
         acc = rv_mad64(m, p_limb, acc);
         // the window moves one limb down: lane j keeps its carry (column i + j + 1) and takes the low 30 bits of lane j + 1
         const rv64 hi = rv_shr64(acc, 30);
         acc = rv_add64(hi, rv_and(rv_from_next(rv_lo(acc)), mask));
-        if (ECG_ROW_SUMPROD == 2) acc = rv_pin64(acc);
-#endif
     }
     // acc < 2^35: two carry passes upwards leave limbs <= 2^30 (the top limb of a value < 2p is far below)
     rv32 v = rv_add(rv_and(rv_lo(acc), mask), rv_from_prev(rv_lo(rv_shr64(acc, 30))));
