@@ -492,7 +492,7 @@ static const int g_row_stages = [] {  // ECGPU_ROW_STAGES=0: the SSWU maps and t
 }();
 static const u32 g_h2c_quad_max = [] {  // ECGPU_H2C_QUAD_MAX: up to this many messages the end of the message stage takes a WAVE per message
     const char* e = getenv("ECGPU_H2C_QUAD_MAX");  // (0: always a row pair per message)
-    return e ? (u32)strtoul(e, nullptr, 10) : 512u;
+    return e ? (u32)strtoul(e, nullptr, 10) : 1024u;  // (768 / 1 024 messages: 1.42 ms against the row pair's 1.47-1.49, profiles/r05l_*)
 }();
 static const int g_row_decode = [] {  // ECGPU_ROW_DECODE=0: keys and signatures of a small batch are decoded on one lane each (their square roots
     const char* e = getenv("ECGPU_ROW_DECODE");  // included), only the subgroup checks run on rows: the first form of round 5
