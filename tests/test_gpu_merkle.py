@@ -912,9 +912,10 @@ def _random_step(r, st, m, fork):
                                                       ("altair", "minimal", 700, 170), ("bellatrix", "minimal", 1100, 170),
                                                       ("capella", "mainnet", 2500, 170), ("deneb", "minimal", 37, 170),
                                                       ("deneb", "mainnet", 5000, 170), ("deneb", "minimal", 2040, 170),
-                                                      ("electra", "minimal", 900, 170)])
+                                                      ("electra", "minimal", 900, 170),
+                                                      ("capella", "mainnet", 300_000, 30)])  # (trees of height 19: 1 024-entry regions, several active per patch set)
 def test_resident_state_randomised_patch_append_truncate_sequences(gpu, fork, preset, n_val, steps):
-    """1 480 randomised steps over every resident fork (phase0 ... electra; phase0 with attestations pushed and rotated): after EVERY step the resident root (dirty paths climbed, rebuilt fields,
+    """1 510 randomised steps over every resident fork (phase0 ... electra; phase0 with attestations pushed and rotated): after EVERY step the resident root (dirty paths climbed, rebuilt fields,
     finishing jobs over the cached levels) equals ecgpu_htr_beacon_state of the re-serialized state, computed from scratch."""
     from ethereum_consensus_amd import synthetic
     from tests._statemodel import EncodingModel
