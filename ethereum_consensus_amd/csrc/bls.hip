@@ -500,7 +500,9 @@ static const int g_row_decode = [] {  // ECGPU_ROW_DECODE=0: keys and signatures
 }();
 static const u32 g_h2c_row_max = [] {
     const char* e = getenv("ECGPU_H2C_ROW_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : 1024u;  // (4 096 messages on rows: 3.2 ms against the lane pair's 2.9, profiles/r05l_probe.txt)
+    // (first form of the rows: 4 096 messages 3.2 ms against the lane pair's 2.9, profiles/r05l_probe.txt: 1 024.  With the decoders on
+    // rows and the wave-per-message end: 2 048 tuples 6.5 -> 5.2 ms, 3 072 tuples 6.6 -> 6.1, 4 096 tuples 6.6 -> 7.7, profiles/r05o_*, r05p2_*)
+    return e ? (u32)strtoul(e, nullptr, 10) : 3072u;
 }();
 // Up to this many tuples the pairing check runs on the row machine (round 5, bls_row.hip: one workgroup per tuple, one Fp
 // operation per 16-lane row): a lone check 3.45 -> 1.0 ms, 1 024 tuples 3.4 -> 2.3 ms.  Its throughput is below the lane groups'
@@ -622,7 +624,9 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
     const bool two_waves = g_tower.load() != 2 && (g_g2_waves == 2 || (g_g2_waves == 0 && n > 65536u) || overlap_sides);
     // (round 5) small batches: the decoding on one lane per signature, the psi subgroup check -- a 63-doubling chain -- with one
     // signature per 16-lane ROW (bls_rowcurve.h); likewise the two SSWU maps of a message on a row each
-    const bool rows = g_row_stages && n <= g_h2c_row_max;
+    // (beyond 1 024 tuples only for batches of few keys per tuple: with 2 048 keys per aggregate the key stage -- or the sums over a
+    // registry -- fills the chip beside the side stages, and 2 048 such tuples cost 6.96 ms on rows against 6.74, profiles/r05r_bench.json)
+    const bool rows = g_row_stages && n <= g_h2c_row_max && (n <= 1024u || !d_pk_off || n_pks < 4ull * n);
     auto run_sig = [&] {
         ProfScope ps("bls_sig", s3);
         if (rows) {
