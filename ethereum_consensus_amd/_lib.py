@@ -77,6 +77,15 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_resident_state_truncate": (c_int, [ctypes.c_void_p, c_int, c_u64]),
         "ecgpu_resident_state_replace": (c_int, [ctypes.c_void_p, c_int, u8p, c_u64]),
         "ecgpu_resident_state_size": (c_u64, [ctypes.c_void_p]),
+        "ecgpu_resident_state_patch_field": (c_int, [ctypes.c_void_p, c_u32, c_u64, u8p, c_u64]),
+        "ecgpu_resident_state_patch_elements": (c_int, [ctypes.c_void_p, c_u32, c_u64, u8p, c_u64]),
+        "ecgpu_resident_state_push": (c_int, [ctypes.c_void_p, c_u32, u8p, c_u64]),
+        "ecgpu_resident_state_truncate_field": (c_int, [ctypes.c_void_p, c_u32, c_u64]),
+        "ecgpu_resident_state_set_field": (c_int, [ctypes.c_void_p, c_u32, u8p, c_u64]),
+        "ecgpu_resident_state_add_validator": (c_int, [ctypes.c_void_p, u8p, c_u64]),
+        "ecgpu_resident_state_rotate_participation": (c_int, [ctypes.c_void_p]),
+        "ecgpu_resident_state_flush": (c_int, [ctypes.c_void_p]),
+        "ecgpu_resident_state_field_size": (ctypes.c_int64, [ctypes.c_void_p, c_u32]),
         "ecgpu_resident_state_root": (c_int, [ctypes.c_void_p, u8p]),
         "ecgpu_resident_state_root_dev": (c_int, [ctypes.c_void_p, u8p, ctypes.c_void_p]),
         "ecgpu_compute_shuffled_indices": (c_int, [ctypes.c_void_p, c_u64, u8p, c_u32, ctypes.c_void_p]),

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "merkle_driver.h"
+#include "state_fields.h"
 #include "state_plan.h"
 #include "state_tree_host.h"
 
@@ -378,7 +379,10 @@ __global__ void k_apply_patches(u8* state, const u8* data, const PatchDesc* p) {
 
 }  // namespace ecg
 
+struct ResidentSink;  // the device-resident encoding as state_fields.h's FieldWriter sees it (below)
+
 struct ecgpu_resident_state {
+    ecg::FieldWriter<ResidentSink> queue;  // field-addressed writes / pushes not yet applied (round 6)
     int preset = 0;
     int fork = ecg::FORK_DENEB;
     u8* d_ssz = nullptr;   // encoding (cap_bytes allocated: lists grow in place, ecgpu_resident_state_append)
@@ -455,6 +459,20 @@ int ecgpu_resident_state_create_fork(int fork, int preset, const uint8_t* ssz, u
 // ---- lists that change length (add_validator_to_registry, phase0/block_processing.rs:317-349; the eth1_data_votes reset of
 // process_eth1_data_reset; historical_summaries growing once per period) ------------------------------------------------------
 namespace {
+// Cross-stream ordering (advisor, round 5).  A state may be handed from one host thread to another (each has its own stream)
+// or rooted on a caller's stream: whatever changes bytes or tree marks on stream `s` first waits for the last change and for
+// the last root enqueued on OTHER streams -- stream order covers the same stream.
+static int order_after_earlier_work(ecgpu_resident_state* st, hipStream_t s) {
+    if (st->patched && st->patch_stream != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, st->patched, 0));
+    if (st->rooted && st->root_stream != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, st->rooted, 0));
+    return ECGPU_SUCCESS;
+}
+static int record_change(ecgpu_resident_state* st, hipStream_t s) {
+    if (!st->patched) ECG_HIP_CHECK(hipEventCreateWithFlags(&st->patched, hipEventDisableTiming));
+    ECG_HIP_CHECK(hipEventRecord(st->patched, s));
+    st->patch_stream = s;
+    return ECGPU_SUCCESS;
+}
 // variable-size fields of the state in encoding order: position of the offset word in the fixed part, element size
 struct VarField {
     u64 word;
@@ -509,9 +527,17 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
     VarField vf[N_VAR_FIELDS];
     var_fields(st, vf);
     const bool attestations = st->fork == FORK_PHASE0 && (fi == 4 || fi == 5);
-    if (fi < 0 || fi >= N_VAR_FIELDS || vf[fi].word == NO_FIELD || (vf[fi].elem == 0 && !(replace && attestations))) {
+    const bool header = fi == 7;  // latest_execution_payload_header: one container whose extra_data changes length (replace only)
+    if (fi < 0 || fi >= N_VAR_FIELDS || vf[fi].word == NO_FIELD || (vf[fi].elem == 0 && !(replace && (attestations || header)))) {
         set_last_error(attestations ? "a list of variable-size elements changes through ecgpu_resident_state_replace" : "not a variable-length list of this fork");
         return ECGPU_ERR_BAD_ARG;
+    }
+    if (header) {  // what the reference's deserializer accepts: the fixed part, <= 32 bytes of extra_data, its offset word == the fixed size
+        const u64 hf = payload_header_fixed(st->fork);
+        if (!data || add_len < hf || add_len > hf + 32 || rd32(data + PAYLOAD_EXTRA_DATA_OFFSET_WORD) != hf) {
+            set_last_error("payload header: bad length or extra_data offset");
+            return ECGPU_ERR_BAD_ARG;
+        }
     }
     u8 new_att_root[32];
     if (attestations) {  // the list's root, from the caller's bytes (which also validates the encoding), before anything moves
@@ -557,7 +583,9 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
     Arena& ar = c->arena(s);
-    int rc = splice(st, s, ar, pos, remove, data, insert);
+    int rc = order_after_earlier_work(st, s);
+    if (rc) return rc;
+    rc = splice(st, s, ar, pos, remove, data, insert);
     if (rc) return rc;
     // later fields start `insert - remove` bytes later: their offset words change on the host mirror and on the device
     for (int k = fi + 1; k < N_VAR_FIELDS; k++)
@@ -602,15 +630,58 @@ static int resize_field(ecgpu_resident_state* st, int fi, const u8* data, u64 ad
             }
         }
     }
+    if ((rc = record_change(st, s))) return rc;
     ECG_HIP_CHECK(hipStreamSynchronize(s));
     return ECGPU_SUCCESS;
 }
+static int patch_now(ecgpu_resident_state* st, const u64* offsets, const u64* data_off, const u8* data, u32 n);
+// previous_epoch_participation <- current_epoch_participation <- zeros, on the device (nothing travels); both trees are rebuilt
+// at the next root (2 x n / 32 hash64)
+static int rotate_now(ecgpu_resident_state* st, u64 prev_start, u64 cur_start, u64 len) {
+    ThreadCtx* c = tctx();
+    hipStream_t s = c->stream_or_own(nullptr);
+    int rc = order_after_earlier_work(st, s);
+    if (rc) return rc;
+    ECG_HIP_CHECK(hipMemcpyAsync(st->d_ssz + prev_start, st->d_ssz + cur_start, len, hipMemcpyDeviceToDevice, s));
+    ECG_HIP_CHECK(hipMemsetAsync(st->d_ssz + cur_start, 0, len, s));
+    StatePlan plan;
+    if (!build_state_plan(st->fork, st->h_fixed.data(), st->n_bytes, st->preset, plan, st->ext_roots(), nullptr)) {
+        set_last_error(plan.error);
+        return ECGPU_ERR_BAD_ARG;
+    }
+    for (u32 k = 0; k < plan.bigs.size() && k < TREE_MAX_FIELDS; k++)
+        if ((plan.bigs[k].out_chunk == 15 || plan.bigs[k].out_chunk == 16) && plan.bigs[k].mix) st->trees.f[k].all_dirty = true;
+    return record_change(st, s);
+}
 }  // namespace
+
+// the resident state as csrc/state_fields.h's queue sees it
+struct ResidentSink {
+    ecgpu_resident_state* st;
+    int fork() const { return st->fork; }
+    int preset() const { return st->preset; }
+    const u8* fixed() const { return st->h_fixed.data(); }
+    u64 size() const { return st->n_bytes; }
+    void fail(const char* m) { set_last_error(m); }
+    int apply_patches(const u64* offsets, const u64* data_off, const u8* data, u32 n) { return patch_now(st, offsets, data_off, data, n); }
+    int apply_resize(u32 vi, const u8* data, u64 add_len, u64 keep, FieldResize mode) {
+        return resize_field(st, (int)vi, data, add_len, keep, mode == FIELD_APPEND ? RESIZE_APPEND : mode == FIELD_TRUNCATE ? RESIZE_TRUNCATE : RESIZE_REPLACE);
+    }
+    int apply_rotate(u64 prev_start, u64 cur_start, u64 len) { return rotate_now(st, prev_start, cur_start, len); }
+};
+// everything queued through the field-addressed entries reaches the device before an operation addressed in bytes, a root,
+// or a size query sees the state
+static int flush_queue(ecgpu_resident_state* st) {
+    if (!st->queue.pending()) return ECGPU_SUCCESS;
+    ResidentSink sink{st};
+    return st->queue.flush(sink);
+}
 
 int ecgpu_resident_state_append(ecgpu_resident_state_t* st, int field, const uint8_t* data, uint64_t n_bytes) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!st) return ECGPU_ERR_BAD_ARG;
+    if ((rc = flush_queue(st))) return rc;
     return resize_field(st, field, data, n_bytes, 0, RESIZE_APPEND);
 }
 
@@ -618,6 +689,7 @@ int ecgpu_resident_state_replace(ecgpu_resident_state_t* st, int field, const ui
     int rc = ensure_init();
     if (rc) return rc;
     if (!st) return ECGPU_ERR_BAD_ARG;
+    if ((rc = flush_queue(st))) return rc;
     return resize_field(st, field, data, n_bytes, 0, RESIZE_REPLACE);
 }
 
@@ -625,10 +697,12 @@ int ecgpu_resident_state_truncate(ecgpu_resident_state_t* st, int field, uint64_
     int rc = ensure_init();
     if (rc) return rc;
     if (!st) return ECGPU_ERR_BAD_ARG;
+    if ((rc = flush_queue(st))) return rc;
     return resize_field(st, field, nullptr, 0, new_n_bytes, RESIZE_TRUNCATE);
 }
 
-uint64_t ecgpu_resident_state_size(const ecgpu_resident_state_t* st) { return st ? st->n_bytes : 0; }
+// (the size the caller's program order implies: queued pushes count)
+uint64_t ecgpu_resident_state_size(const ecgpu_resident_state_t* st) { return st ? st->n_bytes + st->queue.pushed_bytes() : 0; }
 
 void ecgpu_resident_state_destroy(ecgpu_resident_state_t* st) {
     if (!st) return;
@@ -646,6 +720,15 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
     int rc = ensure_init();
     if (rc) return rc;
     if (!st || (n && (!offsets || !data_off || !data))) return ECGPU_ERR_BAD_ARG;
+    if ((rc = flush_queue(st))) return rc;  // byte offsets refer to the encoding as program order has left it
+    return patch_now(st, offsets, data_off, data, n);
+}
+
+}  // extern "C"
+
+namespace {
+static int patch_now(ecgpu_resident_state* st, const u64* offsets, const u64* data_off, const u8* data, u32 n) {
+    int rc = ECGPU_SUCCESS;
     if (!n) return ECGPU_SUCCESS;
     // (scratch vectors are the thread's: a slot's 4 096 patches are 200 KB of descriptors -- above malloc's mmap threshold, so a
     // fresh vector per call is an mmap, its page faults and an munmap)
@@ -735,7 +818,7 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
         if (!pairs.empty()) ECG_HIP_CHECK(hipMemcpyAsync(d_block + off_pairs, pairs.data(), 8 * pairs.size(), hipMemcpyHostToDevice, s));
         if (total) ECG_HIP_CHECK(hipMemcpyAsync(d_block + off_data, data, total, hipMemcpyHostToDevice, s));
     }
-    if (st->rooted && st->root_stream != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, st->rooted, 0));
+    if ((rc = order_after_earlier_work(st, s))) return rc;
     hipLaunchKernelGGL(k_apply_patches, dim3(n), dim3(64), 0, s, st->d_ssz, (const u8*)(d_block + off_data), (const PatchDesc*)d_block);
     ECG_HIP_CHECK(hipGetLastError());
     if (!pairs.empty()) {
@@ -746,11 +829,76 @@ int ecgpu_resident_state_patch(ecgpu_resident_state_t* st, const uint64_t* offse
         for (u64 b = 0; b < descs[i].len; b++)
             if (descs[i].dst_off + b < st->h_fixed.size()) st->h_fixed[descs[i].dst_off + b] = data[descs[i].src_off + b];
     // a root may be asked for on another stream (ecgpu_resident_state_root_dev): it waits for this event, not the host
-    if (!st->patched) ECG_HIP_CHECK(hipEventCreateWithFlags(&st->patched, hipEventDisableTiming));
-    ECG_HIP_CHECK(hipEventRecord(st->patched, s));
-    st->patch_stream = s;
+    if ((rc = record_change(st, s))) return rc;
     if (!ring) ECG_HIP_CHECK(hipStreamSynchronize(s));
     return ECGPU_SUCCESS;
+}
+}  // namespace
+
+extern "C" {
+
+// ---- field-addressed entries (round 6; csrc/state_fields.h) ------------------------------------------------------------------
+#define ECG_FIELD_ENTRY(st)                       \
+    int rc = ensure_init();                       \
+    if (rc) return rc;                            \
+    if (!(st)) return ECGPU_ERR_BAD_ARG;          \
+    ResidentSink sink { (st) }
+
+int ecgpu_resident_state_patch_field(ecgpu_resident_state_t* st, uint32_t field, uint64_t offset_in_field, const uint8_t* data, uint64_t n_bytes) {
+    ECG_FIELD_ENTRY(st);
+    return st->queue.write(sink, field, offset_in_field, data, n_bytes);
+}
+
+int ecgpu_resident_state_patch_elements(ecgpu_resident_state_t* st, uint32_t field, uint64_t first_index, const uint8_t* data, uint64_t n_bytes) {
+    ECG_FIELD_ENTRY(st);
+    const FieldStatic f = field_static(st->fork, st->preset, field);
+    if (!f.present || !f.elem || n_bytes % f.elem) {
+        set_last_error("patch_elements: not a whole number of elements of this field");
+        return ECGPU_ERR_BAD_ARG;
+    }
+    if (first_index > (~0ull) / f.elem) return ECGPU_ERR_BAD_ARG;
+    return st->queue.write(sink, field, first_index * f.elem, data, n_bytes);
+}
+
+int ecgpu_resident_state_push(ecgpu_resident_state_t* st, uint32_t field, const uint8_t* data, uint64_t n_bytes) {
+    ECG_FIELD_ENTRY(st);
+    return st->queue.push(sink, field, data, n_bytes);
+}
+
+int ecgpu_resident_state_truncate_field(ecgpu_resident_state_t* st, uint32_t field, uint64_t new_n_bytes) {
+    ECG_FIELD_ENTRY(st);
+    return st->queue.truncate(sink, field, new_n_bytes);
+}
+
+int ecgpu_resident_state_set_field(ecgpu_resident_state_t* st, uint32_t field, const uint8_t* data, uint64_t n_bytes) {
+    ECG_FIELD_ENTRY(st);
+    return st->queue.set(sink, field, data, n_bytes);
+}
+
+int ecgpu_resident_state_add_validator(ecgpu_resident_state_t* st, const uint8_t validator121[121], uint64_t balance) {
+    ECG_FIELD_ENTRY(st);
+    if (!validator121) return ECGPU_ERR_BAD_ARG;
+    return st->queue.add_validator(sink, validator121, balance);
+}
+
+int ecgpu_resident_state_rotate_participation(ecgpu_resident_state_t* st) {
+    ECG_FIELD_ENTRY(st);
+    return st->queue.rotate_participation(sink);
+}
+
+int ecgpu_resident_state_flush(ecgpu_resident_state_t* st) {
+    ECG_FIELD_ENTRY(st);
+    (void)sink;
+    return flush_queue(st);
+}
+
+int64_t ecgpu_resident_state_field_size(ecgpu_resident_state_t* st, uint32_t field) {
+    if (!st) return ECGPU_ERR_BAD_ARG;
+    ResidentSink sink{st};
+    FieldLoc loc;
+    u64 seen = 0;
+    if (!st->queue.locate(sink, field, loc, seen)) return ECGPU_ERR_BAD_ARG;
+    return (int64_t)seen;
 }
 
 // Root of a resident state: (1) fields flagged for a rebuild are rebuilt level by level, (2) ONE climb launch re-hashes the
@@ -760,6 +908,7 @@ int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, e
     int rc = ensure_init();
     if (rc) return rc;
     if (!st || !d_root) return ECGPU_ERR_BAD_ARG;
+    if ((rc = flush_queue(st))) return rc;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(stream);
     if (st->patched && st->patch_stream != s) ECG_HIP_CHECK(hipStreamWaitEvent(s, st->patched, 0));
@@ -779,6 +928,7 @@ int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]) {
     if (!st || !root) return ECGPU_ERR_BAD_ARG;
     int rc = ensure_init();
     if (rc) return rc;
+    if ((rc = flush_queue(st))) return rc;
     ThreadCtx* c = tctx();
     hipStream_t s = c->stream_or_own(nullptr);
     u8* d_root = st->d_rootbuf;

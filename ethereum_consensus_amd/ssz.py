@@ -197,14 +197,64 @@ class ResidentBeaconStateDeneb:
         _lib.check(rc, "ecgpu_resident_state_truncate")
 
     def add_validator(self, validator121: bytes, balance: int) -> None:
-        """add_validator_to_registry (phase0/block_processing.rs:317-349; altair and later: + participation flags, inactivity score)"""
-        self.append(self.VALIDATORS, validator121)
-        self.append(self.BALANCES, int(balance).to_bytes(8, "little"))
-        if self._fork == 0:
-            return
-        self.append(self.PREVIOUS_EPOCH_PARTICIPATION, b"\x00")
-        self.append(self.CURRENT_EPOCH_PARTICIPATION, b"\x00")
-        self.append(self.INACTIVITY_SCORES, bytes(8))
+        """add_validator_to_registry (phase0/block_processing.rs:317-349; altair and later: + participation flags, inactivity
+        score): queued, applied at the next root -- one call of the C ABI, the fork's list of pushes is the library's"""
+        if len(validator121) != 121:
+            raise MerkleizationError("a Validator record is 121 bytes")
+        self._field_rc(self._L.ecgpu_resident_state_add_validator(self._h, _buf(validator121), int(balance)), "add_validator")
+
+    # ---- field-addressed changes (include/ecgpu.h ECGPU_BS_*: the field's POSITION in the fork's BeaconState container) ----
+    FIELD_POSITIONS = {name: i for i, name in enumerate((
+        "genesis_time", "genesis_validators_root", "slot", "fork", "latest_block_header", "block_roots", "state_roots",
+        "historical_roots", "eth1_data", "eth1_data_votes", "eth1_deposit_index", "validators", "balances", "randao_mixes",
+        "slashings", "previous_epoch_participation", "current_epoch_participation", "justification_bits",
+        "previous_justified_checkpoint", "current_justified_checkpoint", "finalized_checkpoint", "inactivity_scores",
+        "current_sync_committee", "next_sync_committee", "latest_execution_payload_header", "next_withdrawal_index",
+        "next_withdrawal_validator_index", "historical_summaries", "deposit_receipts_start_index", "deposit_balance_to_consume",
+        "exit_balance_to_consume", "earliest_exit_epoch", "consolidation_balance_to_consume", "earliest_consolidation_epoch",
+        "pending_balance_deposits", "pending_partial_withdrawals", "pending_consolidations"))}
+    FIELD_POSITIONS["previous_epoch_attestations"] = 15  # phase0
+    FIELD_POSITIONS["current_epoch_attestations"] = 16
+
+    def _pos(self, field) -> int:
+        return self.FIELD_POSITIONS[field] if isinstance(field, str) else int(field)
+
+    def _field_rc(self, rc: int, what: str) -> None:
+        if rc == -3:
+            raise MerkleizationError((self._L.ecgpu_last_error() or what.encode()).decode())
+        _lib.check(rc, "ecgpu_resident_state_" + what)
+
+    def patch_field(self, field, offset_in_field: int, data: bytes) -> None:
+        """bytes of one field overwritten, addressed INSIDE the field (`state.slot = ..`, one byte of a validator record ...)"""
+        self._field_rc(self._L.ecgpu_resident_state_patch_field(self._h, self._pos(field), offset_in_field, _buf(data), len(data)), "patch_field")
+
+    def patch_elements(self, field, first_index: int, data: bytes) -> None:
+        """elements first_index .. of a list / vector overwritten (`state.balances[i] = ..`, `state.block_roots[slot % N] = ..`)"""
+        self._field_rc(self._L.ecgpu_resident_state_patch_elements(self._h, self._pos(field), first_index, _buf(data), len(data)), "patch_elements")
+
+    def push(self, field, data: bytes) -> None:
+        """`state.<list>.push(..)`: whole elements appended"""
+        self._field_rc(self._L.ecgpu_resident_state_push(self._h, self._pos(field), _buf(data), len(data)), "push")
+
+    def truncate_field(self, field, new_n_bytes: int) -> None:
+        self._field_rc(self._L.ecgpu_resident_state_truncate_field(self._h, self._pos(field), new_n_bytes), "truncate_field")
+
+    def set_field(self, field, data: bytes) -> None:
+        """the whole field exchanged for a new serialization of it"""
+        self._field_rc(self._L.ecgpu_resident_state_set_field(self._h, self._pos(field), _buf(data), len(data)), "set_field")
+
+    def rotate_participation(self) -> None:
+        """process_participation_flag_updates: previous = current, current = zeros (on the device)"""
+        self._field_rc(self._L.ecgpu_resident_state_rotate_participation(self._h), "rotate_participation")
+
+    def flush(self) -> None:
+        self._field_rc(self._L.ecgpu_resident_state_flush(self._h), "flush")
+
+    def field_size(self, field) -> int:
+        n = int(self._L.ecgpu_resident_state_field_size(self._h, self._pos(field)))
+        if n < 0:
+            raise MerkleizationError("no such field in this fork")
+        return n
 
     def __len__(self):
         return int(self._L.ecgpu_resident_state_size(self._h))

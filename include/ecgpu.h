@@ -166,10 +166,19 @@ uint64_t ecgpu_last_hash64_count(void);
  * (phase0/slot_processing.rs:67); shipping 148 MB of serialization over PCIe per slot would cost more than hashing
  * it.  A resident state is uploaded once; afterwards only the bytes a block changed travel: `patch` overwrites byte
  * ranges of the encoding in place (same total length: field values, balances, participation flags, roots ...),
- * `root` re-Merkleizes on the device; lists change length through `append` / `truncate` below.  One resident
- * state must not be used from two threads at once.  The state also caches hash_tree_root(Validator) of every record
- * (32 B each): a patch marks the records its bytes belong to, `root` re-hashes only those and feeds the registry to the
- * tree as ready chunks (first level) -- same roots, half the time. */
+ * `root` re-Merkleizes on the device; lists change length through `append` / `truncate` below.
+ * What stays on the device (csrc/state_tree.h): next to the encoding, EVERY interior node of the tree
+ * of every big field (the registry, balances, participation, inactivity scores, the root vectors, randao mixes ...).  A
+ * patch / append marks the level-0 entries its bytes belong to; `root` re-hashes the paths above the marked entries and
+ * nothing else (one climb launch), then one finishing job per field and the small fields: ~28 k hash64 for a slot's 4 096
+ * balance + 4 096 participation writes on a 2^20-validator state instead of 10.1 M.  A field rewritten wholesale (an epoch's
+ * balances) or whose tree height changed is rebuilt level by level at the next root.
+ * Threads, streams, ordering.  One resident state must not be used from two host threads AT ONCE; it may be handed from one
+ * thread to another.  patch / append / truncate / replace and the field-addressed entries below run on the calling thread's
+ * own stream; root_dev runs on the caller's stream.  Each of them first waits (hipStreamWaitEvent, no host block) for the last
+ * change and the last root enqueued on any OTHER stream, so the effects of the calls on one state are always those of the
+ * order in which the host issued them.  patch returns once its bytes are staged (asynchronous up to 1 MB per call: the
+ * caller's buffers are free on return); append / truncate / replace synchronise their stream before they return. */
 typedef struct ecgpu_resident_state ecgpu_resident_state_t;
 int ecgpu_resident_state_create(int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out); /* deneb */
 int ecgpu_resident_state_create_fork(int fork, int preset, const uint8_t* ssz, uint64_t n_bytes, ecgpu_resident_state_t** out);
@@ -207,6 +216,81 @@ int ecgpu_resident_state_truncate(ecgpu_resident_state_t* st, int field, uint64_
  * elements can be replaced too (their cached tree is rebuilt at the next root). */
 int ecgpu_resident_state_replace(ecgpu_resident_state_t* st, int field, const uint8_t* data, uint64_t n_bytes);
 uint64_t ecgpu_resident_state_size(const ecgpu_resident_state_t* st);
+
+/* Field-addressed changes (round 6; csrc/state_fields.h).  The reference's state transition names what it changes by field and
+ * index -- `state.balances[index]` (increase_balance / decrease_balance, phase0/helpers.rs:979-1030), `state.validators.push`
+ * (add_validator_to_registry, phase0/block_processing.rs:317-349, altair/block_processing.rs:192-213),
+ * `state.current_epoch_participation[index]` (altair/block_processing.rs:98-170), `state.eth1_data_votes.push` / `.clear()`
+ * (phase0/block_processing.rs:689-700), `state.state_roots[slot % N]`, `state.slot` (phase0/slot_processing.rs:58-86) -- never
+ * by a byte offset.  These entries take the same coordinates: `field` = POSITION of the field in the fork's BeaconState
+ * container (ECGPU_BS_*: phase0/beacon_state.rs:50-88 ... electra/beacon_state.rs:73-145; the same number is the field's chunk
+ * in the container tree), plus a byte offset / element index INSIDE the field.  The library resolves them against the
+ * encoding as it is when the bytes are applied, i.e. after every length change issued before -- a balance written after a
+ * deposit of the same block lands behind the new validator record, without the caller recomputing anything.
+ * Semantics: as if every call were applied at once, in program order (also relative to the byte-addressed entries above).
+ * Implementation: writes and pushes are queued on the host and travel in ONE block at the next root / flush / byte-addressed
+ * call (where two queued writes cover the same byte the later one wins; a write may target elements that are still queued);
+ * truncate_field, set_field on a variable-size field and rotate_participation flush the queue and run at once.  An entry that
+ * returns ECGPU_ERR_BAD_ARG (no such field in the fork, outside the field, past a list limit, not whole elements) has changed
+ * nothing. */
+#define ECGPU_BS_GENESIS_TIME 0
+#define ECGPU_BS_GENESIS_VALIDATORS_ROOT 1
+#define ECGPU_BS_SLOT 2
+#define ECGPU_BS_FORK 3
+#define ECGPU_BS_LATEST_BLOCK_HEADER 4
+#define ECGPU_BS_BLOCK_ROOTS 5
+#define ECGPU_BS_STATE_ROOTS 6
+#define ECGPU_BS_HISTORICAL_ROOTS 7
+#define ECGPU_BS_ETH1_DATA 8
+#define ECGPU_BS_ETH1_DATA_VOTES 9
+#define ECGPU_BS_ETH1_DEPOSIT_INDEX 10
+#define ECGPU_BS_VALIDATORS 11
+#define ECGPU_BS_BALANCES 12
+#define ECGPU_BS_RANDAO_MIXES 13
+#define ECGPU_BS_SLASHINGS 14
+#define ECGPU_BS_PREVIOUS_EPOCH_PARTICIPATION 15 /* phase0: previous_epoch_attestations (set_field only) */
+#define ECGPU_BS_CURRENT_EPOCH_PARTICIPATION 16  /* phase0: current_epoch_attestations (set_field only) */
+#define ECGPU_BS_JUSTIFICATION_BITS 17
+#define ECGPU_BS_PREVIOUS_JUSTIFIED_CHECKPOINT 18
+#define ECGPU_BS_CURRENT_JUSTIFIED_CHECKPOINT 19
+#define ECGPU_BS_FINALIZED_CHECKPOINT 20
+#define ECGPU_BS_INACTIVITY_SCORES 21              /* altair+ */
+#define ECGPU_BS_CURRENT_SYNC_COMMITTEE 22
+#define ECGPU_BS_NEXT_SYNC_COMMITTEE 23
+#define ECGPU_BS_LATEST_EXECUTION_PAYLOAD_HEADER 24 /* bellatrix+ */
+#define ECGPU_BS_NEXT_WITHDRAWAL_INDEX 25           /* capella+ */
+#define ECGPU_BS_NEXT_WITHDRAWAL_VALIDATOR_INDEX 26
+#define ECGPU_BS_HISTORICAL_SUMMARIES 27
+#define ECGPU_BS_DEPOSIT_RECEIPTS_START_INDEX 28    /* electra: 28 .. 33 are its six uint64 fields, in struct order */
+#define ECGPU_BS_PENDING_BALANCE_DEPOSITS 34
+#define ECGPU_BS_PENDING_PARTIAL_WITHDRAWALS 35
+#define ECGPU_BS_PENDING_CONSOLIDATIONS 36
+/* bytes [offset_in_field, offset_in_field + n_bytes) of the field's serialization are overwritten (any field except phase0's
+ * two attestation lists; inside the payload header everything but its extra_data offset word) */
+int ecgpu_resident_state_patch_field(ecgpu_resident_state_t* st, uint32_t field, uint64_t offset_in_field, const uint8_t* data,
+                                     uint64_t n_bytes);
+/* the same with the offset given as an element index: elements first_index .. of a list / vector (121-byte validators, 8-byte
+ * balances / scores / slashings, 1-byte participation flags, 32-byte roots, 72-byte eth1 votes, 64-byte summaries ...) */
+int ecgpu_resident_state_patch_elements(ecgpu_resident_state_t* st, uint32_t field, uint64_t first_index, const uint8_t* data,
+                                        uint64_t n_bytes);
+/* whole elements appended to a list of fixed-size elements (`list.push`) */
+int ecgpu_resident_state_push(ecgpu_resident_state_t* st, uint32_t field, const uint8_t* data, uint64_t n_bytes);
+/* the list keeps its first new_n_bytes (`list.clear()` = 0: process_eth1_data_reset) */
+int ecgpu_resident_state_truncate_field(ecgpu_resident_state_t* st, uint32_t field, uint64_t new_n_bytes);
+/* the whole field exchanged for `data`: a fixed-size field keeps its size; a list may change length; the payload header may
+ * arrive with another extra_data; phase0's attestation lists change this way only */
+int ecgpu_resident_state_set_field(ecgpu_resident_state_t* st, uint32_t field, const uint8_t* data, uint64_t n_bytes);
+/* add_validator_to_registry: the 121-byte record and the balance are pushed; from altair on also a zero flag on both
+ * participation lists and a zero inactivity score */
+int ecgpu_resident_state_add_validator(ecgpu_resident_state_t* st, const uint8_t validator121[121], uint64_t balance);
+/* process_participation_flag_updates (altair/epoch_processing.rs): previous_epoch_participation = current, current = zeros --
+ * on the device, nothing travels */
+int ecgpu_resident_state_rotate_participation(ecgpu_resident_state_t* st);
+/* apply what is queued now (root does it anyway) */
+int ecgpu_resident_state_flush(ecgpu_resident_state_t* st);
+/* byte length of the field as program order has left it (queued pushes count), or a negative error */
+int64_t ecgpu_resident_state_field_size(ecgpu_resident_state_t* st, uint32_t field);
+
 int ecgpu_resident_state_root(ecgpu_resident_state_t* st, uint8_t root[32]);
 /* asynchronous form: root written to device memory on `stream` */
 int ecgpu_resident_state_root_dev(ecgpu_resident_state_t* st, uint8_t* d_root, ecgpu_stream_t stream);

@@ -67,3 +67,37 @@ def oracle_state_root_fast(f: dict, preset_name: str) -> bytes:
     roots[names.index("current_epoch_participation")] = cref.merkleize_bytes(
         f["current_epoch_participation"].tobytes(), lim1, n)[0]
     return ssz.merkleize_chunks(roots, len(roots))
+
+
+def fork_state_value(fork, f, rnd):
+    """the oracle value of a `fork` BeaconState built from the deneb field dict of ethereum_consensus_amd.synthetic"""
+    O = ssz
+    v = dict(oracle_state_value(f))
+    if fork == "phase0":
+        att = lambda k: {"aggregation_bits": [rnd.random() < 0.6 for _ in range(rnd.choice([0, 1, 7, 8, 9, 130, 2048][:k % 7 + 1]))],
+                         "data": {"slot": rnd.randrange(1 << 40), "index": rnd.randrange(64), "beacon_block_root": rnd.randbytes(32),
+                                  "source": {"epoch": rnd.randrange(1 << 30), "root": rnd.randbytes(32)},
+                                  "target": {"epoch": rnd.randrange(1 << 30), "root": rnd.randbytes(32)}},
+                         "inclusion_delay": rnd.randrange(1, 33), "proposer_index": rnd.randrange(1 << 20)}
+        v["previous_epoch_attestations"] = [att(k) for k in range(rnd.choice([0, 3, 40]))]
+        v["current_epoch_attestations"] = [att(k) for k in range(rnd.choice([1, 17]))]
+    if fork in ("bellatrix", "capella"):
+        hdr = dict(v["latest_execution_payload_header"])
+        for k in (["blob_gas_used", "excess_blob_gas"] + (["withdrawals_root"] if fork == "bellatrix" else [])):
+            hdr.pop(k)
+        v["latest_execution_payload_header"] = hdr
+    if fork == "electra":
+        hdr = dict(v["latest_execution_payload_header"])
+        hdr["deposit_receipts_root"], hdr["withdrawal_requests_root"] = rnd.randbytes(32), rnd.randbytes(32)
+        v["latest_execution_payload_header"] = hdr
+        for k in ("deposit_receipts_start_index", "deposit_balance_to_consume", "exit_balance_to_consume", "earliest_exit_epoch",
+                  "consolidation_balance_to_consume", "earliest_consolidation_epoch"):
+            v[k] = rnd.randrange(1 << 64)
+        small = f["_preset"] == "minimal"
+        v["pending_balance_deposits"] = [{"index": rnd.randrange(1 << 40), "amount": rnd.randrange(1 << 64)} for _ in range(rnd.choice([0, 1, 5, 1500]))]
+        v["pending_partial_withdrawals"] = [{"index": rnd.randrange(1 << 40), "amount": rnd.randrange(1 << 64), "withdrawable_epoch": rnd.randrange(1 << 64)}
+                                            for _ in range(rnd.choice([0, 3, 64] if small else [0, 3, 700]))]
+        v["pending_consolidations"] = [{"source_index": rnd.randrange(1 << 40), "target_index": rnd.randrange(1 << 40)}
+                                       for _ in range(rnd.choice([0, 2, 64] if small else [1, 300]))]
+    t = O.BeaconState(fork, O.MINIMAL if f["_preset"] == "minimal" else O.MAINNET)
+    return t, {n: v[n] for n, _ in t.fields}

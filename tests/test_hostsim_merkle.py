@@ -160,7 +160,7 @@ def test_beacon_state_plan_of_every_fork(fork):
     three-uint64 containers: electra/beacon_state.rs:73-145), both presets, empty / short / tile-sized pending lists."""
     import random
     from ethereum_consensus_amd import synthetic as S
-    from tests.test_gpu_merkle import _fork_state_value
+    from tests._statevalue import fork_state_value as _fork_state_value
     fork_id = {"altair": 1, "bellatrix": 2, "capella": 3, "deneb": 4, "electra": 5}[fork]
     rnd = random.Random(100 + fork_id)
     for preset, n in (("minimal", 0), ("minimal", 37), ("mainnet", 5), ("minimal", 3), ("mainnet", 2)):
@@ -210,6 +210,49 @@ def _full_root(kind, data, n0, depth, mix, mix_len):
     return out.raw
 
 
+def _canon(kind, buf: bytearray) -> bytearray:
+    """Validator records: the `slashed` member is an SSZ boolean, one byte that is 0 or 1 (any other value is not an encoding
+    the reference's deserializer accepts), so that the oracle's typed hash_tree_root applies to the bytes"""
+    if kind == 2:
+        for i in range(88, len(buf), 121):
+            buf[i] &= 1
+    return buf
+
+
+def _oracle_root(kind, data, n0, depth, mix, mix_len):
+    """the same tree by oracle/ssz.py: typed hash_tree_root of every record, merkleize to 2^depth leaves, length mix-in -- nothing
+    of the product's (passes, tiles, cached levels, climbs) is involved"""
+    data = bytes(data)
+    if kind == 0:
+        root = ssz.merkleize_bytes(data, 1 << depth)
+    else:
+        rec = REC[kind]
+        assert len(data) == rec * n0
+        if kind == 2:
+            offs, o = [], 0
+            for name, ty in ssz.Validator.fields:
+                offs.append((name, ty, o))
+                o += ty.fixed_size
+
+            def val(b):
+                d = {}
+                for name, ty, o in offs:
+                    raw = b[o:o + ty.fixed_size]
+                    d[name] = raw if isinstance(ty, ssz.ByteVector) else (bool(raw[0]) if isinstance(ty, ssz.Boolean) else int.from_bytes(raw, "little"))
+                return d
+            leaves = [ssz.Validator.htr(val(data[rec * i:rec * i + rec])) for i in range(n0)]
+        elif kind == 3:
+            leaves = [ssz.BlsPublicKey.htr(data[rec * i:rec * i + rec]) for i in range(n0)]
+        elif kind == 4:
+            leaves = [ssz.HistoricalSummary.htr({"block_summary_root": data[rec * i:rec * i + 32], "state_summary_root": data[rec * i + 32:rec * i + 64]})
+                      for i in range(n0)]
+        else:
+            leaves = [ssz.Eth1Data.htr({"deposit_root": data[rec * i:rec * i + 32], "deposit_count": int.from_bytes(data[rec * i + 32:rec * i + 40], "little"),
+                                        "block_hash": data[rec * i + 40:rec * i + 72]}) for i in range(n0)]
+        root = ssz.merkleize_chunks(leaves, 1 << depth)
+    return ssz.mix_in_length(root, mix_len) if mix else root
+
+
 def _tree_update(kind, before, n0_before, after, n0_after, depth, mix, mix_len, marks, seed):
     L = hs.lib()
     L.hs_tree_update.restype = ctypes.c_uint64
@@ -233,7 +276,7 @@ def test_resident_tree_rehashes_dirty_paths_only(kind, n):
     rec = REC[kind]
     # a packed field's last chunk may be partial
     nbytes = rec * n - (r.randrange(1, 31) if kind == 0 and n > 2 else 0)
-    before = bytearray(r.randbytes(nbytes))
+    before = _canon(kind, bytearray(r.randbytes(nbytes)))
     depth = max(1, (n - 1).bit_length()) + r.randrange(0, 21)
     mix = kind != 3
     for trial, n_dirty in enumerate((0, 1, 2, min(n, 40), min(n, 700))):
@@ -243,11 +286,15 @@ def test_resident_tree_rehashes_dirty_paths_only(kind, n):
             lo, hi = rec * e, min(rec * e + rec, nbytes)
             pos = r.randrange(lo, hi)
             after[pos] ^= 1 + r.randrange(255)
+            if kind == 2 and pos % 121 == 88:
+                after[pos] = 1 - (before[pos] & 1)  # `slashed` flips between its two values
         marks = list(touched) + [r.choice(touched) for _ in range(len(touched) // 3)]  # duplicates are welcome
         r.shuffle(marks)
         root, hashes, left, rebuilt = _tree_update(kind, bytes(before), n, bytes(after), n, depth, mix, n, marks, seed=trial * 77 + n)
         assert left == 0  # every counter and flag back at zero
         assert root == _full_root(kind, bytes(after), n, depth, mix, n)
+        if n <= 9000:  # ... and the ORACLE's root of the same records (the climb was only ever compared with the product's own from-scratch schedule)
+            assert root == _oracle_root(kind, after, n, depth, mix, n), (kind, n, trial)
         # only dirty paths: at most (leaf work + T) hash64 per dirty entry, and no more than a rebuild
         H = max(1, (n - 1).bit_length())
         T = max(H - 9, 1 if kind == 0 else 0)
@@ -267,7 +314,7 @@ def test_resident_tree_follows_an_append(kind, n, grow):
     unit = 8 if kind == 0 else rec  # balances: 8-byte elements packed four to a chunk
     nb0 = unit * (n * (4 if kind == 0 else 1) - (1 if kind == 0 else 0))
     nb1 = nb0 + unit * grow * (4 if kind == 0 else 1)
-    data = r.randbytes(nb1)
+    data = bytes(_canon(kind, bytearray(r.randbytes(nb1))))
     n0_0, n0_1 = (nb0 + rec - 1) // rec, (nb1 + rec - 1) // rec
     assert (n0_0 - 1).bit_length() == (n0_1 - 1).bit_length()
     depth = 40
@@ -275,3 +322,4 @@ def test_resident_tree_follows_an_append(kind, n, grow):
     root, hashes, left, _ = _tree_update(kind, data[:nb0], n0_0, data, n0_1, depth, True, nb1 // unit, marks, seed=n)
     assert left == 0
     assert root == _full_root(kind, data, n0_1, depth, True, nb1 // unit)
+    assert root == _oracle_root(kind, data, n0_1, depth, True, nb1 // unit)
