@@ -39,6 +39,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     sig = {
         "ecgpu_init": (c_int, [c_int]),
         "ecgpu_device_count": (c_int, []),
+        "ecgpu_warmup": (c_int, [ctypes.c_uint]),
         "ecgpu_bind_thread": (c_int, [c_int]),
         "ecgpu_thread_device": (c_int, []),
         "ecgpu_fast_aggregate_verify_batch_multi": (c_int, [ctypes.c_void_p, c_u32, u8p, ctypes.c_void_p, u8p, u8p, c_u32, c_int, u8p]),

@@ -6,6 +6,7 @@
 #include "bls_verify.h"
 #include "bls_vm_host.h"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -118,13 +119,15 @@ __global__ void __launch_bounds__(192) k_row_pair_c(Vm3Desc d, const u32* xfer, 
 // from VM3_CONST_BASE up, sit behind the nreg registers of the tuple), so an operand's image starts at dword 16 x its byte --
 // the interpreter does not spend five instructions per operand telling constants from registers.
 static Vm3Desc g_row_prog[MAX_DEVICES][2];
-static bool g_row_prog_ready[MAX_DEVICES] = {};
-static int row_programs() {
+// (advisor, round 5: the flag is read outside the mutex by threads making their first small-batch call at the same time -- an
+// acquire load pairs with the release store behind the descriptor writes)
+static std::atomic<bool> g_row_prog_ready[MAX_DEVICES] = {};
+int row_programs() {
     const int dev = current_device();
-    if (g_row_prog_ready[dev]) return ECGPU_SUCCESS;
+    if (g_row_prog_ready[dev].load(std::memory_order_acquire)) return ECGPU_SUCCESS;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    if (g_row_prog_ready[dev]) return ECGPU_SUCCESS;
+    if (g_row_prog_ready[dev].load(std::memory_order_acquire)) return ECGPU_SUCCESS;
     for (int part = 0; part < 2; part++) {
         Vm3Desc d = vm3_program(part);
         const u32 slots = part == 0 ? VM3_SLOTS_A : VM3_SLOTS_C;
@@ -151,7 +154,7 @@ static int row_programs() {
         d.prog = dp;
         g_row_prog[dev][part] = d;
     }
-    g_row_prog_ready[dev] = true;
+    g_row_prog_ready[dev].store(true, std::memory_order_release);
     return ECGPU_SUCCESS;
 }
 

@@ -42,6 +42,18 @@ int ecgpu_bind_thread(int device);
 /* the device the calling thread's calls run on (ecgpu_init / ecgpu_bind_thread), or ECGPU_ERR_NO_DEVICE before ecgpu_init: a
  * multi-process host checks it against its own LOCAL_RANK before the first collective (bench.py multi_gpu_preflight) */
 int ecgpu_thread_device(void);
+/* Warm-up.  The first call of a process pays for the box self-check, the upload of the small-batch programs, the calling
+ * thread's stream sets and arenas and the code objects of the kernels it launches: ~45 ms against ~2 ms for a warm
+ * verify_signature.  ecgpu_warmup makes real calls with the reference's fixed vector (crypto/bls.rs:530-544) on the calling
+ * thread -- ECGPU_WARM_BLS: one verify_signature (the small-batch path: what a block's scalar calls use); ECGPU_WARM_BLS_BATCHES:
+ * also one batch per larger dispatch class (~60 ms in all; for hosts that verify epochs); ECGPU_WARM_MERKLE: one header root.
+ * flags == 0 means BLS | MERKLE.  Process-wide state is warm for every thread afterwards; the per-thread part (streams, arenas:
+ * ~1 ms) is paid by each thread's own first call.  Returns 0, or a negative code -- ECGPU_ERR_HIP when the fixed vector does
+ * not verify (a broken build or device). */
+#define ECGPU_WARM_BLS 1u
+#define ECGPU_WARM_BLS_BATCHES 2u
+#define ECGPU_WARM_MERKLE 4u
+int ecgpu_warmup(unsigned flags);
 const char* ecgpu_version(void);
 const char* ecgpu_last_error(void); /* thread-local description of the last negative return */
 

@@ -19,6 +19,8 @@ def lib():
         L = ctypes.CDLL(path)
         L.cbls_fast_aggregate_verify.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                                  ctypes.c_int]
+        L.cbls_fast_aggregate_verify_mt.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                                    ctypes.c_int, ctypes.c_int]
         L.cbls_fav_batch_k1.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p]
         L.cbls_fav_batch_k1.restype = None
         L.cbls_key_validate.argtypes = [ctypes.c_char_p]
@@ -42,6 +44,11 @@ def host_threads() -> int:
 
 def fast_aggregate_verify(pks, msg: bytes, sig: bytes, eth: bool = False) -> int:
     return lib().cbls_fast_aggregate_verify(b"".join(pks), len(pks), msg, len(msg), sig, 1 if eth else 0)
+
+
+def fast_aggregate_verify_long(pks48: bytes, msg: bytes, sig: bytes, eth: bool = False, threads: int = 0) -> int:
+    """one call over a LONG key list (keys concatenated): the key validations on all host threads, the first failure in list order decides"""
+    return lib().cbls_fast_aggregate_verify_mt(pks48, len(pks48) // 48, msg, len(msg), sig, 1 if eth else 0, threads or host_threads())
 
 
 def fast_aggregate_verify_batch_k1(pks48: bytes, msgs32: bytes, sigs96: bytes, threads: int = 0) -> bytes:

@@ -757,6 +757,28 @@ def test_randomised_differential_parity_over_mutated_encodings(mutated_workload,
     assert res["ok"] and res["n"] == n and res["python_samples_checked"] >= (256 if n == 65536 else 100 if n >= 30000 else 60 if n >= 20000 else 1), res
 
 
+@pytest.mark.parametrize("fork_threads_max", [None, "64"])
+def test_sixteen_host_threads_first_calls_at_once_then_mixed_batches(mutated_workload, fork_threads_max):
+    """16 host threads in one process -- their FIRST calls released by one barrier (ecgpu_init, the tower
+    decision, the row-program upload, stream sets under contention), then each looping over batch sizes {1, 64, 700, 5 000} x
+    {host keys, registry, collector flush}; every status against the C++ oracle.  Once with the small-batch stream forking
+    gated at its default (4 live stream sets) and once at 64 (every thread forks).  tests/_bls_threads.py;
+    spec-tests/main.rs:114-124 is how the reference's harness runs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    path, info = mutated_workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    if fork_threads_max:
+        env["ECGPU_FORK_THREADS_MAX"] = fork_threads_max
+    out = subprocess.run([sys.executable, "-m", "tests._bls_threads", path, "16", "3"], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-2500:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["calls"]["tuples"] >= 16 * 3 * 5765, res
+
+
 def _random_dispatch_environment(r):
     """one assignment of the library's dispatch controls, each drawn from the values it documents"""
     pick = lambda *v: r.choice(v)
@@ -1155,3 +1177,100 @@ def test_multi_scalar_multiplication(gpu):
         M.g2_multi_scalar_mul([sigs[0], syn.off_subgroup_signature(0)], [1, 2], 64)
     with pytest.raises(M.EmptyAggregate):
         M.g1_multi_scalar_mul([], [])
+
+
+# ---- SURVEY.md 8(d) config 2, the OTHER readings (missing 4) -------------------------------------------------------
+def _long_list_workload(gpu, K):
+    from ethereum_consensus_amd import synthetic as syn
+    skb = syn.bls_secret_keys(K)
+    sks = [int.from_bytes(skb[32 * i:32 * i + 32], "big") for i in range(K)]
+    pks = gpu.sk_to_pk_batch(skb)
+    return sks, pks
+
+
+def test_config2_one_call_with_65536_keys_and_one_message(gpu):
+    """configs[1] read literally against the signature of the reference function -- `fast_aggregate_verify(&[&PublicKey], &[u8],
+    &Signature)` (crypto/bls.rs:114-118): ONE call, K = 65 536 keys, one message.  GPU status == the C++ oracle over the same list
+    (oracle/c cbls_fast_aggregate_verify_mt: every key validated, the lowest failing index decides) for the valid list, a wrong
+    message, one damaged key at position 0 / K/2 / K - 1 (three kinds of damage), two damaged keys (the earlier one decides),
+    and a list whose keys cancel to the point at infinity; through host keys and through the validated-key registry."""
+    from ethereum_consensus_amd import synthetic as syn
+    from oracle import cbls
+    K = 65536
+    sks, pks = _long_list_workload(gpu, K)
+    msg = syn.bls_messages(1, tag=b"one-call")
+    sig = gpu.sign_batch(sk_bytes(sum(sks) % B.R), [msg])
+    inf, zero, off = b"\xc0" + bytes(47), bytes(48), syn.off_subgroup_public_key(2)
+    lists = [("valid", pks, msg, sig)]
+    lists.append(("wrong message", pks, bytes([msg[0] ^ 1]) + msg[1:], sig))
+    for pos in (0, K // 2, K - 1):
+        for name, dmg in (("infinity", inf), ("bad encoding", zero), ("outside G1", off)):
+            lists.append((f"{name} at {pos}", pks[:48 * pos] + dmg + pks[48 * pos + 48:], msg, sig))
+    two = bytearray(pks)
+    two[48 * 40000:48 * 40001] = zero
+    two[48 * 39999:48 * 40000] = off
+    lists.append(("two damaged keys", bytes(two), msg, sig))
+    # keys that cancel: the second half of the list holds the negatives of the first half (sk -> r - sk): the sum is the point at infinity
+    neg = gpu.sk_to_pk_batch(b"".join(sk_bytes(B.R - s) for s in sks[:K // 2]))
+    cancel = pks[:48 * (K // 2)] + neg
+    lists.append(("keys cancel to infinity", cancel, msg, sig))
+    lists.append(("keys cancel, signature at infinity", cancel, msg, b"\xc0" + bytes(95)))
+    reg = gpu.ValidatorKeyRegistry(K)
+    seen = set()
+    for name, keys, m, s in lists:
+        want = cbls.fast_aggregate_verify_long(keys, m, s)
+        got = gpu.fast_aggregate_verify_batch(keys, [0, K], m, s)[0]
+        assert got == want, (name, got, want)
+        got1 = gpu._lib.load().ecgpu_fast_aggregate_verify(gpu._buf(keys), K, gpu._buf(m), len(m), gpu._buf(s), 0)
+        assert got1 == want, (name, "scalar entry", got1, want)
+        reg.set(0, keys)
+        got2 = reg.fast_aggregate_verify_batch(list(range(K)), [0, K], m, s)[0]
+        assert got2 == want, (name, "registry", got2, want)
+        seen.add(want)
+    assert {0, B.BLST_VERIFY_FAIL, B.BLST_PK_IS_INFINITY, B.BLST_BAD_ENCODING, B.BLST_POINT_NOT_IN_GROUP} <= seen
+    reg.close()
+
+
+def test_config2_64_aggregates_of_1024_keys(gpu):
+    """the third reading of configs[1] SURVEY.md 8(d) promised: n = 64 tuples x K = 1 024 keys (65 536 signatures), one batch call.
+    Every tuple's status against the C++ oracle over the tuple's own key list; tuples 1, 9, 17 ... carry one damaged key at
+    position 0 / K/2 / K - 1 in turn, tuple 5 a wrong message, tuple 7 keys that cancel to infinity."""
+    from ethereum_consensus_amd import synthetic as syn
+    from oracle import cbls
+    n, K = 64, 1024
+    sks, pks = _long_list_workload(gpu, n * K)
+    msgs = syn.bls_messages(n, tag=b"n64")
+    agg = [sum(sks[K * t:K * t + K]) % B.R for t in range(n)]
+    sigs = gpu.sign_batch(b"".join(sk_bytes(a) for a in agg), [msgs[32 * t:32 * t + 32] for t in range(n)])
+    keys = bytearray(pks)
+    msgb = bytearray(msgs)
+    dmg = [b"\xc0" + bytes(47), bytes(48), syn.off_subgroup_public_key(3)]
+    for j, t in enumerate(range(1, n, 8)):
+        pos = (0, K // 2, K - 1)[j % 3]
+        keys[48 * (K * t + pos):48 * (K * t + pos) + 48] = dmg[(j // 3) % 3]
+    msgb[32 * 5 + 9] ^= 0x10
+    neg = gpu.sk_to_pk_batch(b"".join(sk_bytes(B.R - s) for s in sks[7 * K:7 * K + K // 2]))
+    keys[48 * (7 * K + K // 2):48 * (8 * K)] = neg
+    keys, msgb = bytes(keys), bytes(msgb)
+    want = bytes(cbls.fast_aggregate_verify_long(keys[48 * K * t:48 * K * (t + 1)], msgb[32 * t:32 * t + 32], sigs[96 * t:96 * t + 96]) for t in range(n))
+    got = gpu.fast_aggregate_verify_batch(keys, [K * t for t in range(n + 1)], msgb, sigs)
+    assert got == want, [(t, got[t], want[t]) for t in range(n) if got[t] != want[t]]
+    assert want.count(0) == n - 10 and len(set(want)) >= 5
+    reg = gpu.ValidatorKeyRegistry(n * K)
+    reg.set(0, keys)
+    assert reg.fast_aggregate_verify_batch(list(range(n * K)), [K * t for t in range(n + 1)], msgb, sigs) == want
+    reg.close()
+
+
+def test_warmup_takes_the_first_call_cost(gpu):
+    """ecgpu_warmup (missing 6): in a fresh process, the first verify_signature after the warm-up costs at most
+    twice a steady-state call (cold: tens of milliseconds -- the box self-check, program uploads, stream sets, code objects)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import first_call_probe
+    res = first_call_probe.probe()
+    assert res["first_call_after_warmup_ms"] <= 2.0 * res["warm_call_ms"] + 0.3, res
+    assert res["cold_first_call_ms"] > res["first_call_after_warmup_ms"], res
+    L = gpu._lib.load()
+    assert L.ecgpu_warmup(0) == 0 and L.ecgpu_warmup(1 | 2 | 4) == 0  # idempotent; the batch classes verify the fixed vector too

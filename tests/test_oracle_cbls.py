@@ -150,3 +150,35 @@ def test_both_oracles_agree_on_aggregates_with_damaged_members():
         assert got == want, (kind, len(members), got[0], want[0])
         seen.add((kind, got[0]))
     assert {("pk", 0), ("sig", 0)}.issubset(seen) and len(seen) >= 5, seen
+
+
+def test_long_list_threaded_entry_equals_the_sequential_function():
+    """cbls_fast_aggregate_verify_mt (the checker of SURVEY.md 8d config 2's one-call-many-keys reading) == the sequential
+    restatement on every case of the status algebra, and on lists with damaged keys at several positions: the LOWEST failing
+    index decides whichever thread meets it (crypto/bls.rs:119-121 converts left to right)."""
+    for pks, msg, sig, eth in C.fav_cases():
+        for threads in (1, 3, 8):
+            assert cbls.fast_aggregate_verify_long(b"".join(pks), msg, sig, bool(eth), threads) == cbls.fast_aggregate_verify(pks, msg, sig, bool(eth))
+    r = random.Random(8)
+    sks = [r.randrange(1, B.R) for _ in range(40)]
+    pks = [cbls.sk_to_pk(k) for k in sks]
+    msg = b"\x07" * 32
+    sig = cbls.sign(sum(sks) % B.R, msg)
+    assert cbls.fast_aggregate_verify_long(b"".join(pks), msg, sig, False, 5) == 0
+    inf = b"\xc0" + bytes(47)
+    bad_enc = bytes(48)
+    off = syn.off_subgroup_public_key(1)
+    for positions in ([0], [39], [20], [13, 7], [38, 2, 21], [5, 6, 7]):
+        for damage in (inf, bad_enc, off):
+            lst = list(pks)
+            for j, p in enumerate(positions):
+                lst[p] = (damage, inf, off)[j % 3] if j else damage
+            want = cbls.fast_aggregate_verify(lst, msg, sig)
+            assert want != 0
+            for threads in (1, 4, 7):
+                assert cbls.fast_aggregate_verify_long(b"".join(lst), msg, sig, False, threads) == want, (positions, threads)
+    # keys that cancel: sk and r - sk
+    pair = [cbls.sk_to_pk(9), cbls.sk_to_pk(B.R - 9)]
+    for lst in (pair, pks[:3] + pair):
+        s2 = cbls.sign(sum(sks[:3]) % B.R if len(lst) > 2 else 1, msg)
+        assert cbls.fast_aggregate_verify_long(b"".join(lst), msg, s2, False, 4) == cbls.fast_aggregate_verify(lst, msg, s2)
