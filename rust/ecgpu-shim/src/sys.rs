@@ -27,6 +27,21 @@ pub const ECGPU_STATE_HISTORICAL_SUMMARIES: c_int = 8;
 pub const ECGPU_STATE_PENDING_BALANCE_DEPOSITS: c_int = 9; // electra
 pub const ECGPU_STATE_PENDING_PARTIAL_WITHDRAWALS: c_int = 10;
 pub const ECGPU_STATE_PENDING_CONSOLIDATIONS: c_int = 11;
+// field positions in the fork's BeaconState container (include/ecgpu.h ECGPU_BS_*): the coordinates of the field-addressed entries
+pub const ECGPU_BS_SLOT: u32 = 2;
+pub const ECGPU_BS_BLOCK_ROOTS: u32 = 5;
+pub const ECGPU_BS_STATE_ROOTS: u32 = 6;
+pub const ECGPU_BS_HISTORICAL_ROOTS: u32 = 7;
+pub const ECGPU_BS_ETH1_DATA_VOTES: u32 = 9;
+pub const ECGPU_BS_VALIDATORS: u32 = 11;
+pub const ECGPU_BS_BALANCES: u32 = 12;
+pub const ECGPU_BS_RANDAO_MIXES: u32 = 13;
+pub const ECGPU_BS_SLASHINGS: u32 = 14;
+pub const ECGPU_BS_PREVIOUS_EPOCH_PARTICIPATION: u32 = 15;
+pub const ECGPU_BS_CURRENT_EPOCH_PARTICIPATION: u32 = 16;
+pub const ECGPU_BS_INACTIVITY_SCORES: u32 = 21;
+pub const ECGPU_BS_LATEST_EXECUTION_PAYLOAD_HEADER: u32 = 24;
+pub const ECGPU_BS_HISTORICAL_SUMMARIES: u32 = 27;
 pub const ECGPU_STATE_PREVIOUS_EPOCH_ATTESTATIONS: c_int = 4; // phase0, in place of the participation lists: replace only
 pub const ECGPU_STATE_CURRENT_EPOCH_ATTESTATIONS: c_int = 5;
 
@@ -100,6 +115,17 @@ extern "C" {
     pub fn ecgpu_resident_state_truncate(st: *mut ecgpu_resident_state_t, field: c_int, new_n_bytes: u64) -> c_int;
     pub fn ecgpu_resident_state_replace(st: *mut ecgpu_resident_state_t, field: c_int, data: *const u8, n_bytes: u64) -> c_int;
     pub fn ecgpu_resident_state_size(st: *const ecgpu_resident_state_t) -> u64;
+    // field-addressed changes (round 6): queued in program order, applied at the next root
+    pub fn ecgpu_resident_state_patch_field(st: *mut ecgpu_resident_state_t, field: u32, offset_in_field: u64, data: *const u8, n_bytes: u64) -> c_int;
+    pub fn ecgpu_resident_state_patch_elements(st: *mut ecgpu_resident_state_t, field: u32, first_index: u64, data: *const u8, n_bytes: u64) -> c_int;
+    pub fn ecgpu_resident_state_push(st: *mut ecgpu_resident_state_t, field: u32, data: *const u8, n_bytes: u64) -> c_int;
+    pub fn ecgpu_resident_state_truncate_field(st: *mut ecgpu_resident_state_t, field: u32, new_n_bytes: u64) -> c_int;
+    pub fn ecgpu_resident_state_set_field(st: *mut ecgpu_resident_state_t, field: u32, data: *const u8, n_bytes: u64) -> c_int;
+    pub fn ecgpu_resident_state_add_validator(st: *mut ecgpu_resident_state_t, validator121: *const u8, balance: u64) -> c_int;
+    pub fn ecgpu_resident_state_rotate_participation(st: *mut ecgpu_resident_state_t) -> c_int;
+    pub fn ecgpu_resident_state_flush(st: *mut ecgpu_resident_state_t) -> c_int;
+    pub fn ecgpu_resident_state_field_size(st: *mut ecgpu_resident_state_t, field: u32) -> i64;
+    pub fn ecgpu_warmup(flags: u32) -> c_int;
     pub fn ecgpu_ssz_generalized_index(types: *const ecgpu_ssz_type, n_types: u32, fields: *const u32, n_field_refs: u32,
                                        root_type: u32, path: *const u64, path_len: u32, gindex: *mut u64) -> c_int;
     pub fn ecgpu_ssz_prove(types: *const ecgpu_ssz_type, n_types: u32, fields: *const u32, n_field_refs: u32, root_type: u32,
