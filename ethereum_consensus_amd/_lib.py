@@ -133,6 +133,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         "ecgpu_selfcheck_ifetch_sweep": (c_int, [ctypes.POINTER(ctypes.c_double)]),
         "ecgpu_bls_tower": (c_int, []),
         "ecgpu_bls_last_pairing_path": (c_int, []),
+        "ecgpu_bls_dispatch_thresholds": (c_int, [ctypes.c_void_p]),
     }
     missing = []
     for name, (res, args) in sig.items():

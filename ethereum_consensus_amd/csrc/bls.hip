@@ -21,6 +21,7 @@
 #include "runtime.h"
 
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -508,9 +509,11 @@ static const u32 g_h2c_row_max = [] {
 // operation per 16-lane row): a lone check 3.45 -> 1.0 ms, 1 024 tuples 3.4 -> 2.3 ms.  Its throughput is below the lane groups'
 // (3 of 16 lanes idle, two barriers per round): 3.9 ms at 2 048 tuples against 3.5 -- it hands over where the lane groups'
 // latency catches up (profiles/r05i_probe_row_machine.txt).
+// (round 6: 1 792 -- the row machine's pairing costs 2.2 / 3.0 / 3.8 ms at 1 024 / 1 536 / 2 048 tuples against the lane groups' flat
+// 3.3-3.4: the crossover, profiles/r06c_latency_paths.txt.  ecgpu_warmup(ECGPU_WARM_BLS_BATCHES) measures it on THIS device.)
 static const u32 g_row_max_tuples = [] {
     const char* e = getenv("ECGPU_ROW_MAX");
-    return e ? (u32)strtoul(e, nullptr, 10) : 1024u;
+    return e ? (u32)strtoul(e, nullptr, 10) : 1792u;
 }();
 static const u32 g_vm_max_tuples = [] {  // (round 3: 24 576, the crossover with the lane kernel's 22 ms; round 4: with the split path's 12.4 ms)
     const char* e = getenv("ECGPU_VM_MAX");
@@ -520,6 +523,22 @@ static const u32 g_split_max_tuples = [] {  // up to here two lanes per tuple ar
     const char* e = getenv("ECGPU_SPLIT_MAX");
     return e ? (u32)strtoul(e, nullptr, 10) : 32768u;
 }();
+// Per-device thresholds ("pick thresholds per device ... instead of static const values from one box"): the
+// two crossovers that depend on how fast THIS device runs each kernel set -- rows | lane groups, lane groups | two lanes per tuple
+// -- as measured by calibrate_dispatch (ecgpu_warmup with ECGPU_WARM_BLS_BATCHES); 0 = not measured: the defaults above.  An
+// environment variable, where set, wins.  (The other two are geometry: half a round and a round of lanes.)
+static std::atomic<u32> g_cal_row_max[MAX_DEVICES] = {}, g_cal_vm_max[MAX_DEVICES] = {};
+static const bool g_row_max_from_env = getenv("ECGPU_ROW_MAX") != nullptr, g_vm_max_from_env = getenv("ECGPU_VM_MAX") != nullptr;
+static u32 row_max_here() {
+    const u32 c = g_row_max_from_env ? 0u : g_cal_row_max[current_device()].load(std::memory_order_relaxed);
+    return c ? c : g_row_max_tuples;
+}
+static u32 vm_max_here() {
+    const u32 c = g_vm_max_from_env ? 0u : g_cal_vm_max[current_device()].load(std::memory_order_relaxed);
+    return c ? c : g_vm_max_tuples;
+}
+// calibrate_dispatch runs the same batch through one path after the other
+static thread_local int t_force_pairing_path = 0;
 
 }  // namespace ecg
 // validated-key registry (include/ecgpu.h): per validator index the affine key or the status its conversion raises
@@ -764,8 +783,12 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
                                       (const A2*)sigpts + base, (const u8*)st_dec + base, (const u8*)st_grp + base, d_sigs96 + (size_t)96 * base, cnt,
                                       eth_variant, d_status + base, xfer);
         };
-        const u32 row_max = g_pairing_mode == 3 ? g_row_max_tuples : 0;  // (auto1 = round 3's rule: no row machine)
-        auto small_path = [&](u32 cnt) { return cnt <= row_max ? 7 : cnt <= g_vm_max_tuples ? 3 : cnt <= split_max ? 5 : 1; };
+        const u32 row_max = g_pairing_mode == 3 ? row_max_here() : 0;  // (auto1 = round 3's rule: no row machine)
+        const u32 vm_max = vm_max_here();
+        auto small_path = [&](u32 cnt) {
+            if (t_force_pairing_path && cnt <= lane_round) return t_force_pairing_path;
+            return cnt <= row_max ? 7 : cnt <= vm_max ? 3 : cnt <= split_max ? 5 : 1;
+        };
         int rc = ECGPU_SUCCESS;
         if (g_pairing_mode == 7 || (auto_mode && slow_box && n <= row_max)) {
             t_last_pairing_path = 7;  // (its hot loop is ~30 KB of code: inside the instruction cache, like the lane groups')
@@ -1369,6 +1392,76 @@ const u8 WARM_SIG[96] = {0xa0, 0x1e, 0x49, 0x27, 0x67, 0x30, 0xe4, 0x75, 0x2e, 0
 const char WARM_MSG[] = "blst is such a blast";
 }  // namespace
 
+// n copies of the fixed vector through ONE pairing path (0: as dispatched); returns the best wall time of `reps` calls in *ms, or a
+// negative code; a status other than success comes back as ECGPU_VERIFY_FAIL
+static int timed_fixed_vector_batch(u32 n, int path, int reps, double* ms) {
+    const size_t ml = sizeof(WARM_MSG) - 1;
+    std::vector<u8> pks((size_t)48 * n), sigs((size_t)96 * n), msgs(ml * n), st(n, 0xff);
+    std::vector<u64> moff(n + 1);
+    for (u32 i = 0; i < n; i++) {
+        std::memcpy(&pks[(size_t)48 * i], WARM_PK, 48);
+        std::memcpy(&sigs[(size_t)96 * i], WARM_SIG, 96);
+        std::memcpy(&msgs[ml * i], WARM_MSG, ml);
+        moff[i + 1] = ml * (i + 1);
+    }
+    double best = 1e30;
+    for (int r = 0; r < reps; r++) {
+        t_force_pairing_path = path;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = fav_batch_host(pks.data(), nullptr, n, msgs.data(), moff.data(), msgs.size(), sigs.data(), n, 0, st.data());
+        const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        t_force_pairing_path = 0;
+        if (rc) return rc;
+        for (u32 i = 0; i < n; i++)
+            if (st[i]) return ECGPU_VERIFY_FAIL;
+        if (r && dt < best) best = dt;  // (the first call of a size grows the arena)
+    }
+    *ms = best;
+    return ECGPU_SUCCESS;
+}
+// Where THIS device's kernel sets cross (include/ecgpu.h ecgpu_warmup).  The side stages of a batch are the same whatever runs
+// its pairing check, so whole-call times compare the paths directly.
+//   rows | lane groups: the rows' time grows by a fixed amount per tuple beyond ~512 (a workgroup per tuple, eight resident per
+//       CU), the lane groups' is flat up to 4 096 tuples (one wave per SIMD): rows at 1 024 and 2 048, lane groups at 2 048.
+//   lane groups | two lanes per tuple: the lane groups grow per tuple, the two-lane kernels are flat up to half a round: lane
+//       groups at 12 288 and 16 384, two lanes at 16 384.
+// On a box with slow instruction fetch (tower 2) auto mode sends every size to rows / lane groups: only the first is measured.
+static int calibrate_dispatch() {
+    const int dev = current_device();
+    double r1 = 0, r2 = 0, v2 = 0;
+    if (g_pairing_mode != 3) {  // ECGPU_PAIRING forces one path: nothing to place, the batches still warm what will run
+        int rc0 = ECGPU_SUCCESS;
+        for (u32 n : {g_row_max_tuples + 1, g_vm_max_tuples + 1, g_split_max_tuples + 1})
+            if (!rc0) rc0 = timed_fixed_vector_batch(n, 0, 1, &r1);
+        return rc0;
+    }
+    int rc = timed_fixed_vector_batch(1024, 7, 3, &r1);
+    if (!rc) rc = timed_fixed_vector_batch(2048, 7, 3, &r2);
+    if (!rc) rc = timed_fixed_vector_batch(2048, 3, 3, &v2);
+    if (rc) return rc;
+    if (r2 > r1) {
+        const double per_tuple = (r2 - r1) / 1024.0;
+        double n = 1024.0 + (v2 - r1) / per_tuple;
+        n = n < 512 ? 512 : n > 3072 ? 3072 : n;
+        g_cal_row_max[dev].store(((u32)n / 64u) * 64u, std::memory_order_relaxed);
+    }
+    if (g_tower.load() != 2 && g_pairing_mode == 3) {
+        double v12 = 0, v16 = 0, s16 = 0, l1 = 0;
+        rc = timed_fixed_vector_batch(12288, 3, 2, &v12);
+        if (!rc) rc = timed_fixed_vector_batch(16384, 3, 2, &v16);
+        if (!rc) rc = timed_fixed_vector_batch(16384, 5, 2, &s16);
+        if (!rc) rc = timed_fixed_vector_batch(g_split_max_tuples + 1, 1, 2, &l1);  // (the one-lane kernel: warmed, not a threshold)
+        if (rc) return rc;
+        if (v16 > v12) {
+            const double per_tuple = (v16 - v12) / 4096.0;
+            double n = 12288.0 + (s16 - v12) / per_tuple;
+            n = n < 8192 ? 8192 : n > 24576 ? 24576 : n;
+            g_cal_vm_max[dev].store(((u32)n / 256u) * 256u, std::memory_order_relaxed);
+        }
+    }
+    return ECGPU_SUCCESS;
+}
+
 int ecgpu_warmup(unsigned flags) {
     int rc = ensure_init();
     if (rc) return rc;
@@ -1383,24 +1476,10 @@ int ecgpu_warmup(unsigned flags) {
         if (rc) return rc < 0 ? rc : broken("ecgpu_verify");
     }
     if (flags & ECGPU_WARM_BLS_BATCHES) {
-        // one batch per dispatch class above the rows: general-message batches of the same tuple (statuses must all be 0).
-        // Sizes: just inside the lane groups' range, the two-lane window, and one lane per tuple (a 22 ms round).
-        const u32 sizes[3] = {g_row_max_tuples + 1, g_vm_max_tuples + 1, g_split_max_tuples + 1};
-        const size_t ml = sizeof(WARM_MSG) - 1;
-        for (u32 n : sizes) {
-            std::vector<u8> pks((size_t)48 * n), sigs((size_t)96 * n), msgs(ml * n), st(n, 0xff);
-            std::vector<u64> moff(n + 1);
-            for (u32 i = 0; i < n; i++) {
-                std::memcpy(&pks[(size_t)48 * i], WARM_PK, 48);
-                std::memcpy(&sigs[(size_t)96 * i], WARM_SIG, 96);
-                std::memcpy(&msgs[ml * i], WARM_MSG, ml);
-                moff[i + 1] = ml * (i + 1);
-            }
-            rc = fav_batch_host(pks.data(), nullptr, n, msgs.data(), moff.data(), msgs.size(), sigs.data(), n, 0, st.data());
-            if (rc) return rc;
-            for (u32 i = 0; i < n; i++)
-                if (st[i]) return broken("a batch");
-        }
+        // every dispatch class above the rows runs the fixed vector once (their code objects, arenas at full size) -- and the runs
+        // are TIMED: the two crossovers between the kernel sets are placed where this device puts them (calibrate_dispatch)
+        rc = calibrate_dispatch();
+        if (rc) return rc < 0 ? rc : broken("a batch");
     }
     if (flags & ECGPU_WARM_MERKLE) {
         u8 hdr[112] = {}, root[32];
@@ -1414,6 +1493,16 @@ int ecgpu_warmup(unsigned flags) {
 }
 
 int ecgpu_bls_last_pairing_path(void) { return ecg::t_last_pairing_path; }
+int ecgpu_bls_dispatch_thresholds(uint32_t out[4]) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!out) return ECGPU_ERR_BAD_ARG;
+    out[0] = g_pairing_mode == 3 ? row_max_here() : 0;
+    out[1] = vm_max_here();
+    out[2] = g_pairing_mode == 3 ? g_split_max_tuples : 0;
+    out[3] = g_cal_row_max[current_device()].load() || g_cal_vm_max[current_device()].load() ? 1u : 0u;
+    return ECGPU_SUCCESS;
+}
 int ecgpu_bls_tower(void) {
     int rc = ensure_init();
     if (rc) return rc;

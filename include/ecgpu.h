@@ -46,7 +46,8 @@ int ecgpu_thread_device(void);
  * thread's stream sets and arenas and the code objects of the kernels it launches: ~45 ms against ~2 ms for a warm
  * verify_signature.  ecgpu_warmup makes real calls with the reference's fixed vector (crypto/bls.rs:530-544) on the calling
  * thread -- ECGPU_WARM_BLS: one verify_signature (the small-batch path: what a block's scalar calls use); ECGPU_WARM_BLS_BATCHES:
- * also one batch per larger dispatch class (~60 ms in all; for hosts that verify epochs); ECGPU_WARM_MERKLE: one header root.
+ * also every larger dispatch class, timed -- the crossovers between the kernel sets are placed where THIS device puts them
+ * (ecgpu_bls_dispatch_thresholds; ~0.3 s in all; for hosts that verify blocks and epochs); ECGPU_WARM_MERKLE: one header root.
  * flags == 0 means BLS | MERKLE.  Process-wide state is warm for every thread afterwards; the per-thread part (streams, arenas:
  * ~1 ms) is paid by each thread's own first call.  Returns 0, or a negative code -- ECGPU_ERR_HIP when the fixed vector does
  * not verify (a broken build or device). */
@@ -484,6 +485,11 @@ int ecgpu_bls_tower(void);
  * size; auto (default) chooses by batch size: rows up to ECGPU_ROW_MAX tuples, lane groups up to ECGPU_VM_MAX, two lanes per
  * tuple up to ECGPU_SPLIT_MAX, the lane kernel above. */
 int ecgpu_bls_last_pairing_path(void);
+/* The batch sizes at which auto mode changes kernels on the calling thread's device: out[0] = rows up to, out[1] = lane groups up
+ * to, out[2] = two lanes per tuple up to (then one lane per tuple); out[3] = 1 when out[0] / out[1] were MEASURED on this device
+ * (ecgpu_warmup with ECGPU_WARM_BLS_BATCHES times the kernel sets against each other on the reference's fixed vector and places
+ * the two crossovers), 0 for the built-in defaults.  ECGPU_ROW_MAX / ECGPU_VM_MAX / ECGPU_SPLIT_MAX override. */
+int ecgpu_bls_dispatch_thresholds(uint32_t out[4]);
 
 #ifdef __cplusplus
 }

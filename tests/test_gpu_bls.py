@@ -672,8 +672,10 @@ def config2_workload(gpu, tmp_path_factory):
     ("sums", "row", 4096, 1, "row"),
     ("sums", "row", 65536, 1, "row"),       # ... and the whole fault cycle at full size (64 workgroups per CU in turn)
     ("calls", "row", 1024, 2, "row"),       # behind the compact-code G2 stage kernels
-    ("sums", "auto", 1024, 1, "row"),       # the default dispatch on either side of ECGPU_ROW_MAX
-    ("sums", "auto", 1025, 1, "vm3"),
+    ("sums", "auto", 1024, 1, "row"),
+    ("sums", "auto", 1792, 1, "row"),       # the default dispatch on either side of ECGPU_ROW_MAX (round 6: 1 792, the measured crossover) ...
+    ("sums", "auto", 1793, 1, "vm3"),
+    ("sums", "auto:ECGPU_ROW_MAX=1024", 1025, 1, "vm3"),  # ... and of round 5's value, still selectable
     ("sums", "auto", 65536 + 300, 1, "lane"),    # a ragged tail short enough for the row machine behind a full round of the lane kernel
 ])
 def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, tower, pairing, n, want_tower, want_path):
@@ -687,7 +689,11 @@ def test_config2_full_size_fault_cycle_on_every_pairing_build(config2_workload, 
     import sys
     path, info = config2_workload
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ECGPU_TOWER=tower, ECGPU_PAIRING=pairing, PYTHONPATH=root)
+    extra = {}
+    if ":" in pairing:  # "auto:NAME=VALUE": one more dispatch control for this case
+        pairing, kv = pairing.split(":", 1)
+        extra = dict([kv.split("=", 1)])
+    env = dict(os.environ, ECGPU_TOWER=tower, ECGPU_PAIRING=pairing, PYTHONPATH=root, **extra)
     if pairing == "split2":
         env.update(ECGPU_PAIRING="split", ECGPU_FINALEXP_LANES="2")
     out = subprocess.run([sys.executable, "-m", "tests._bls_config2", "run", path, str(n), str(want_tower), want_path], env=env, cwd=root,
@@ -1274,3 +1280,46 @@ def test_warmup_takes_the_first_call_cost(gpu):
     assert res["cold_first_call_ms"] > res["first_call_after_warmup_ms"], res
     L = gpu._lib.load()
     assert L.ecgpu_warmup(0) == 0 and L.ecgpu_warmup(1 | 2 | 4) == 0  # idempotent; the batch classes verify the fixed vector too
+
+
+def test_measured_dispatch_thresholds_keep_parity(mutated_workload):
+    """ecgpu_warmup(ECGPU_WARM_BLS_BATCHES) times the kernel sets against each other on THIS device and places the two crossovers
+    (rows | lane groups, lane groups | two lanes per tuple: ecgpu_bls_dispatch_thresholds).  In a fresh process: the thresholds
+    are reported as measured and lie in their clamps, and batches on either side of EACH measured threshold return the C++
+    oracle's statuses through the path the thresholds name."""
+    import json
+    import os
+    import subprocess
+    import sys
+    path, info = mutated_workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import ctypes, json, pickle, sys
+from ethereum_consensus_amd import _lib, bls
+w = pickle.load(open(sys.argv[1], 'rb'))
+L = _lib.load(build_if_missing=False)
+assert L.ecgpu_init(0) == 0
+before = (ctypes.c_uint32 * 4)(); L.ecgpu_bls_dispatch_thresholds(before)
+assert L.ecgpu_warmup(1 | 2 | 4) == 0, L.ecgpu_last_error()
+thr = (ctypes.c_uint32 * 4)(); L.ecgpu_bls_dispatch_thresholds(thr)
+out = {'before': list(before), 'after': list(thr), 'cases': []}
+names = {1: 'lane', 3: 'vm3', 5: 'split', 7: 'row'}
+for n, want_path in ((thr[0], 'row'), (thr[0] + 1, 'vm3'), (thr[1], 'vm3'), (thr[1] + 1, 'split')):
+    got = bls.fast_aggregate_verify_batch(w['pks'][:48 * n], None, w['msgs'][:32 * n], w['sigs'][:96 * n])
+    bad = [i for i in range(n) if got[i] != w['cpp'][i]]
+    out['cases'].append({'n': n, 'path': names.get(L.ecgpu_bls_last_pairing_path()), 'want_path': want_path, 'mismatches': bad[:4]})
+print(json.dumps(out))
+"""
+    env = dict(os.environ, PYTHONPATH=root)
+    for k in ("ECGPU_ROW_MAX", "ECGPU_VM_MAX", "ECGPU_PAIRING", "ECGPU_TOWER"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code, path], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["before"][3] == 0 and res["after"][3] == 1, res
+    if res["after"][1] > 13000 or True:  # (a box with slow instruction fetch measures the first crossover only)
+        assert 512 <= res["after"][0] <= 3072 and 8192 <= res["after"][1] <= 24576, res
+    for c in res["cases"]:
+        assert not c["mismatches"], c
+        if res["after"][2]:
+            assert c["path"] == c["want_path"], (c, res)
