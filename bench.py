@@ -638,9 +638,7 @@ def run_bls(args, L, torch, dist, rank, world, n_total=None, strong=None):
         ops["bls_pairing"] = (0, 0, vm3_multiplies_per_tuple())
     if path == 5:  # Miller loop on two lanes per tuple; final exponentiation on one lane, or (up to half a round of lanes, or when
         # ECGPU_FINALEXP_LANES=2) on the lane pair as well: the same multiplies either way
-        two = os.environ.get("ECGPU_FINALEXP_LANES", "0")
-        pair_too = two == "2" or (two == "0" and 2 * n <= 65536 and os.environ.get("ECGPU_M2_WAVES") != "2")
-        pairing_kernel = "k_miller2_w1 + k_finalexp2_w1" if pair_too and 2 * n <= 65536 else ("k_miller2 + k_finalexp2" if pair_too else "k_miller2 + k_finalexp")
+        pairing_kernel = "k_miller2_w1 + k_finalexp2_w1"  # (the two-wave builds and the one-lane final exponentiation: experiments library only)
     mults_per_sig = sum(m * 351 + s_ * 273 + x for m, s_, x in ops.values())
     stages = {}
     for tag in ops:

@@ -17,15 +17,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-OBJDIR = os.path.join(LIBDIR, "obj")
-LIB = os.path.join(LIBDIR, "libecgpu.so")
+# ECGPU_EXPERIMENTS=1: the library with the kernel builds and dispatch controls that lost on measurement and are the default at
+# no size on any box (two-wave k_miller2 / k_finalexp2, the one-lane k_finalexp, ECGPU_PAIRING=auto1, ECGPU_SIDE_OVERLAP,
+# ECGPU_M2_WAVES, ECGPU_FINALEXP_LANES) -- lib/libecgpu_exp.so next to the product, selected with ECGPU_LIB
+EXPERIMENTS = os.environ.get("ECGPU_EXPERIMENTS") == "1"
+OBJDIR = os.path.join(LIBDIR, "obj_exp" if EXPERIMENTS else "obj")
+LIB = os.path.join(LIBDIR, "libecgpu_exp.so" if EXPERIMENTS else "libecgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 VM3_GEN_ARGS = os.environ.get("ECGPU_VM3_GEN_ARGS", "--lanes 16 --lanes-c 12 --window 60").split()
 # -pragma-unroll-threshold: the sums of products (bls_fp.h fp_sumprod) are 13 rows x up to 13 x 13 multiply-adds that
 # must be fully unrolled for their column accumulators to stay in registers; the default threshold stops at ~1000.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-         "-mllvm", "-pragma-unroll-threshold=1000000", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-mllvm", "-pragma-unroll-threshold=1000000", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + (["-DECG_EXPERIMENTS"] if EXPERIMENTS else [])
 
 
 def _newer(target: str, deps) -> bool:
@@ -84,7 +88,7 @@ def source_hash(src: str) -> str:
     return h.hexdigest()[:16]
 
 
-MANIFEST = os.path.join(LIBDIR, "build_manifest.json")
+MANIFEST = os.path.join(LIBDIR, "build_manifest_exp.json" if EXPERIMENTS else "build_manifest.json")
 
 
 def _write_manifest(entries: dict, path: str = MANIFEST):

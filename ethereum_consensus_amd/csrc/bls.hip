@@ -110,10 +110,46 @@ __global__ void __launch_bounds__(BLOCK, ECG_BLS_WAVES) k_sum(const Aff<F>* pts,
         if (out_st) out_st[t] = s;
     }
 }
+// chunk boundaries of a two-level sum: tuple t's range [lo, hi) cut into C pieces of equal length (the last ones may be empty)
+__global__ void k_sum_chunk_offsets(const u32* off, u32 n_total, u32 n_tuples, u32 C, u32* chunk_off) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_tuples * C) return;
+    if (i == n_tuples * C) {
+        chunk_off[i] = off ? off[n_tuples] : n_total;
+        return;
+    }
+    const u32 t = i / C, c = i % C;
+    const u32 lo = off ? off[t] : 0, hi = off ? off[t + 1] : n_total;
+    const u32 per = (hi - lo + C - 1) / C;
+    const u64 at = (u64)lo + (u64)per * c;
+    chunk_off[i] = at < hi ? (u32)at : hi;
+}
+// ar != nullptr: scratch for the two-level form.  A FEW LONG lists (SURVEY.md 8d config 2 read as ONE call with 65 536 keys:
+// crypto/bls.rs:114-132 over a whole registry; ecgpu_aggregate_sigs / _pks of 65 536 members) would otherwise be summed by one
+// workgroup -- 256 dependent additions per lane, 4 ms -- while 255 CUs idle: the list is cut into C chunks, a workgroup each
+// (statuses: the chunk's lowest failing index), and one more workgroup per tuple adds the C partial sums, where the first chunk
+// with a failure decides -- chunks are in list order, so that is the list's lowest failing index (round 6).
 template <class F>
 static void launch_sum(hipStream_t s, u32 n_tuples, u32 n_pts, const Aff<F>* pts, const u8* st, const u32* off, Aff<F>* out, u8* out_st,
-                       const u32* idx = nullptr, u32 idx_limit = 0) {
+                       const u32* idx = nullptr, u32 idx_limit = 0, Arena* ar = nullptr) {
     const bool wide = (u64)n_pts >= 512ull * n_tuples && n_tuples < 4096;
+    if (ar && n_tuples && n_tuples <= 32 && (u64)n_pts >= 8192ull * n_tuples) {
+        u32 C = n_pts / n_tuples / 1024;  // ~4 members per lane of a 256-lane workgroup
+        C = C > 256 ? 256 : C < 8 ? 8 : C;
+        const u32 n_chunks = n_tuples * C;
+        u32* chunk_off = (u32*)ar->take((size_t)(n_chunks + 1) * 4);
+        Aff<F>* part = (Aff<F>*)ar->take((size_t)n_chunks * sizeof(Aff<F>));
+        u8* part_st = ar->take(n_chunks);
+        u32* top_off = (u32*)ar->take((size_t)(n_tuples + 1) * 4);
+        if (chunk_off && part && part_st && top_off) {
+            hipLaunchKernelGGL(k_sum_chunk_offsets, dim3((n_chunks + 256) / 256), dim3(256), 0, s, off, n_pts, n_tuples, C, chunk_off);
+            hipLaunchKernelGGL(k_sum_chunk_offsets, dim3(1), dim3(256), 0, s, (const u32*)nullptr, n_chunks, 1u, n_tuples, top_off);  // top_off[t] = C t
+            hipLaunchKernelGGL((k_sum<F, 256>), dim3(n_chunks), dim3(256), 0, s, pts, st, (const u32*)chunk_off, n_pts, part, part_st, idx, idx_limit);
+            hipLaunchKernelGGL((k_sum<F, 64>), dim3(n_tuples), dim3(64), 0, s, (const Aff<F>*)part, (const u8*)part_st, (const u32*)top_off, n_chunks, out,
+                               out_st, (const u32*)nullptr, 0u);
+            return;
+        }
+    }
     if (wide)
         hipLaunchKernelGGL((k_sum<F, 256>), dim3(n_tuples), dim3(256), 0, s, pts, st, off, n_pts, out, out_st, idx, idx_limit);
     else
@@ -416,7 +452,8 @@ static size_t fav_ws_bytes(u32 n, u32 n_pks) {
     const size_t xf = vm3_xfer_bytes(n);
     const size_t maps = n <= g_h2c_split_max ? (size_t)2 * n * sizeof(J2) + 256 : 0;
     const size_t miller_values = (size_t)n * sizeof(Fp12) + 256;  // k_miller2 -> k_finalexp (not alive together with xf: the larger counts)
-    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + (xf > miller_values ? xf : miller_values) + maps + 8192;
+    const size_t two_level_sum = 32 * 256 * (sizeof(A1) + 8) + 8192;  // launch_sum's chunk offsets, partial sums and statuses (<= 32 tuples x 256 chunks)
+    return (size_t)n_pks * (sizeof(A1) + 1) + (size_t)n * (sizeof(A1) + 2 * sizeof(A2) + 4) + (xf > miller_values ? xf : miller_values) + maps + two_level_sum + 8192;
 }
 // Which kernels run the pairing check.  The lane kernel (one lane per tuple, state in VGPRs/AGPRs + LDS lane slots + private
 // segment) has the best throughput but one tuple's check is a 24 ms dependent chain, so a batch of a few thousand tuples
@@ -429,7 +466,9 @@ static const int g_pairing_mode = [] {
     if (e && !strcmp(e, "lane")) return 0;
     if (e && !strcmp(e, "vm3")) return 4;
     if (e && !strcmp(e, "split")) return 5;   // two lanes per tuple for the Miller loop (k_miller2) + k_finalexp, every size
+#if defined(ECG_EXPERIMENTS)
     if (e && !strcmp(e, "auto1")) return 6;   // round 3's dispatch: lane groups up to ECGPU_VM_MAX tuples, the one-lane kernel above
+#endif
     if (e && !strcmp(e, "row")) return 7;     // round 5: the row machine (bls_row.hip) at every size
     return 3;
 }();
@@ -477,8 +516,12 @@ static const int g_g2_waves = [] {  // ECGPU_G2_WAVES=1|2 forces the register bu
 // ECGPU_SIDE_OVERLAP=1 (experiment): the three side stages of a big K = 1 batch on three streams, the G2 ones in their two-wave
 // builds, so that a SIMD holds a wave of each
 static const int g_side_overlap = [] {
+#if defined(ECG_EXPERIMENTS)
     const char* e = getenv("ECGPU_SIDE_OVERLAP");
     return e ? atoi(e) : 0;
+#else
+    return 0;  // (measured twice, never a gain: DESIGN.md 3.2; the control exists in the experiments library only)
+#endif
 }();
 // ECGPU_H2C_FINISH_LANES=1: the one-lane (round 3) end of the small-batch message stage.  Default: the lane pair -- on a box
 // with slow instruction fetch as well (its hot loop, one 43 KB doubling, fits the instruction cache: a slot 11.0 -> 8.2 ms
@@ -634,7 +677,7 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         }
         if (d_pk_off) {
             ProfScope ps("bls_pk_aggregate", s);
-            launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u);
+            launch_sum<Fp>(s, n, n_pks, (const A1*)pts, (const u8*)st, d_pk_off, agg, st_pk, d_idx, reg ? (u32)reg->capacity : 0u, &ar);
         }
     };
     // beyond 65 536 tuples more than one wave per SIMD is waiting: the builds that leave room for two (bls_g2_kernels_w2.hip).
@@ -721,8 +764,10 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             lane_round = hipGetDeviceProperties(&prop, current_device()) == hipSuccess ? (u32)prop.multiProcessorCount * 4u * BLS_BLOCK : 65536u;
             lane_rounds[current_device()].store(lane_round, std::memory_order_relaxed);
         }
+#if defined(ECG_EXPERIMENTS)
         static const int g_finalexp_lanes = [] { const char* e = getenv("ECGPU_FINALEXP_LANES"); return e ? atoi(e) : 0; }();
         static const int g_m2_waves = [] { const char* e = getenv("ECGPU_M2_WAVES"); return e ? atoi(e) : 0; }();  // 2: the two-wave build of k_miller2 at every size
+#endif
         // The three pairing paths over a sub-range [base, base + cnt) of the batch (every per-tuple array is indexed by tuple;
         // the key offsets are only ever differenced).
         auto run_lane = [&](u32 base, u32 cnt) {
@@ -743,24 +788,35 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
         auto run_split = [&](u32 base, u32 cnt) -> int {
             Fp12* fs = (Fp12*)ar.take((size_t)cnt * sizeof(Fp12));
             if (!fs) return ECGPU_ERR_OOM;
+            // The builds with the whole register file: up to half a round of lanes -- everything auto mode sends here -- one wave per
+            // SIMD is all there is (a forced ECGPU_PAIRING=split beyond that runs them in rounds).  The two-wave builds (k_miller2,
+            // k_finalexp2) and the one-lane final exponentiation (k_finalexp) lost on measurement and live in the
+            // experiments library only (round 6: ECGPU_EXPERIMENTS=1 at build time).
+            auto miller = k_miller2_w1;
+            auto finalexp_pair = k_finalexp2_w1;
+            bool pair_finalexp = true;
+#if defined(ECG_EXPERIMENTS)
             const bool one_wave = 2 * (u64)cnt <= lane_round && g_m2_waves != 2;
+            if (!one_wave) miller = k_miller2, finalexp_pair = k_finalexp2;
+            pair_finalexp = g_finalexp_lanes == 2 || (g_finalexp_lanes == 0 && one_wave);
+#endif
             {
                 ProfScope p2("bls_miller2", s);
-                // up to half a round of lanes one wave per SIMD is all there is: the build with the whole register file
-                hipLaunchKernelGGL(one_wave ? k_miller2_w1 : k_miller2, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s,
-                                   (const A1*)agg + base, (const u8*)st_pk + base,
+                hipLaunchKernelGGL(miller, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s, (const A1*)agg + base, (const u8*)st_pk + base,
                                    d_pk_off ? d_pk_off + base : nullptr, (const A2*)hpts + base, (const A2*)sigpts + base, (const u8*)st_dec + base,
                                    (const u8*)st_grp + base, d_sigs96 + (size_t)96 * base, cnt, eth_variant, d_status + base, fs);
             }
             {
                 ProfScope p3("bls_finalexp", s);
-                // on the lane pair as well (bls_finalexp2.h) where that is one wave per SIMD: 32 768 tuples 10.4 -> 6.3 ms; with two
-                // waves per SIMD it is 11.6 ms against the one-lane kernel's 10.4 (profiles/r04f2_*).  ECGPU_FINALEXP_LANES=1 | 2 forces.
-                if (g_finalexp_lanes == 2 || (g_finalexp_lanes == 0 && one_wave))
-                    hipLaunchKernelGGL(one_wave ? k_finalexp2_w1 : k_finalexp2, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, cnt,
-                                       d_status + base);
-                else
+                // on the lane pair as well (bls_finalexp2.h): 32 768 tuples 10.4 -> 6.3 ms (profiles/r04f2_*)
+                if (pair_finalexp) {
+                    hipLaunchKernelGGL(finalexp_pair, grid_for(2 * cnt), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, cnt, d_status + base);
+                }
+#if defined(ECG_EXPERIMENTS)
+                else {
                     hipLaunchKernelGGL(k_finalexp, grid_for(cnt), dim3(BLS_BLOCK), 0, s, (const Fp12*)fs, cnt, d_status + base);
+                }
+#endif
             }
             return ECGPU_SUCCESS;
         };
@@ -1041,7 +1097,7 @@ int ecgpu_aggregate_sigs(const uint8_t* sigs96, uint32_t n, uint8_t* out96) {
     if (n == 0) return ECGPU_EMPTY_AGGREGATE;  // bls.rs:80-82
     if (!sigs96 || !out96) return ECGPU_ERR_BAD_ARG;
     CallCtx k;
-    int rc = begin_call(k, nullptr, (size_t)n * (96 + sizeof(A2) + 2) + sizeof(A2) + 8192);
+    int rc = begin_call(k, nullptr, (size_t)n * (96 + sizeof(A2) + 2) + sizeof(A2) + 256 * (sizeof(A2) + 8) + 16384);
     if (rc) return rc;
     u8* d_sigs;
     if ((rc = h2d(k, d_sigs, sigs96, (size_t)n * 96))) return rc;
@@ -1053,7 +1109,7 @@ int ecgpu_aggregate_sigs(const uint8_t* sigs96, uint32_t n, uint8_t* out96) {
     if (!pts || !st_dec || !st_grp || !sum || !d_out) return ECGPU_ERR_OOM;
     hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, k.s, d_sigs, n, pts, st_dec, st_grp);
     hipLaunchKernelGGL(k_agg_sig_status, dim3(1), dim3(AGG_STATUS_BLOCK), 0, k.s, (const u8*)st_dec, (const u8*)st_grp, n, d_out + 96);
-    launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr);
+    launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr, (const u32*)nullptr, 0u, k.ar);
     hipLaunchKernelGGL(k_compress_g2, dim3(1), dim3(64), 0, k.s, (const A2*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
     u8 h[97];
@@ -1068,7 +1124,7 @@ int ecgpu_aggregate_pks(const uint8_t* pks48, uint32_t n, uint8_t* out48) {
     if (n == 0) return ECGPU_EMPTY_AGGREGATE;  // bls.rs:136-138
     if (!pks48 || !out48) return ECGPU_ERR_BAD_ARG;
     CallCtx k;
-    int rc = begin_call(k, nullptr, (size_t)n * (48 + sizeof(A1) + 1) + sizeof(A1) + 8192);
+    int rc = begin_call(k, nullptr, (size_t)n * (48 + sizeof(A1) + 1) + sizeof(A1) + 256 * (sizeof(A2) + 8) + 16384);
     if (rc) return rc;
     u8* d_pks;
     if ((rc = h2d(k, d_pks, pks48, (size_t)n * 48))) return rc;
@@ -1078,7 +1134,7 @@ int ecgpu_aggregate_pks(const uint8_t* pks48, uint32_t n, uint8_t* out48) {
     u8* d_out = k.ar->take(48 + 1);
     if (!pts || !st || !sum || !d_out) return ECGPU_ERR_OOM;
     launch_pk_validate(k.s, d_pks, n, pts, st);
-    launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48);
+    launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48, (const u32*)nullptr, 0u, k.ar);
     hipLaunchKernelGGL(k_compress_g1, dim3(1), dim3(64), 0, k.s, (const A1*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
     u8 h[49];
@@ -1098,7 +1154,7 @@ int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uin
         return ECGPU_ERR_BAD_ARG;
     }
     CallCtx k;
-    int rc = begin_call(k, nullptr, (size_t)n * (48 + 32 + sizeof(A1) + 1) + sizeof(A1) + msm_ws_bytes(n, sizeof(J1)) + 8192);
+    int rc = begin_call(k, nullptr, (size_t)n * (48 + 32 + sizeof(A1) + 1) + sizeof(A1) + msm_ws_bytes(n, sizeof(J1)) + 256 * (sizeof(A2) + 8) + 16384);
     if (rc) return rc;
     u8 *d_pks, *d_sc;
     if ((rc = h2d(k, d_pks, pks48, (size_t)n * 48))) return rc;
@@ -1118,7 +1174,7 @@ int ecgpu_g1_msm(const uint8_t* pks48, const uint8_t* scalars32, uint32_t n, uin
             ProfScope ps("bls_scalar_mul_g1", k.s);
             hipLaunchKernelGGL(k_scalar_mul<Fp>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st, (const u8*)d_sc, scalar_bits, n);
         }
-        launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48);
+        launch_sum<Fp>(k.s, 1, n, (const A1*)pts, (const u8*)st, (const u32*)nullptr, sum, d_out + 48, (const u32*)nullptr, 0u, k.ar);
     }
     hipLaunchKernelGGL(k_compress_g1, dim3(1), dim3(64), 0, k.s, (const A1*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());
@@ -1139,7 +1195,7 @@ int ecgpu_g2_msm(const uint8_t* sigs96, const uint8_t* scalars32, uint32_t n, ui
         return ECGPU_ERR_BAD_ARG;
     }
     CallCtx k;
-    int rc = begin_call(k, nullptr, (size_t)n * (96 + 32 + sizeof(A2) + 2) + sizeof(A2) + msm_ws_bytes(n, sizeof(J2)) + 8192);
+    int rc = begin_call(k, nullptr, (size_t)n * (96 + 32 + sizeof(A2) + 2) + sizeof(A2) + msm_ws_bytes(n, sizeof(J2)) + 256 * (sizeof(A2) + 8) + 16384);
     if (rc) return rc;
     u8 *d_sigs, *d_sc;
     if ((rc = h2d(k, d_sigs, sigs96, (size_t)n * 96))) return rc;
@@ -1161,7 +1217,7 @@ int ecgpu_g2_msm(const uint8_t* sigs96, const uint8_t* scalars32, uint32_t n, ui
             ProfScope ps("bls_scalar_mul_g2", k.s);
             hipLaunchKernelGGL(k_scalar_mul<Fp2>, grid_for(n), dim3(BLS_BLOCK), 0, k.s, pts, (const u8*)st_dec, (const u8*)d_sc, scalar_bits, n);
         }
-        launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr);
+        launch_sum<Fp2>(k.s, 1, n, (const A2*)pts, (const u8*)nullptr, (const u32*)nullptr, sum, (u8*)nullptr, (const u32*)nullptr, 0u, k.ar);
     }
     hipLaunchKernelGGL(k_compress_g2, dim3(1), dim3(64), 0, k.s, (const A2*)sum, d_out);
     ECG_HIP_CHECK(hipGetLastError());

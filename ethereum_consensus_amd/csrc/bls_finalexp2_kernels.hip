@@ -11,6 +11,9 @@
 #define ECG_F2_NAME k_finalexp2
 #endif
 #define ECG_BLS_WAVES ECG_F2_WAVES
+// (round 6) the two-wave build runs at no batch size by default (11.6 ms against the one-lane kernel's 10.4, profiles/r04f2_*): compiled
+// only into the experiments library, like the two-wave k_miller2
+#if ECG_F2_WAVES == 1 || defined(ECG_EXPERIMENTS)
 #include "bls_kernels.h"
 #include "bls_finalexp2.h"
 
@@ -30,3 +33,4 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_F2_WAVES) ECG_F2_NAME(const Fp1
 }
 
 }  // namespace ecg
+#endif

@@ -51,12 +51,16 @@ __global__ void k_sig_decode_calls(const u8* sigs96, u32 n, A2* pts, u8* st_dec)
 // bls_pairing_kernels.hip
 __global__ void k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out);
+#if defined(ECG_EXPERIMENTS)
 __global__ void k_finalexp(const Fp12* fs, u32 n, u8* status_out);
 __global__ void k_finalexp2(const Fp12* fs, u32 n, u8* status_out);
+#endif
 __global__ void k_finalexp2_w1(const Fp12* fs, u32 n, u8* status_out);
 // bls_pairing2_kernels.hip: the same check's Miller loop on two lanes per tuple, two waves per SIMD (bls_pair2.h)
+#if defined(ECG_EXPERIMENTS)
 __global__ void k_miller2(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out, Fp12* fs);
+#endif
 __global__ void k_miller2_w1(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                           const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* status_out, Fp12* fs);
 __global__ void k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs);

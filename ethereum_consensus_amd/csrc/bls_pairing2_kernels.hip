@@ -13,6 +13,9 @@
 #define ECG_M2_NAME k_miller2
 #endif
 #define ECG_BLS_WAVES ECG_M2_WAVES
+// (round 6) the two-wave build is the default at no batch size on any box (17.6 GB of private-segment traffic per
+// 65 536-tuple launch): it is compiled only into the experiments library (ECGPU_EXPERIMENTS=1 python -m ethereum_consensus_amd.build)
+#if ECG_M2_WAVES == 1 || defined(ECG_EXPERIMENTS)
 #include "bls_kernels.h"
 #include "bls_pair2.h"
 
@@ -50,3 +53,4 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_M2_WAVES) ECG_M2_NAME(const A1*
 }
 
 }  // namespace ecg
+#endif

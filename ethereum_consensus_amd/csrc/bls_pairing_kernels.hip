@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_pairing(const A1* 
 
 // Second half of the two-lanes-per-tuple pairing check (bls_pairing2_kernels.hip k_miller2 wrote the Miller value of every
 // tuple whose status is still 0xff): final exponentiation on one lane per tuple, status.
+#if defined(ECG_EXPERIMENTS)  // the one-lane final exponentiation behind k_miller2: default at no size since round 4 (the lane pair runs it)
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_finalexp(const Fp12* fs, u32 n, u8* status_out) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -40,6 +41,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_finalexp(const Fp1
     final_exponentiation(e, f);
     status_out[i] = fp12_is_one(e) ? ECGPU_SUCCESS : ECGPU_VERIFY_FAIL;
 }
+#endif
 
 // ---- aggregate_verify: one Miller loop per lane, product + final exponentiation on one lane ------
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) k_miller_pairs(const A1* pts, const A2* hpts, const A2* sigpt, u32 n, Fp12* fs) {

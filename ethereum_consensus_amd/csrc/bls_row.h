@@ -43,7 +43,11 @@ ROW_FN rv32 rv_lt(rv32 a, u32 k) { return a < k ? 1u : 0u; }
 ROW_FN rv32 rv_sel(rv32 c, rv32 a, rv32 b) { return c ? a : b; }
 ROW_FN rv64 rv_zero64() { return 0; }
 ROW_FN rv64 rv_mad64(rv32 a, rv32 b, rv64 c) { return (u64)a * b + c; }  // v_mad_u64_u32
-ROW_FN rv64 rv_mad64s(rv32 a_signed, rv32 b, rv64 c) { return (u64)((int64_t)(int32_t)a_signed * (int64_t)b + (int64_t)c); }  // v_mad_i64_i32 (b < 2^31)
+// b < 2^31 (a limb <= 2^30 + a few, or the small non-negative top limb of a value in range): BOTH operands are stated as signed
+// 32-bit, which is what makes this ONE v_mad_i64_i32.  (Round 5 extended b as unsigned: the compiler then emulates the 32 x 33-bit
+// signed product with two v_mad_u64_u32, an arithmetic shift and two moves -- five instructions per term of every linear step,
+// 12 of the ~45 instructions of an addition or subtraction on a row: profiles/r06e_row_linear_ops.txt.)
+ROW_FN rv64 rv_mad64s(rv32 a_signed, rv32 b, rv64 c) { return (u64)((int64_t)(int32_t)a_signed * (int64_t)(int32_t)b + (int64_t)c); }
 ROW_FN rv32 rv_lo(rv64 a) { return (u32)a; }
 ROW_FN rv64 rv_shr64(rv64 a, u32 n) { return a >> n; }
 ROW_FN rv64 rv_sar64(rv64 a, u32 n) { return (u64)((int64_t)a >> n); }
@@ -93,7 +97,9 @@ ROW_FN rv32 rv_pair_any(rv32 x) {
 // (limbs 0 .. 11 come out < 2^30; the top limb, lane 12, takes its carry and keeps every bit -- it may be a signed dword)
 ROW_FN rv32 rv_carry_exact(rv32 v) {
     const bool low = (threadIdx.x & 15u) < 12;
-    const u64 g = __builtin_amdgcn_ballot_w64(low && (v >> 30) != 0), pr = __builtin_amdgcn_ballot_w64(low && v == FP_MASK);
+    // (the lane condition as a constant mask on the scalar side: a ballot of `low && ...` costs a select and a second compare per ballot)
+    constexpr u64 LOW_LANES = 0x0fff0fff0fff0fffull;
+    const u64 g = __builtin_amdgcn_ballot_w64(v > FP_MASK) & LOW_LANES, pr = __builtin_amdgcn_ballot_w64(v == FP_MASK) & LOW_LANES;
     const u64 y = g << 1, cin = ((pr + y) ^ pr ^ y) | y;
     const u32 t = v + (u32)((cin >> (threadIdx.x & 63u)) & 1ull);
     return low ? (t & FP_MASK) : t;
