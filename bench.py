@@ -139,6 +139,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the strong_2p20 / epoch / slots sub-records of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aggregates", action="store_true", help="skip the secondary K = 2048 aggregates line")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="warm up without the timed batches that place the dispatch thresholds (counter passes: the per-launch means of "
+                         "tools/pmc_to_json.py must not mix in the calibration's launches)")
     ap.add_argument("--even-shards", action="store_true", help="strong scaling: keep the even split (no speed-weighted re-sharding)")
     ap.add_argument("--verbose", action="store_true",
                     help="print the full record (every note and provenance string) instead of the compact line; the full record is "
@@ -1454,7 +1457,7 @@ def main():
         raise RuntimeError(f"ecgpu_init -> {rc}: {L.ecgpu_last_error()}")
     # what a host that verifies blocks and epochs does once per process: the warm-up with the reference's fixed
     # vector, which also places the dispatch thresholds where THIS device's kernels cross (untimed; `latency_curve.thresholds`)
-    rc = L.ecgpu_warmup(1 | 2 | 4)
+    rc = L.ecgpu_warmup((1 | 4) if args.no_calibration else (1 | 2 | 4))
     if rc != 0:
         raise RuntimeError(f"ecgpu_warmup -> {rc}: {L.ecgpu_last_error()}")
     preflight = multi_gpu_preflight(L, torch, dist, rank, world, local) if dist is not None else None

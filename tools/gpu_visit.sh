@@ -27,7 +27,7 @@ for step in "$@"; do
     tests) timeout $TT python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/${tag}${sfx}_gpu_tests.txt;;
     tests:*) timeout $TT python -m pytest tests -m gpu -x -q -k "${step#tests:}" 2>&1 | tail -6 | tee gpurun_out/${tag}${sfx}_gpu_tests_k.txt;;
     bench) timeout 900 python bench.py > gpurun_out/${tag}${sfx}_bench.json 2> gpurun_out/${tag}${sfx}_bench_err.txt; tail -c 600 gpurun_out/${tag}${sfx}_bench_err.txt
-           python tools/bench_digest.py gpurun_out/${tag}${sfx}_bench.json;;
+           cp gpurun_out/bench_full.json gpurun_out/${tag}${sfx}_bench_full.json 2>/dev/null; python tools/bench_digest.py gpurun_out/${tag}${sfx}_bench.json;;
     bench:*) a=${step#bench:}; timeout 900 python bench.py ${a//_/ } > gpurun_out/${tag}${sfx}_bench_${a//[^A-Za-z0-9]/}.json 2> gpurun_out/${tag}${sfx}_bench_err.txt
            tail -c 600 gpurun_out/${tag}${sfx}_bench_err.txt; python tools/bench_digest.py gpurun_out/${tag}${sfx}_bench_${a//[^A-Za-z0-9]/}.json;;
     probe) timeout $TO python tools/bls_probe.py 65536 2>&1 | tee gpurun_out/${tag}${sfx}_probe.txt;;
@@ -37,19 +37,19 @@ for step in "$@"; do
            [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" gpurun_out/${tag}${sfx}_kernel_stats.txt && head -14 gpurun_out/${tag}${sfx}_kernel_stats.txt | cut -c1-70,100-200
            rm -rf gpurun_out/prof_$tag;;
     pmc) for c in FETCH_SIZE WRITE_SIZE; do
-           timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-aggregates --workload bls > gpurun_out/${tag}${sfx}_pmc_$c.log 2>&1
+           timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-aggregates --no-calibration --workload bls > gpurun_out/${tag}${sfx}_pmc_$c.log 2>&1
            python tools/pmc_summary.py gpurun_out/pmc_${tag}_$c gpurun_out/${tag}${sfx}_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_pmc_$c.txt | cut -c1-160
          done
          # profiles/pmc_traffic.json: per-step traffic of the dominant kernels, keyed by the source hash of the kernels that ran (4 steps: 3 + 1 warm-up)
          python tools/pmc_to_json.py $tag 4 > gpurun_out/${tag}${sfx}_pmc_traffic.json && cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
          for c in FETCH_SIZE WRITE_SIZE; do rm -rf gpurun_out/pmc_${tag}_$c; done;;
     sq) P1="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INSTS_LDS"
-        timeout 900 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-aggregates --workload bls > gpurun_out/${tag}${sfx}_sq.log 2>&1
+        timeout 900 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-aggregates --no-calibration --workload bls > gpurun_out/${tag}${sfx}_sq.log 2>&1
         python tools/pmc_summary.py gpurun_out/pmc_${tag}_sq gpurun_out/${tag}${sfx}_sq_raw.txt
         python tools/sq_digest.py gpurun_out/${tag}${sfx}_sq_raw.txt | tee gpurun_out/${tag}${sfx}_sq_counters.txt
         rm -rf gpurun_out/pmc_${tag}_sq;;
     pmc_merkle) for c in FETCH_SIZE WRITE_SIZE; do
-           timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload merkle > gpurun_out/${tag}${sfx}_merkle_pmc_$c.log 2>&1
+           timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-calibration --workload merkle > gpurun_out/${tag}${sfx}_merkle_pmc_$c.log 2>&1
            python tools/pmc_summary.py gpurun_out/pmc_${tag}_$c gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt; head -6 gpurun_out/${tag}${sfx}_merkle_pmc_$c.txt | cut -c1-160
          done
          python tools/pmc_to_json.py $tag 4 merkle > gpurun_out/${tag}${sfx}_merkle_pmc_traffic.json && cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json

@@ -36,6 +36,35 @@ def main(db, out=None):
                     lines.append(f"{name[:70]:70s} {r[1]:12d} {r[2]:6d} {r[3]:10.2f} {r[4]:10.2f} {r[5]:10.2f}")
     except sqlite3.Error as e:  # (an older schema: the aggregate table stands alone)
         lines += ["", f"# per-launch-size table unavailable: {e}"]
+    # lone vs overlapped launches (the Merkle pass's table average mixed the two-roots-in-flight launches, which
+    # run beside another root's tail, with the lone ones the roofline is quoted on): a launch is "overlapped" when launches of OTHER
+    # streams cover more than 10 % of its duration; kernels that have both kinds get a row each
+    try:
+        evs = con.execute("select name, start, end from kernels order by start").fetchall()
+        kinds = {}
+        active = []  # (end, index) of launches still running
+        cover = [0.0] * len(evs)
+        for i, (name, st, en) in enumerate(evs):
+            active = [(e, j) for (e, j) in active if e > st]
+            for e, j in active:
+                ov = min(e, en) - st
+                if ov > 0:
+                    cover[i] += ov
+                    cover[j] += ov
+            active.append((en, i))
+        for i, (name, st, en) in enumerate(evs):
+            dur = max(en - st, 1)
+            kinds.setdefault(name, {}).setdefault("overlapped" if cover[i] > 0.1 * dur else "lone", []).append(dur / 1e3)
+        both = {k: v for k, v in kinds.items() if len(v) == 2}
+        if both:
+            lines += ["", "# lone vs overlapped launches (overlapped: other launches run during > 10 % of the launch): kernels that have both",
+                      f"{'kernel':70s} {'kind':>11s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}"]
+            for name, v in sorted(both.items(), key=lambda kv: -sum(sum(x) for x in kv[1].values()))[:24]:
+                for kind in ("lone", "overlapped"):
+                    d = v[kind]
+                    lines.append(f"{name[:70]:70s} {kind:>11s} {len(d):6d} {sum(d) / len(d):10.2f} {min(d):10.2f} {max(d):10.2f}")
+    except sqlite3.Error as e:
+        lines += ["", f"# lone / overlapped table unavailable: {e}"]
     text = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(text)
