@@ -799,15 +799,15 @@ static int patch_now(ecgpu_resident_state* st, const u64* offsets, const u64* da
     // from where it lies, and the call waits for it.
     const size_t off_pairs = n * sizeof(PatchDesc), off_data = off_pairs + 8 * pairs.size(), block = off_data + total;
     rc = ar.reserve(block + 8192);
-    if (rc) return rc;
+    if (rc) return st->trees.abandon_collected(), rc;
     u8* d_block = ar.take(block ? block : 1);
-    if (!d_block) return ECGPU_ERR_OOM;
+    if (!d_block) return st->trees.abandon_collected(), ECGPU_ERR_OOM;
     const bool ring = block <= (1u << 20);
     if (ring) {
         u8* h_block;
         hipEvent_t copied;
         rc = c->uploads.acquire(block, &h_block, &copied);
-        if (rc) return rc;
+        if (rc) return st->trees.abandon_collected(), rc;
         std::memcpy(h_block, descs.data(), off_pairs);
         if (!pairs.empty()) std::memcpy(h_block + off_pairs, pairs.data(), 8 * pairs.size());
         if (total) std::memcpy(h_block + off_data, data, total);

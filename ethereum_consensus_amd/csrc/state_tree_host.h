@@ -39,6 +39,12 @@ struct ResidentTrees {
     // whose share of the list would overflow is flagged all_dirty instead
     void collect(u64 lo, u64 hi, std::vector<u64>& pairs);
     void collect_entries(u32 slot, u64 first, u64 last, std::vector<u64>& pairs);
+    // an error between collect() and mark(): the host's accounting describes marks that never reached the device (advisor, round 5).
+    // Nothing was changed on the device either, so no root can be wrong -- the fields with pending accounting are simply rebuilt
+    void abandon_collected() {
+        for (u32 s = 0; s < n_slots; s++)
+            if (f[s].live && f[s].bound) f[s].all_dirty = true;
+    }
     // enqueue the marks (pairs already on the device)
     int mark(hipStream_t s, const u64* d_pairs, u32 n);
     // enqueue rebuilds of all_dirty fields and ONE climb launch over the dirty list; *hashes += the host-known part (rebuilds)

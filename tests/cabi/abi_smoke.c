@@ -27,6 +27,9 @@ int main(int argc, char** argv) {
         unsigned char pk[48] = {0}, sig[96] = {0};
         if (ecgpu_verify(pk, (const unsigned char*)"x", 1, sig) != ECGPU_ERR_NO_DEVICE) return 3;
         if (ecgpu_last_error() == NULL) return 4;
+        if (ecgpu_warmup(0) != ECGPU_ERR_NO_DEVICE) return 5;
+        uint32_t thr0[4];
+        if (ecgpu_bls_dispatch_thresholds(thr0) != ECGPU_ERR_NO_DEVICE) return 6;
         printf("no device: every entry point refused, as designed (%s)\n", ecgpu_last_error());
         return 0;
     }
@@ -35,6 +38,10 @@ int main(int argc, char** argv) {
     if (hex2bin(argv[2], want_root, 32) || hex2bin(argv[3], pk, 48) || hex2bin(argv[4], sig, 96)) return 65;
     const char* msg = argv[5];
     if (ecgpu_init(-1) != ECGPU_SUCCESS) return 10;
+    /* the warm-up a host makes once per process (real calls with the reference's fixed vector) and the dispatch thresholds */
+    if (ecgpu_warmup(ECGPU_WARM_BLS | ECGPU_WARM_MERKLE) != ECGPU_SUCCESS) return 30;
+    uint32_t thr[4];
+    if (ecgpu_bls_dispatch_thresholds(thr) != ECGPU_SUCCESS || thr[0] == 0 || thr[1] < thr[0] || thr[2] < thr[1]) return 31;
     if (ecgpu_htr_beacon_block_header(hdr, root) != ECGPU_SUCCESS || memcmp(root, want_root, 32)) return 11;
     if (ecgpu_verify(pk, (const unsigned char*)msg, strlen(msg), sig) != ECGPU_SUCCESS) return 12;
     if (ecgpu_verify(pk, (const unsigned char*)"forged", 6, sig) != ECGPU_VERIFY_FAIL) return 13;
