@@ -238,6 +238,10 @@ ROW_FN rv32 row_sumprod(const rv32 (&a)[N], const rv32 (&b)[N][13], rv32 p_limb)
     v = rv_add(rv_and(v, mask), rv_from_prev(rv_shr(v, 30)));
     return v;
 }
+// (Round 6 experiment, not kept: the compiler computes the 13 column sums first and then runs the reduction as one dependent chain;
+// issuing the products of column i + 2 INSIDE iteration i -- a scheduling barrier per iteration held them there, the hazard slots
+// shrank from two wait states to one -- made a lone check 1.01 -> 0.985 ms and 1 024 tuples 2.09 -> 2.36 ms: the interleaved form
+// holds more accumulators live and the waves that share a SIMD lose more than the lone wave gains.  profiles/r06g_interleave_probe.txt)
 
 // c_own * own + c_par * par + K p, small signed coefficients (the lane groups' vm3_derive): positive by construction, limbs
 // <= 2^30 except the top one (limb 12), which keeps everything above it.
