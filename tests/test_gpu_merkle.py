@@ -1164,3 +1164,57 @@ def test_resident_state_field_writes_at_2_pow_20_validators_against_the_c_oracle
         assert root == oracle_state_root_fast(f, "mainnet"), slot
         assert hashes <= 160_000, hashes  # dirty paths only
     st.close()
+
+
+def test_resident_state_handed_between_threads_keeps_host_order(gpu):
+    """a state may be handed from one host thread to another -- each has its own stream -- and every
+    change / root must then see the host's order without a host synchronisation in between: patches return as soon as their
+    bytes are staged.  Two threads alternate on ONE state (never at once): A writes balances and flushes (asynchronous), B at
+    once pushes a validator, writes the new validator's balance and roots; then the roles swap.  Every root == oracle."""
+    import threading
+    from oracle import ssz as O
+    from tests import _statefields as SF
+    ssz = gpu
+    r = random.Random(31)
+    t, v = _fresh_state("deneb", "minimal", 800, seed=12)
+    st = ssz.ResidentBeaconStateDeneb(t.serialize(v), ssz.MINIMAL)
+    assert st.hash_tree_root() == t.htr(v)
+    turn = threading.Semaphore(0), threading.Semaphore(0)
+    errors = []
+
+    def worker(me):
+        try:
+            for step in range(40):
+                turn[me].acquire()
+                n = len(v["validators"])
+                if step % 2 == me:  # writer of this step: many small writes, flushed, NOT synchronised
+                    for _ in range(300):
+                        i = r.randrange(n)
+                        v["balances"][i] = r.randrange(1 << 40)
+                        st.patch_elements("balances", i, v["balances"][i].to_bytes(8, "little"))
+                    st.flush()
+                else:  # the other thread carries on at once: a length change, a write behind it, a root
+                    rec = SF.random_validator(r)
+                    v["validators"].append(rec)
+                    v["balances"].append(7)
+                    for name in ("previous_epoch_participation", "current_epoch_participation", "inactivity_scores"):
+                        v[name].append(0)
+                    st.add_validator(O.Validator.serialize(rec), 7)
+                    v["balances"][n] = 9
+                    st.patch_elements("balances", n, (9).to_bytes(8, "little"))
+                    if st.hash_tree_root() != t.htr(v):
+                        errors.append((me, step))
+                turn[1 - me].release()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+            turn[1 - me].release()
+
+    th = [threading.Thread(target=worker, args=(k,), daemon=True) for k in (0, 1)]
+    for x in th:
+        x.start()
+    turn[0].release()
+    for x in th:
+        x.join(timeout=600)
+    assert not errors, errors[:5]
+    assert st.hash_tree_root() == t.htr(v)
+    st.close()
