@@ -1318,3 +1318,29 @@ print(json.dumps(out))
         # (a box with slow instruction fetch -- tower 2 -- sends everything above the rows to the lane groups)
         want = c["want_path"] if res["tower"] == 1 or c["want_path"] == "row" else "vm3"
         assert c["path"] == want, (c, res)
+
+
+@pytest.mark.parametrize("n", [8191, 8192, 8193, 20000])
+def test_eth_aggregate_public_keys_of_long_lists_through_the_two_level_sum(gpu, n):
+    """crypto/bls.rs:135-148 at the sizes where ONE list is cut into chunks (launch_sum, csrc/bls.hip: >= 8 192 members per list,
+    round 6) and just below: the sum equals (sum of the secret keys) g1; a damaged member at the first / last position of a chunk
+    and in the list's last position reports ITS status, the lowest damaged index winning over later ones (the reference converts
+    left to right, `?` on the first failure: crypto/bls.rs:139-142)."""
+    from ethereum_consensus_amd import synthetic as syn
+    skb = syn.bls_secret_keys(n, base=777)
+    sks = [int.from_bytes(skb[32 * i:32 * i + 32], "big") for i in range(n)]
+    pk_all = gpu.sk_to_pk_batch(skb)
+    pks = [pk_all[48 * i:48 * i + 48] for i in range(n)]
+    assert gpu.eth_aggregate_public_keys_status(pks) == (0, B.sk_to_pk(sum(sks) % B.R))
+    inf, zero, off = B.INFINITY_PUBLIC_KEY, bytes(48), syn.off_subgroup_public_key(5)
+    want_of = {inf: B.eth_aggregate_public_keys([inf])[0], zero: B.eth_aggregate_public_keys([zero])[0], off: B.eth_aggregate_public_keys([off])[0]}
+    assert len(set(want_of.values())) == 3
+    C_chunks = max(8, min(256, n // 1024))
+    per = (n + C_chunks - 1) // C_chunks
+    for pos, dmg in ((0, off), (per - 1, inf), (per, zero), (n - 1, off), (n // 2, inf)):
+        lst = list(pks)
+        lst[pos] = dmg
+        assert gpu.eth_aggregate_public_keys_status(lst)[0] == want_of[dmg], (n, pos)
+    lst = list(pks)
+    lst[per + 3], lst[per - 2], lst[n - 1] = zero, off, inf   # three damaged members in three chunks: the lowest index decides
+    assert gpu.eth_aggregate_public_keys_status(lst)[0] == want_of[off]
