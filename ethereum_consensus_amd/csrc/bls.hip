@@ -526,9 +526,14 @@ static const int g_side_overlap = [] {
 // ECGPU_H2C_FINISH_LANES=1: the one-lane (round 3) end of the small-batch message stage.  Default: the lane pair -- on a box
 // with slow instruction fetch as well (its hot loop, one 43 KB doubling, fits the instruction cache: a slot 11.0 -> 8.2 ms
 // there, profiles/r04slow_*).
-static const int g_h2c_finish_lanes = [] {  // (round 5 default: 16 = a row per message up to ECGPU_H2C_ROW_MAX messages, the lane pair above)
-    const char* e = getenv("ECGPU_H2C_FINISH_LANES");
-    return e ? atoi(e) : 16;
+static const int g_h2c_finish_lanes = [] {  // 16 (default) = a wave / a row pair per message up to ECGPU_H2C_QUAD_MAX / ECGPU_H2C_ROW_MAX messages, the lane
+    const char* e = getenv("ECGPU_H2C_FINISH_LANES");  // pair above; 2 = the lane pair at every size.  (1 = the one-lane end of round 3: experiments library only)
+    const int v = e ? atoi(e) : 16;
+#if defined(ECG_EXPERIMENTS)
+    return v;
+#else
+    return v == 1 ? 2 : v;
+#endif
 }();
 static const int g_row_stages = [] {  // ECGPU_ROW_STAGES=0: the SSWU maps and the signature's subgroup check stay on one lane each
     const char* e = getenv("ECGPU_ROW_STAGES");
@@ -538,9 +543,13 @@ static const u32 g_h2c_quad_max = [] {  // ECGPU_H2C_QUAD_MAX: up to this many m
     const char* e = getenv("ECGPU_H2C_QUAD_MAX");  // (0: always a row pair per message)
     return e ? (u32)strtoul(e, nullptr, 10) : 1024u;  // (768 / 1 024 messages: 1.42 ms against the row pair's 1.47-1.49, profiles/r05l_*)
 }();
-static const int g_row_decode = [] {  // ECGPU_ROW_DECODE=0: keys and signatures of a small batch are decoded on one lane each (their square roots
-    const char* e = getenv("ECGPU_ROW_DECODE");  // included), only the subgroup checks run on rows: the first form of round 5
+static const int g_row_decode = [] {  // (experiments library: ECGPU_ROW_DECODE=0 = keys and signatures of a small batch decoded on one lane each, only
+#if defined(ECG_EXPERIMENTS)           // the subgroup checks on rows: the first form of round 5)
+    const char* e = getenv("ECGPU_ROW_DECODE");
     return e ? atoi(e) : 1;
+#else
+    return 1;
+#endif
 }();
 static const u32 g_h2c_row_max = [] {
     const char* e = getenv("ECGPU_H2C_ROW_MAX");
@@ -667,10 +676,13 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
             if (g_row_stages && n_pks <= g_h2c_row_max) {  // (round 5) a few keys: a row each
                 if (g_row_decode) {  // ... square root included
                     launch_pk_row(s, d_pks48, n_pks, pts, st);
-                } else {             // ... the decoding on one lane (ECGPU_ROW_DECODE=0)
+                }
+#if defined(ECG_EXPERIMENTS)
+                else {               // ... the decoding on one lane (ECGPU_ROW_DECODE=0)
                     hipLaunchKernelGGL(k_pk_decode_w1, grid_for(n_pks), dim3(BLS_BLOCK), 0, s, d_pks48, n_pks, pts, st);
                     launch_pk_group_row(s, (const A1*)pts, n_pks, st);
                 }
+#endif
             } else {
                 launch_pk_validate(s, d_pks48, n_pks, pts, st);
             }
@@ -696,9 +708,11 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
                 launch_sig_row(s3, d_sigs96, n, sigpts, st_dec, st_grp);
                 return;
             }
+#if defined(ECG_EXPERIMENTS)
             hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_decode_calls : k_sig_decode, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts, st_dec);
             launch_sig_group_row(s3, (const A2*)sigpts, (const u8*)st_dec, n, st_grp);
             return;
+#endif
         }
         hipLaunchKernelGGL(g_tower.load() == 2 ? k_sig_calls : two_waves ? k_sig_w2 : k_sig, grid_for(n), dim3(BLS_BLOCK), 0, s3, d_sigs96, n, sigpts,
                            st_dec, st_grp);
@@ -717,8 +731,10 @@ static int fav_batch_device(hipStream_t s, const u8* d_pks48, const u32* d_pk_of
                 launch_h2c_finish_quad(s2, (const J2*)h2c_maps, n, hpts);  // (round 5, last) a wave per message while waves are free
             else if (g_h2c_finish_lanes == 16 && n <= g_h2c_row_max)
                 launch_h2c_finish_row(s2, (const J2*)h2c_maps, n, hpts);
+#if defined(ECG_EXPERIMENTS)
             else if (g_h2c_finish_lanes == 1)
                 hipLaunchKernelGGL(calls ? k_h2c_finish_calls : k_h2c_finish, grid_for(n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
+#endif
             else
                 hipLaunchKernelGGL(k_h2c_finish2, grid_for(2 * n), dim3(BLS_BLOCK), 0, s2, (const J2*)h2c_maps, n, hpts);
         } else {

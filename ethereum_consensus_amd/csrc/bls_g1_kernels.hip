@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_G1_OCCUPANCY) ECG_G1_KN(k_pk_va
     st[i] = s;
 }
 
-#if ECG_G1_WAVES == 1
+#if ECG_G1_WAVES == 1 && defined(ECG_EXPERIMENTS)  // (round 6: the first form of the row stages, like k_sig_decode)
 // the decoding alone (small batches: the subgroup check then runs on rows, bls_row_g2.hip k_pk_group_row): the status
 // key_validate would return before its group check
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_G1_OCCUPANCY) k_pk_decode_w1(const u8* pks48, u32 n, A1* pts, u8* st) {

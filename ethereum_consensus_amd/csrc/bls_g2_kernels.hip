@@ -23,6 +23,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig)(const 
     st_grp[i] = sg;
 }
 
+#if defined(ECG_EXPERIMENTS)  // (round 6) the first form of the row stages -- decoding on one lane, the subgroup check on rows -- is the
+                               // default at no size since k_sig_row: experiments library only
 // the decoding alone (small batches: the subgroup check then runs on rows, bls_row_g2.hip k_sig_group_row)
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig_decode)(const u8* sigs96, u32 n, A2* pts, u8* st_dec) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
@@ -32,6 +34,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_sig_decode)
     pts[i] = p;
     st_dec[i] = sd;
 }
+#endif
 
 // msg_off == nullptr: message i = msgs + 32 i (32 bytes)
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c)(const u8* msgs, const u64* msg_off, u32 n, A2* hpts) {
@@ -56,6 +59,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c_map)(co
     hash_to_g2_map(q, m, len, (int)(t & 1));
     maps[t] = q;
 }
+#if defined(ECG_EXPERIMENTS)  // (round 6) the one-lane end of the two-lane message stage (round 3): the lane pair took over in round 4, rows in
+                               // round 5 -- the default at no size on any box: experiments library only
 __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c_finish)(const J2* maps, u32 n, A2* hpts) {
     u32 i = blockIdx.x * BLS_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -64,5 +69,6 @@ __global__ void __launch_bounds__(BLS_BLOCK, ECG_BLS_WAVES) ECG_KN(k_h2c_finish)
     hash_to_g2_finish(h, q0, q1);
     hpts[i] = h;
 }
+#endif
 
 }  // namespace ecg

@@ -24,10 +24,8 @@ __global__ void k_pk_validate_w2(const u8* pks48, u32 n, A1* pts, u8* st);
 __global__ void k_sig(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
 __global__ void k_h2c(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
 __global__ void k_h2c_map(const u8* msgs, const u64* msg_off, u32 n, J2* maps);
-__global__ void k_h2c_finish(const J2* maps, u32 n, A2* hpts);
 __global__ void k_h2c_finish2(const J2* maps, u32 n, A2* hpts);  // bls_g2_pair2_kernels.hip: two lanes per message
 __global__ void k_h2c_map_calls(const u8* msgs, const u64* msg_off, u32 n, J2* maps);
-__global__ void k_h2c_finish_calls(const J2* maps, u32 n, A2* hpts);
 // bls_g2_kernels_w2.hip: room for two waves per SIMD (batches beyond 65 536 tuples)
 __global__ void k_sig_w2(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);
 __global__ void k_h2c_w2(const u8* msgs, const u64* msg_off, u32 n, A2* hpts);
@@ -40,13 +38,17 @@ __global__ void k_h2c_calls(const u8* msgs, const u64* msg_off, u32 n, A2* hpts)
 void launch_h2c_finish_row(hipStream_t s, const J2* maps, u32 n, A2* hpts);
 void launch_h2c_finish_quad(hipStream_t s, const J2* maps, u32 n, A2* hpts);  // one message per wave, doublings over both row pairs
 void launch_h2c_map_row(hipStream_t s, const u8* msgs, const u64* msg_off, u32 n, J2* maps);
-void launch_sig_group_row(hipStream_t s, const A2* pts, const u8* st_dec, u32 n, u8* st_grp);
-void launch_pk_group_row(hipStream_t s, const A1* pts, u32 n, u8* st);
 void launch_sig_row(hipStream_t s, const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp);  // decoding + group check on a row pair
 void launch_pk_row(hipStream_t s, const u8* pks48, u32 n, A1* pts, u8* st);                    // key_validate on a row
+#if defined(ECG_EXPERIMENTS)  // first forms that are the default at no size (round 6: experiments library only)
+__global__ void k_h2c_finish(const J2* maps, u32 n, A2* hpts);        // the one-lane end of the two-lane message stage (round 3)
+__global__ void k_h2c_finish_calls(const J2* maps, u32 n, A2* hpts);
+void launch_sig_group_row(hipStream_t s, const A2* pts, const u8* st_dec, u32 n, u8* st_grp);
+void launch_pk_group_row(hipStream_t s, const A1* pts, u32 n, u8* st);
 __global__ void k_pk_decode_w1(const u8* pks48, u32 n, A1* pts, u8* st);  // bls_g1_kernels.hip: decoding + infinity alone
 __global__ void k_sig_decode(const u8* sigs96, u32 n, A2* pts, u8* st_dec);  // bls_g2_kernels.hip: Signature::try_from alone
 __global__ void k_sig_decode_calls(const u8* sigs96, u32 n, A2* pts, u8* st_dec);
+#endif
 
 // bls_pairing_kernels.hip
 __global__ void k_pairing(const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,

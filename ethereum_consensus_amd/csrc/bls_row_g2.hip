@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(64) k_h2c_map_row(const u8* msgs, const u64* m
     const size_t len = msg_off ? (size_t)(msg_off[i + 1] - msg_off[i]) : 32;
     r_hash_to_g2_map(&maps[t], m, len, (int)(t & 1), tab[row]);
 }
+#if defined(ECG_EXPERIMENTS)  // (round 6) the first form of the row stages: subgroup checks of points decoded on one lane each
 // row t = signature t, already decoded (k_sig_decode): the psi subgroup check of verify (crypto/bls.rs:71,126)
 __global__ void __launch_bounds__(64) k_sig_group_row(const A2* pts, const u8* st_dec, u32 n, u8* st_grp) {
     const u32 row = threadIdx.x >> 4, i = blockIdx.x * 2 + (row >> 1);  // a row pair per signature
@@ -50,6 +51,13 @@ __global__ void __launch_bounds__(64) k_pk_group_row(const A1* pts, u32 n, u8* s
     if (st[i] != 0) return;  // (the decoder's verdict stands: bad encoding, not on the curve, x == 0, infinity)
     if (!r_g1_in_subgroup(&pts[i]) && (threadIdx.x & 15u) == 0) st[i] = ECGPU_POINT_NOT_IN_GROUP;
 }
+void launch_pk_group_row(hipStream_t s, const A1* pts, u32 n, u8* st) {
+    hipLaunchKernelGGL(k_pk_group_row, dim3((n + 3) / 4), dim3(64), 0, s, pts, n, st);
+}
+void launch_sig_group_row(hipStream_t s, const A2* pts, const u8* st_dec, u32 n, u8* st_grp) {
+    hipLaunchKernelGGL(k_sig_group_row, dim3((n + 1) / 2), dim3(64), 0, s, pts, st_dec, n, st_grp);
+}
+#endif
 // (round 5, last) decoding AND group check of a signature on a row pair, of a key on a row: the square roots -- two Fp
 // exponentiations for a signature, one for a key: 0.97 / 0.45 ms on one lane -- run on the row as the SSWU map's do
 __global__ void __launch_bounds__(64) k_sig_row(const u8* sigs96, u32 n, A2* pts, u8* st_dec, u8* st_grp) {
@@ -70,14 +78,8 @@ void launch_sig_row(hipStream_t s, const u8* sigs96, u32 n, A2* pts, u8* st_dec,
 void launch_pk_row(hipStream_t s, const u8* pks48, u32 n, A1* pts, u8* st) {
     hipLaunchKernelGGL(k_pk_row, dim3((n + 3) / 4), dim3(64), 0, s, pks48, n, pts, st);
 }
-void launch_pk_group_row(hipStream_t s, const A1* pts, u32 n, u8* st) {
-    hipLaunchKernelGGL(k_pk_group_row, dim3((n + 3) / 4), dim3(64), 0, s, pts, n, st);
-}
 void launch_h2c_map_row(hipStream_t s, const u8* msgs, const u64* msg_off, u32 n, J2* maps) {
     hipLaunchKernelGGL(k_h2c_map_row, dim3((2 * n + 3) / 4), dim3(64), 0, s, msgs, msg_off, n, maps);
-}
-void launch_sig_group_row(hipStream_t s, const A2* pts, const u8* st_dec, u32 n, u8* st_grp) {
-    hipLaunchKernelGGL(k_sig_group_row, dim3((n + 1) / 2), dim3(64), 0, s, pts, st_dec, n, st_grp);
 }
 void launch_h2c_finish_quad(hipStream_t s, const J2* maps, u32 n, A2* hpts) {
     hipLaunchKernelGGL(k_h2c_finish_quad, dim3(n), dim3(64), 0, s, maps, n, hpts);

@@ -785,8 +785,8 @@ def _random_dispatch_environment(r):
     pick = lambda *v: r.choice(v)
     env = {"ECGPU_TOWER": pick("sums", "sums", "calls"), "ECGPU_PAIRING": pick("auto", "auto", "auto", "lane", "vm3", "split", "row")}
     optional = {"ECGPU_VM_MAX": ("0", "1000", "13312", "40000"), "ECGPU_SPLIT_MAX": ("4096", "32768", "70000"), "ECGPU_SPLIT_DEFAULT": ("0", "1"),
-                "ECGPU_ROW_MAX": ("0", "64", "1024", "3000"), "ECGPU_ROW_STAGES": ("0", "1"), "ECGPU_ROW_DECODE": ("0", "1"), "ECGPU_H2C_QUAD_MAX": ("0", "100", "512", "5000"), "ECGPU_H2C_ROW_MAX": ("0", "100", "1024", "2500"),
-                "ECGPU_H2C_FINISH_LANES": ("1", "2", "16"), "ECGPU_H2C_SPLIT_MAX": ("0", "2000", "32768"), "ECGPU_H2C_SPLIT_KEYS_MAX": ("0", "4096"),
+                "ECGPU_ROW_MAX": ("0", "64", "1024", "3000"), "ECGPU_ROW_STAGES": ("0", "1"), "ECGPU_H2C_QUAD_MAX": ("0", "100", "512", "5000"), "ECGPU_H2C_ROW_MAX": ("0", "100", "1024", "2500"),
+                "ECGPU_H2C_FINISH_LANES": ("2", "16"), "ECGPU_H2C_SPLIT_MAX": ("0", "2000", "32768"), "ECGPU_H2C_SPLIT_KEYS_MAX": ("0", "4096"),
                 "ECGPU_G2_WAVES": ("1", "2"), "ECGPU_PK_WAVES": ("1", "2"),
                 "ECGPU_FORK_SMALL": ("0", "1"), "ECGPU_FORK_MAX": ("0", "1024", "32768"), "ECGPU_FORK_THREADS_MAX": ("0", "4"),
                 "ECGPU_RAGGED_TAIL": ("0", "1"), "ECGPU_AUX1_PRIORITY": ("0", "1")}
