@@ -59,6 +59,18 @@ fn backend_fault(rc: c_int) -> ! {
     panic!("ecgpu backend fault {rc}: {msg}");
 }
 
+/// What a host does once per process before the first verification (include/ecgpu.h `ecgpu_warmup`): real calls with the reference's
+/// fixed vector (crypto/bls.rs:530-544) -- the first call of a process costs ~52 ms otherwise, 2.3 ms after.  `batches`: also every
+/// larger dispatch class, timed, so that the library changes kernels at the batch sizes measured on THIS device (hosts that
+/// verify blocks and epochs).  The spec-test harness calls `warmup(false)` in its `main` (spec-tests/main.rs:114-124).
+pub fn warmup(batches: bool) {
+    let flags = 1 | 4 | if batches { 2 } else { 0 };
+    let rc = unsafe { sys::ecgpu_warmup(flags) };
+    if rc != 0 {
+        backend_fault(rc);
+    }
+}
+
 /// Status of a verify function -> the reference's `Result` (include/ecgpu.h, "Error identity"): 1, 2, 3, 6 were raised while
 /// CONVERTING a key or the signature (`TryFrom`, crypto/bls.rs:69-70,100-105,119-125) -> `Error::BLST`; everything else that
 /// is not success came out of blst's verify call -> `Error::InvalidSignature` (crypto/bls.rs:72-76,107-111,127-131); that
