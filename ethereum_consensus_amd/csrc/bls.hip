@@ -31,7 +31,13 @@
 
 namespace ecg {
 
-int init_bls_tables(hipStream_t) { return init_vm3_tables(); }
+// (advisor, round 5: the row machine's programs used to be remapped and uploaded -- a blocking copy and a hipMalloc -- inside the
+// first small-batch verification of a process; they are part of a device's initialisation now)
+int init_bls_tables(hipStream_t) {
+    int rc = init_vm3_tables();
+    if (!rc) rc = row_programs();
+    return rc;
+}
 
 // ---- stage kernels ---------------------------------------------------------------------------
 static inline dim3 grid_for(u32 n) { return dim3((n + BLS_BLOCK - 1) / BLS_BLOCK); }

@@ -24,6 +24,7 @@ int init_vm3_tables();
 size_t vm3_xfer_bytes(u32 n);
 // the same check with the programs executed by the ROW machine (bls_row.hip): one workgroup per tuple, one Fp operation per
 // 16-lane row -- the latency path of small batches
+int row_programs();  // the row machine's copy of the two programs on the calling thread's device (built once per device: at its initialisation)
 int row_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
                        const u8* st_grp, const u8* sigs96, u32 n, int eth_variant, u8* d_status, u32* xfer);
 int vm3_pairing_launch(hipStream_t s, const A1* agg, const u8* st_pk, const u32* pk_off, const A2* hpts, const A2* sigpts, const u8* st_dec,
