@@ -112,9 +112,29 @@ inline void state_offset_words(int fork, int preset, u64 out[N_STATE_VAR_FIELDS]
     for (int i = 0; i < N_STATE_VAR_FIELDS; i++) out[i] = w[i];
 }
 
+// the static part of the above for every (fork, preset, position), built once: a hook of the state transition is ONE call per
+// element written (rust/ecgpu-shim StateMirror) -- 8 192 of them per slot -- and must cost a table lookup, not a layout walk
+struct FieldTables {
+    FieldStatic f[FORK_LAST + 1][2][STATE_MAX_FIELD_CHUNKS];
+    u64 words[FORK_LAST + 1][2][N_STATE_VAR_FIELDS];
+    FieldTables() {
+        for (int fork = 0; fork <= FORK_LAST; fork++)
+            for (int preset = 0; preset < 2; preset++) {
+                for (u32 k = 0; k < STATE_MAX_FIELD_CHUNKS; k++) f[fork][preset][k] = field_static(fork, preset, k);
+                state_offset_words(fork, preset, words[fork][preset]);
+            }
+    }
+};
+inline const FieldTables& field_tables() {
+    static const FieldTables T;
+    return T;
+}
+
 // where field `field` lies in the encoding described by `h_fixed` (its fixed part) and `n_bytes` (its length) NOW
 inline bool locate_field(int fork, int preset, const u8* h_fixed, u64 n_bytes, u32 field, FieldLoc& out) {
-    const FieldStatic f = field_static(fork, preset, field);
+    if (preset < 0 || preset > 1 || fork < FORK_PHASE0 || fork > FORK_LAST || field >= STATE_MAX_FIELD_CHUNKS) return false;
+    const FieldTables& T = field_tables();
+    const FieldStatic& f = T.f[fork][preset][field];
     if (!f.present) return false;
     out = FieldLoc{};
     out.elem = f.elem;
@@ -122,8 +142,7 @@ inline bool locate_field(int fork, int preset, const u8* h_fixed, u64 n_bytes, u
         out.start = f.off, out.len = f.size;
         return true;
     }
-    u64 words[N_STATE_VAR_FIELDS];
-    state_offset_words(fork, preset, words);
+    const u64* words = T.words[fork][preset];
     if (words[f.var_index] == NO_FIELD) return false;
     out.variable = true;
     out.var_index = f.var_index;
@@ -158,6 +177,40 @@ struct FieldWriter {
     std::vector<Write> writes;
     std::vector<u8> blob;
     std::vector<u8> pushed[N_STATE_VAR_FIELDS];  // elements appended to list var_index since the last flush
+    // Which ELEMENTS of a field the queued writes touch: a bit per element, set when a write is queued.  A slot's 8 192 writes hit
+    // 8 192 different balances and flags: as long as no element of a field is touched twice its writes are disjoint as they
+    // stand and go to the sink as queued (30 ns each); only a field in which an element WAS touched twice (`collided`: two members
+    // of one validator record, the same balance written twice) is resolved by interval subtraction (flush_writes).  Conservative:
+    // every write marks every element it overlaps.
+    struct Marks {
+        std::vector<u64> bits;
+        std::vector<u32> touched;  // words of `bits` that are non-zero (to clear them without sweeping the bitmap)
+        bool collided = false;
+        void mark(u64 e0, u64 e1) {
+            if (collided) return;
+            if (e1 - e0 > 512) {  // (a long range: not worth a bit per element)
+                collided = true;
+                return;
+            }
+            if ((e1 >> 6) >= bits.size()) bits.resize((e1 >> 6) + 1 + (bits.size() >> 1), 0);
+            for (u64 e = e0; e <= e1; e++) {
+                u64& w = bits[e >> 6];
+                const u64 b = 1ull << (e & 63);
+                if (w & b) {
+                    collided = true;
+                    return;
+                }
+                if (!w) touched.push_back((u32)(e >> 6));
+                w |= b;
+            }
+        }
+        void clear() {
+            for (u32 w : touched) bits[w] = 0;
+            touched.clear();
+            collided = false;
+        }
+    };
+    Marks marks[STATE_MAX_FIELD_CHUNKS];
     static constexpr int BAD = -3;                // ECGPU_ERR_BAD_ARG
     static constexpr u64 DIRECT_BYTES = 1u << 16;  // a write this large is not copied into the queue: flush, then apply from where it lies
 
@@ -199,6 +252,8 @@ struct FieldWriter {
             const u64 o = loc.start + off, d[2] = {0, n};
             return s.apply_patches(&o, d, data, 1);
         }
+        const u64 gran = loc.elem ? loc.elem : 32;  // (any granularity is correct; the element's is the one without false collisions)
+        marks[field].mark(off / gran, (off + n - 1) / gran);
         writes.push_back({field, off, n, (u64)blob.size()});
         blob.insert(blob.end(), data, data + n);
         return 0;
@@ -249,6 +304,7 @@ struct FieldWriter {
         for (const Write& w : writes)
             if (w.field != field) keep_w.push_back(w);
         writes.swap(keep_w);
+        marks[field].clear();
         pushed[loc.var_index].clear();
         int rc = flush_writes(s);
         if (rc) return rc;
@@ -298,6 +354,7 @@ struct FieldWriter {
         writes.clear();
         blob.clear();
         for (auto& p : pushed) p.clear();
+        for (auto& m : marks) m.clear();
     }
 
     // the queued writes as ONE set of non-overlapping patches: where two writes cover the same byte the later one wins
@@ -309,51 +366,75 @@ struct FieldWriter {
         data_off.reserve(writes.size() + 1);
         data.reserve(blob.size());
         data_off.push_back(0);
-        std::map<u32, FieldLoc> locs;
-        std::map<u32, std::map<u64, u64>> covered;  // field -> disjoint [start, end) ranges already claimed by later writes
-        for (size_t k = writes.size(); k-- > 0;) {
-            const Write& w = writes[k];
-            auto it = locs.find(w.field);
-            if (it == locs.end()) {
-                FieldLoc loc;
-                if (!locate_field(s.fork(), s.preset(), s.fixed(), s.size(), w.field, loc)) return drop(), s.fail("field vanished"), BAD;
-                it = locs.emplace(w.field, loc).first;
+        FieldLoc locs[STATE_MAX_FIELD_CHUNKS];
+        bool located[STATE_MAX_FIELD_CHUNKS] = {};
+        auto loc_of = [&](u32 field, const FieldLoc*& out) {
+            if (!located[field]) {
+                if (!locate_field(s.fork(), s.preset(), s.fixed(), s.size(), field, locs[field])) return false;
+                located[field] = true;
             }
-            const FieldLoc& loc = it->second;
-            if (w.off + w.len > loc.len) return drop(), s.fail("queued write outside the field"), BAD;  // (cannot happen: checked when queued)
-            std::map<u64, u64>& cov = covered[w.field];
-            // pieces of [w.off, w.off + w.len) not in `cov`
-            u64 pos = w.off;
-            const u64 end = w.off + w.len;
-            auto c = cov.upper_bound(pos);
-            if (c != cov.begin()) {
-                auto p = std::prev(c);
-                if (p->second > pos) pos = p->second < end ? p->second : end;
+            out = &locs[field];
+            return true;
+        };
+        bool any_collided = false;
+        // fields whose elements were each touched at most once: the writes are disjoint as queued
+        for (const Write& w : writes) {
+            if (marks[w.field].collided) {
+                any_collided = true;
+                continue;
             }
-            while (pos < end) {
-                const u64 stop = (c != cov.end() && c->first < end) ? c->first : end;
-                if (stop > pos) {
-                    offsets.push_back(loc.start + pos);
-                    data.insert(data.end(), blob.begin() + (w.src + (pos - w.off)), blob.begin() + (w.src + (stop - w.off)));
-                    data_off.push_back(data.size());
+            const FieldLoc* loc;
+            if (!loc_of(w.field, loc)) return drop(), s.fail("field vanished"), BAD;
+            if (w.off + w.len > loc->len) return drop(), s.fail("queued write outside the field"), BAD;  // (cannot happen: checked when queued)
+            offsets.push_back(loc->start + w.off);
+            data.insert(data.end(), blob.begin() + w.src, blob.begin() + (w.src + w.len));
+            data_off.push_back(data.size());
+        }
+        // the others: newest first, each write gives the sink only the bytes no later write of the same field has claimed
+        if (any_collided) {
+            std::map<u32, std::map<u64, u64>> covered;  // field -> disjoint [start, end) ranges already claimed by later writes
+            for (size_t k = writes.size(); k-- > 0;) {
+                const Write& w = writes[k];
+                if (!marks[w.field].collided) continue;
+                const FieldLoc* locp;
+                if (!loc_of(w.field, locp)) return drop(), s.fail("field vanished"), BAD;
+                const FieldLoc& loc = *locp;
+                if (w.off + w.len > loc.len) return drop(), s.fail("queued write outside the field"), BAD;
+                std::map<u64, u64>& cov = covered[w.field];
+                // pieces of [w.off, w.off + w.len) not in `cov`
+                u64 pos = w.off;
+                const u64 end = w.off + w.len;
+                auto c = cov.upper_bound(pos);
+                if (c != cov.begin()) {
+                    auto p = std::prev(c);
+                    if (p->second > pos) pos = p->second < end ? p->second : end;
                 }
-                if (c == cov.end() || c->first >= end) break;
-                pos = c->second < end ? c->second : end;
-                ++c;
+                while (pos < end) {
+                    const u64 stop = (c != cov.end() && c->first < end) ? c->first : end;
+                    if (stop > pos) {
+                        offsets.push_back(loc.start + pos);
+                        data.insert(data.end(), blob.begin() + (w.src + (pos - w.off)), blob.begin() + (w.src + (stop - w.off)));
+                        data_off.push_back(data.size());
+                    }
+                    if (c == cov.end() || c->first >= end) break;
+                    pos = c->second < end ? c->second : end;
+                    ++c;
+                }
+                // claim [w.off, end): merge with what it touches
+                u64 lo = w.off, hi = end;
+                auto a = cov.lower_bound(lo);
+                if (a != cov.begin() && std::prev(a)->second >= lo) --a;
+                while (a != cov.end() && a->first <= hi) {
+                    if (a->first < lo) lo = a->first;
+                    if (a->second > hi) hi = a->second;
+                    a = cov.erase(a);
+                }
+                cov[lo] = hi;
             }
-            // claim [w.off, end): merge with what it touches
-            u64 lo = w.off, hi = end;
-            auto a = cov.lower_bound(lo);
-            if (a != cov.begin() && std::prev(a)->second >= lo) --a;
-            while (a != cov.end() && a->first <= hi) {
-                if (a->first < lo) lo = a->first;
-                if (a->second > hi) hi = a->second;
-                a = cov.erase(a);
-            }
-            cov[lo] = hi;
         }
         writes.clear();
         blob.clear();
+        for (auto& m : marks) m.clear();
         if (offsets.empty()) return 0;
         return s.apply_patches(offsets.data(), data_off.data(), data.data(), (u32)offsets.size());
     }
