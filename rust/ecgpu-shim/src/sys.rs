@@ -7,7 +7,10 @@ use std::os::raw::{c_char, c_int, c_void};
 pub const ECGPU_SUCCESS: c_int = 0;
 pub const ECGPU_IN_VERIFY: c_int = 0x40;
 pub const ECGPU_EMPTY_AGGREGATE: c_int = -100;
-pub const ECGPU_ERR_INVALID: c_int = -3;
+pub const ECGPU_ERR_NO_DEVICE: c_int = -1;
+pub const ECGPU_ERR_HIP: c_int = -2;
+pub const ECGPU_ERR_BAD_ARG: c_int = -3;
+pub const ECGPU_ERR_OOM: c_int = -4;
 // fork ids of the BeaconState entry points ({phase0,altair,bellatrix,capella,deneb}/beacon_state.rs)
 pub const ECGPU_FORK_PHASE0: c_int = 0;
 pub const ECGPU_FORK_ALTAIR: c_int = 1;

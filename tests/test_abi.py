@@ -108,3 +108,38 @@ def test_plain_c_caller_on_the_gpu():
     pk = B.sk_to_pk(C.CAN_SIGN_SK).hex()
     r = subprocess.run([exe, "gpu", root, pk, C.CAN_SIGN_SIG.hex(), C.CAN_SIGN_MSG.decode()], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+def test_ctypes_signatures_follow_the_header():
+    """ethereum_consensus_amd/_lib.py states every entry's argument and return types by hand: a c_uint32 where the header says
+    uint64_t still "works" for small values.  Every declared signature is compared with the header's prototype: arity, integer
+    width and signedness, pointer-ness."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_rust_bindings import header_prototypes, c_type
+    from ethereum_consensus_amd import _lib
+    L = _lib.load()
+    protos = header_prototypes()
+    scalar = {"i32": (ctypes.c_int, ctypes.c_int32), "u32": (ctypes.c_uint, ctypes.c_uint32), "u64": (ctypes.c_uint64, ctypes.c_ulong),
+              "i64": (ctypes.c_int64, ctypes.c_long), "usize": (ctypes.c_size_t,), "f64": (ctypes.c_double,)}
+
+    def agrees(ct, want):
+        base, depth, _ = want
+        if depth > 0:
+            return ct is not None and (ct in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(ct, "contents") or hasattr(ct, "_type_") and
+                                       isinstance(getattr(ct, "_type_"), type))
+        if base == "void":
+            return ct is None
+        return any(ct is c or (ct is not None and ctypes.sizeof(ct) == ctypes.sizeof(c) and ct._type_ == c._type_) for c in scalar[base])
+
+    checked = 0
+    for name, (c_ret, c_params) in protos.items():
+        fn = getattr(L, name)
+        if fn.argtypes is None:
+            continue  # not bound from Python (the Rust-only or C-only entries)
+        assert len(fn.argtypes) == len(c_params), (name, fn.argtypes, c_params)
+        for ct, c in zip(fn.argtypes, c_params):
+            assert agrees(ct, c_type(c)), (name, c, ct)
+        assert agrees(fn.restype, c_type(c_ret, is_param=False)), (name, c_ret, fn.restype)
+        checked += 1
+    assert checked >= 80, checked
