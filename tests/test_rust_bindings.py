@@ -142,3 +142,23 @@ def test_the_safe_wrappers_call_only_declared_functions():
     _, src = rust_externs()
     declared = set(re.findall(r"pub const (ECGPU_[A-Z0-9_]+)", src))
     assert not sorted(used_consts - declared), sorted(used_consts - declared)
+
+
+def test_the_patches_use_only_names_the_shim_defines():
+    """rust/patches/*.patch is what a maintainer applies to the reference: every `ecgpu_shim::…` path and every `m.<hook>(` of the
+    mirror it mentions must be a public item of the crate."""
+    import glob
+    shim = open(os.path.join(ROOT, "rust", "ecgpu-shim", "src", "lib.rs")).read() + open(os.path.join(ROOT, "rust", "ecgpu-shim", "src", "sys.rs")).read()
+    public = set(re.findall(r"pub (?:fn|struct|enum|mod|const|type)\s+([A-Za-z_][A-Za-z0-9_]*)", shim))
+    variants = set(re.findall(r"^\s+([A-Z][A-Za-z]+)(?:\(|,|\s*$)", shim, flags=re.M))
+    used_paths, used_hooks = set(), set()
+    for p in glob.glob(os.path.join(ROOT, "rust", "patches", "*.patch")):
+        text = "\n".join(l[1:] for l in open(p).read().splitlines() if l.startswith("+") and not l.startswith("+++"))
+        used_paths |= set(re.findall(r"ecgpu_shim((?:::[A-Za-z_][A-Za-z0-9_]*)+)", text))
+        used_hooks |= set(re.findall(r"\bm\.([a-z_]+)\(", text))
+    assert len(used_paths) >= 20 and len(used_hooks) >= 10
+    for path in used_paths:
+        for part in path.split("::")[1:]:
+            assert part in public or part in variants, (path, part)
+    for h in used_hooks:
+        assert re.search(r"pub fn %s\s*\(\s*&mut self" % h, shim), h
