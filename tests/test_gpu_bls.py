@@ -780,6 +780,24 @@ def test_sixteen_host_threads_first_calls_at_once_then_mixed_batches(mutated_wor
     assert res["ok"] and res["calls"]["tuples"] >= 16 * 3 * 5765, res
 
 
+def test_soak_verifying_threads_and_state_followers_together(mutated_workload):
+    """What one process of a node does: 8 threads verify (lone calls, small batches, collector flushes, epoch-size batches; host
+    keys and the validated-key registry) while 3 threads follow resident states of random forks through the field-addressed
+    entries and Merkleize chunk lists -- for 25 s, every status against the C++ oracle's verdict, every root against
+    oracle/ssz.py / the C restatement (tests/_soak.py; a 15-minute run of the same is profiles/r06m_soak.txt)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    path, info = mutated_workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "tests._soak", path, "25", "8", "3"], env=dict(os.environ, PYTHONPATH=root), cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-2500:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["counts"]["bls_calls"] >= 50 and res["counts"]["state_roots"] >= 20 and res["counts"]["merkleize"] >= 4, res
+
+
 def _random_dispatch_environment(r):
     """one assignment of the library's dispatch controls, each drawn from the values it documents"""
     pick = lambda *v: r.choice(v)
