@@ -165,7 +165,7 @@ def main():
                         loops.append((addr_index[tgt], i))
         for (s, e) in loops:
             body = lines[s:e + 1]
-            if len(body) < 200:
+            if len(body) < int(os.environ.get("CENSUS_MIN_LOOP", "200")):
                 continue
             print("    loop %6x..%6x [%4d KB]  " % (lines[s][0], lines[e][0], (lines[e][0] - lines[s][0]) // 1024) + fmt(census(body)))
 
