@@ -982,7 +982,10 @@ int ecgpu_registry_create(uint64_t capacity, ecgpu_registry_t** out) {
     ECG_HIP_CHECK(hipMalloc((void**)&r->pts, capacity * sizeof(A1)));
     ECG_HIP_CHECK(hipMalloc((void**)&r->st, capacity));
     // an index never set behaves like an undecodable key
-    ECG_HIP_CHECK(hipMemset(r->st, ECGPU_BAD_ENCODING, capacity));
+    // (asynchronous with respect to the host, on the null stream: waited for here, or a registry_set on the caller's non-blocking
+    // stream could be overtaken by it -- the same finding as state_tree.hip sync_geometry)
+    ECG_HIP_CHECK(hipMemsetAsync(r->st, ECGPU_BAD_ENCODING, capacity, nullptr));
+    ECG_HIP_CHECK(hipStreamSynchronize(nullptr));
     *out = r;
     return ECGPU_SUCCESS;
 }

@@ -153,7 +153,12 @@ int ResidentTrees::sync_geometry(const StatePlan& plan) {
     }
     if (!d_count) {
         ECG_HIP_CHECK(hipMalloc((void**)&d_count, 64));
-        ECG_HIP_CHECK(hipMemset(d_count, 0, 64));
+        // hipMemset on device memory is ASYNCHRONOUS with respect to the host and runs on the null stream, which the library's
+        // (non-blocking) streams do not wait for: on a busy device the first mark / climb of a new state could meet the counter
+        // before the zeros did -- an uninitialised count, garbage list entries, a memory violation in k_tree_climb (found by the
+        // round-6 soak: one fault per ~400 states created beside 16 verifying threads; tests/_soak.py, HISTORY.md round 6).
+        ECG_HIP_CHECK(hipMemsetAsync(d_count, 0, 64, nullptr));
+        ECG_HIP_CHECK(hipStreamSynchronize(nullptr));
     }
     if (!d_active) ECG_HIP_CHECK(hipMalloc((void**)&d_active, 4 * TREE_ACTIVE_CAP));
     return ECGPU_SUCCESS;
