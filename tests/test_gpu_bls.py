@@ -794,11 +794,12 @@ def test_soak_verifying_threads_and_state_followers_together(mutated_workload):
     # (short-lived states, every thread forking its side stages: the configuration in which the long runs found the one fault of the
     # round -- a new state's dirty-list counter zeroed on the null stream, which the library's non-blocking streams do not wait for;
     # one k_tree_climb memory violation per ~400 states created beside 16 verifying threads, none in 2 489 after the fix)
-    env = dict(os.environ, PYTHONPATH=root, SOAK_STATE_STEPS="6", ECGPU_FORK_THREADS_MAX="64")
+    env = dict(os.environ, PYTHONPATH=root, SOAK_STATE_STEPS="6", ECGPU_FORK_THREADS_MAX="64", SOAK_MISC_THREADS="2")
     out = subprocess.run([sys.executable, "-m", "tests._soak", path, "25", "8", "3"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-2500:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["ok"] and res["counts"]["bls_calls"] >= 50 and res["counts"]["state_roots"] >= 20 and res["counts"]["merkleize"] >= 4, res
+    assert res["counts"]["aggregate"] + res["counts"]["msm"] + res["counts"]["validators_root"] + res["counts"]["scratch_root"] >= 20, res
 
 
 def _random_dispatch_environment(r):
